@@ -1,0 +1,143 @@
+"""CPU tests: the oracle restatement (oracle/) against the golden vectors that
+oracle/make_golden.py produced from the REAL reference modules (imported from
+/root/reference in the build container).  The reference itself is not needed
+to run these tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dehaze1113_ref as o1113
+from oracle import freqsplit_ref, ssim_ref
+from oracle.detweights import det_input, fill_state_dict
+from oracle.vgg16_ref import Vgg16
+
+TOL = dict(rtol=2e-4, atol=2e-5)      # torch CPU conv summation order may differ across hosts
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_manifest_says_oracle_equals_reference(manifest):
+    for k, v in manifest["ref_vs_oracle_maxabs"].items():
+        assert v <= 1e-6, (k, v)
+    assert manifest["fdgan_numel_with_grad"] == 11803155
+    kat = manifest["kat"]
+    assert abs(kat["psnrssim"]["ssim"] - 0.9875573750475048) < 1e-12
+    assert abs(kat["psnrssim"]["psnr"] - 26.8562966261433) < 1e-10
+
+
+def test_fdgan_state_dict_surface():
+    g = o1113.FDGAN()
+    sd = g.state_dict()
+    assert len(sd) == 786 and sum(p.numel() for p in g.parameters()) == 13980691
+    assert tuple(sd["trans_block4.conv1.weight"].shape) == (768, 128, 1, 1)   # ConvT layout
+    for k in ("conv0.weight", "dense_block31.denselayer16.conv2.weight", "dense_norm31.weight",
+              "dense_block4.bn1.weight", "trans_block4.bn1.running_mean", "conv_refine4.bias",
+              "dense_block1.denselayer1.norm1.num_batches_tracked"):
+        assert k in sd
+    assert g.training
+
+
+def test_fdgan_forward_backward_matches_golden(golden_dir):
+    gold = _load(golden_dir, "fdgan_2x64.npz")
+    g = o1113.FDGAN()
+    fill_state_dict(g, seed=0)
+    x = det_input((2, 3, 64, 64), seed=1234).requires_grad_(True)
+    tgt = det_input((2, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
+    taps = {}
+    y = g(x, taps)
+    np.testing.assert_allclose(y.detach().numpy(), gold["y"], **TOL)
+    for k, v in taps.items():
+        np.testing.assert_allclose(v[:, ::4, ::4, ::4].numpy(), gold["tap__" + k], rtol=1e-3, atol=1e-4)
+    ((y - tgt) ** 2).mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), gold["dx"], rtol=2e-3, atol=1e-7)
+    params = dict(g.named_parameters())
+    for key in gold.files:
+        if key.startswith("grad__"):
+            p = params[key[6:].replace("__", ".")]
+            scale = np.abs(gold[key]).max() + 1e-12
+            assert np.abs(p.grad.numpy() - gold[key]).max() <= 2e-3 * scale, key
+    bufs = dict(g.named_buffers())
+    np.testing.assert_allclose(bufs["trans_block3.norm.running_var"].numpy(),
+                               gold["bn_rv__trans_block3__norm"], rtol=1e-4)
+    assert int(bufs["dense_block1.denselayer1.norm1.num_batches_tracked"]) == int(gold["nbt"]) == 1
+    assert params["conv0.weight"].grad is None and params["dense_block4.bn1.weight"].grad is None
+
+
+def test_fdgan_eval_mode_matches_golden(golden_dir):
+    gold = _load(golden_dir, "fdgan_2x64_eval.npz")
+    g = o1113.FDGAN().eval()
+    fill_state_dict(g, seed=0)
+    with torch.no_grad():
+        y = g(det_input((2, 3, 64, 64), seed=1234))
+    np.testing.assert_allclose(y.numpy(), gold["y"], **TOL)
+
+
+def test_dy_blocks_match_golden(golden_dir):
+    gold = _load(golden_dir, "dyblocks.npz")
+    b = o1113.BottleneckBlockdy(64, 32)
+    fill_state_dict(b, seed=3)
+    x = det_input((2, 64, 16, 16), seed=5, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y = b(x)
+    np.testing.assert_allclose(y.numpy(), gold["y_bottleneck"], **TOL)
+    np.testing.assert_array_equal(x.numpy(), gold["x_after"])          # in-place ReLU aliasing
+    assert (x >= 0).all()
+    t = o1113.TransitionBlockdy(96, 16)
+    fill_state_dict(t, seed=4)
+    with torch.no_grad():
+        z = t(y)
+    np.testing.assert_allclose(z.numpy(), gold["y_transition"], **TOL)
+    assert z.shape == (2, 16, 32, 32)
+
+
+def test_fusion_d_matches_golden(golden_dir):
+    gold = _load(golden_dir, "d_2x64.npz")
+    d = o1113.D(9, 36)
+    fill_state_dict(d, seed=1)
+    assert sum(p.numel() for p in d.parameters()) == 790416
+    x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0).requires_grad_(True)
+    y = d(x)
+    assert y.shape == (2, 1, 30, 30)
+    np.testing.assert_allclose(y.detach().numpy(), gold["y"], **TOL)
+    y.mean().backward()
+    np.testing.assert_allclose(x.grad.numpy(), gold["dx"], rtol=2e-3, atol=1e-9)
+
+
+def test_vgg16_matches_golden(golden_dir):
+    gold = _load(golden_dir, "vgg16_1x32.npz")
+    v = Vgg16()
+    fill_state_dict(v, seed=0)
+    assert sum(p.numel() for p in v.parameters()) == 14714688
+    with torch.no_grad():
+        feats = v(det_input((1, 3, 32, 32), seed=9))
+    assert [f.shape[1] for f in feats] == [64, 128, 256, 512]
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(f.numpy(), gold["relu%d" % i], **TOL)
+
+
+def test_ssim_known_answers(manifest):
+    a1, a2 = det_input((2, 3, 64, 64), seed=1), det_input((2, 3, 64, 64), seed=2)
+    kat = manifest["kat"]["pytorch_ssim"]
+    assert abs(ssim_ref.ssim(a1, a2).item() - kat["rand"][0]) < 1e-6
+    assert abs(ssim_ref.ssim(a1, a1 * 0.9 + 0.1 * a2).item() - kat["near"][0]) < 1e-6
+    assert ssim_ref.ssim(a1, a1).item() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_freqsplit_known_answers(golden_dir, manifest):
+    k = freqsplit_ref.isotropic_gaussian_kernel(15, 3.0)
+    assert abs(k.sum() - 1.0) < 1e-12
+    assert abs(k[7, 7] - 0.0181167153) < 1e-9 and abs(k[0, 0] - 7.8268549e-05) < 1e-12
+    c = torch.full((1, 3, 20, 20), 0.7)
+    assert (freqsplit_ref.blur(c, use_input_norm=False) - 0.7).abs().max() < 1e-6
+    lc = freqsplit_ref.laplacian(torch.ones(1, 3, 8, 8))
+    assert lc[0, 0, 3, 3] == 0 and lc[0, 0, 0, 0] == -5 and lc[0, 1, 0, 3] == -3
+    with pytest.raises(ValueError):
+        freqsplit_ref.laplacian(torch.ones(3, 8, 8))
+    gold = _load(golden_dir, "freqsplit.npz")
+    x = det_input((2, 3, 40, 48), seed=11)
+    np.testing.assert_allclose(freqsplit_ref.blur(x, use_input_norm=True).numpy(), gold["blur_norm"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(freqsplit_ref.laplacian(x).numpy(), gold["lap"], rtol=1e-4, atol=1e-5)
