@@ -1,0 +1,135 @@
+// capi.hip -- error state, the launch recorder (FdPlan) and library identity.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+static thread_local FdPlan* g_recording = nullptr;
+
+void fd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* fdgan_last_error(void) { return g_err; }
+extern "C" int fdgan_version(void) { return FDGAN_ABI_VERSION; }
+
+extern "C" const char* fdgan_device_arch(void) {
+  static thread_local char arch[256];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+  strncpy(arch, prop.gcnArchName, sizeof(arch) - 1);
+  arch[sizeof(arch) - 1] = 0;
+  return arch;
+}
+
+static int do_launch(const FdLaunch& L, hipStream_t stream) {
+  void* argv[1] = {const_cast<char*>(L.arg.data())};
+  hipError_t e = hipLaunchKernel(L.fn, L.grid, L.block, argv, L.shmem, stream);
+  if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "launch %s grid=(%u,%u,%u) block=%u lds=%u: %s", L.name, L.grid.x, L.grid.y,
+                               L.grid.z, L.block.x, L.shmem, hipGetErrorString(e));
+  return FD_OK;
+}
+
+int fd_enqueue(const void* fn, const char* name, dim3 grid, dim3 block, unsigned shmem, const void* arg,
+               size_t arg_bytes, hipStream_t stream) {
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) FD_FAIL(FD_EINVAL, "%s: empty grid", name);
+  FdLaunch L;
+  L.fn = fn;
+  L.name = name;
+  L.grid = grid;
+  L.block = block;
+  L.shmem = shmem;
+  L.arg.assign(static_cast<const char*>(arg), static_cast<const char*>(arg) + arg_bytes);
+  if (g_recording != nullptr) {
+    g_recording->launches.push_back(std::move(L));
+    return FD_OK;
+  }
+  return do_launch(L, stream);
+}
+
+extern "C" FdPlan* fdgan_plan_create(void) { return new (std::nothrow) FdPlan(); }
+
+extern "C" void fdgan_plan_destroy(FdPlan* p) {
+  if (!p) return;
+  if (g_recording == p) g_recording = nullptr;
+  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->graph) hipGraphDestroy(p->graph);
+  delete p;
+}
+
+extern "C" int fdgan_plan_begin(FdPlan* p) {
+  FD_REQUIRE(p, "plan_begin: NULL plan");
+  if (g_recording != nullptr) FD_FAIL(FD_ESTATE, "plan_begin: another plan is recording on this thread");
+  if (p->exec) FD_FAIL(FD_ESTATE, "plan_begin: plan already instantiated as a graph");
+  p->recording = true;
+  g_recording = p;
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_end(FdPlan* p) {
+  FD_REQUIRE(p, "plan_end: NULL plan");
+  if (g_recording != p) FD_FAIL(FD_ESTATE, "plan_end: this plan is not recording");
+  p->recording = false;
+  g_recording = nullptr;
+  return FD_OK;
+}
+
+extern "C" int64_t fdgan_plan_num_launches(const FdPlan* p) { return p ? (int64_t)p->launches.size() : -1; }
+
+extern "C" const char* fdgan_plan_kernel_name(const FdPlan* p, int64_t k) {
+  if (!p || k < 0 || k >= (int64_t)p->launches.size()) return nullptr;
+  return p->launches[(size_t)k].name;
+}
+
+extern "C" int fdgan_plan_launch(FdPlan* p, FdStream stream) {
+  FD_REQUIRE(p, "plan_launch: NULL plan");
+  if (p->recording) FD_FAIL(FD_ESTATE, "plan_launch: plan is still recording");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->exec) {
+    hipError_t e = hipGraphLaunch(p->exec, s);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+    return FD_OK;
+  }
+  for (const FdLaunch& L : p->launches) {
+    int rc = do_launch(L, s);
+    if (rc != FD_OK) return rc;
+  }
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream) {
+  FD_REQUIRE(p, "plan_instantiate_graph: NULL plan");
+  if (p->recording) FD_FAIL(FD_ESTATE, "plan_instantiate_graph: plan is still recording");
+  if (p->exec) return FD_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  int rc = FD_OK;
+  for (const FdLaunch& L : p->launches) {
+    rc = do_launch(L, s);
+    if (rc != FD_OK) break;
+  }
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(s, &g);
+  if (rc != FD_OK) {
+    if (g) hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    FD_FAIL(FD_ELAUNCH, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  p->graph = g;
+  p->exec = ex;
+  return FD_OK;
+}

@@ -1,0 +1,134 @@
+// conv_igemm.hip -- argument validation and the C-ABI entry points of the fused convolution.
+// Kernel: conv_igemm.h; instantiations: conv_k1.hip, conv_k3.hip, conv_k4.hip.
+#include "conv_igemm.h"
+
+static int conv_dispatch(ConvArgs& a, long long nimg, int cout_total, int ksize, int stride, bool pool,
+                         FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  switch (ksize) {
+    case 1: return conv_dispatch_k1(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
+    case 3: return conv_dispatch_k3(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
+    case 4: return conv_dispatch_k4(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
+  }
+  FD_FAIL(FD_EUNSUPPORTED, "no kernel for ksize=%d stride=%d", ksize, stride);
+}
+
+static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias, const FdPrologue* pro,
+                      const FdTensor* y, int cout, const FdStats* stats, const FdConvDesc* d, ConvArgs& a,
+                      long long& nimg, bool& pool) {
+  FD_REQUIRE(x && y && d, "conv2d: NULL tensor/descriptor");
+  FD_REQUIRE(x->dtype == FD_BF16, "conv2d: x must be NHWC bf16");
+  FD_REQUIRE(x->stride[3] == 1 && x->stride[2] % 8 == 0 && x->stride[1] % 8 == 0 && x->stride[0] % 8 == 0,
+             "conv2d: x strides must be channel-contiguous and multiples of 8 elements");
+  FD_REQUIRE(((uintptr_t)x->ptr & 15) == 0, "conv2d: x pointer must be 16-byte aligned");
+  FD_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "conv2d: ksize %d", d->ksize);
+  FD_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride %d", d->stride);
+  pool = pro && pro->pool2;
+  const long long hs = x->h, ws = x->w;
+  const long long hin = pool ? hs / 2 : hs, win = pool ? ws / 2 : ws;
+  const long long ho = (hin + 2 * d->pad - d->ksize) / d->stride + 1;
+  const long long wo = (win + 2 * d->pad - d->ksize) / d->stride + 1;
+  FD_REQUIRE(ho > 0 && wo > 0, "conv2d: empty output");
+  const int up = d->upsample2 ? 2 : 1;
+  FD_REQUIRE(y->n == x->n && y->h == ho * up && y->w == wo * up,
+             "conv2d: y is %lldx%lldx%lld, expected %lldx%lldx%lld", (long long)y->n, (long long)y->h,
+             (long long)y->w, (long long)x->n, ho * up, wo * up);
+  FD_REQUIRE(x->stride[1] * hs < (1ll << 31) && y->stride[1] * y->h < (1ll << 31),
+             "conv2d: one image exceeds 2^31 elements");
+  FD_REQUIRE(x->stride[1] < (1ll << 31) && x->stride[2] < (1ll << 31), "conv2d: stride overflow");
+  a = ConvArgs{};
+  a.x = static_cast<const unsigned short*>(x->ptr);
+  a.x_sn = x->stride[0];
+  a.x_sh = (int)x->stride[1];
+  a.x_sw = (int)x->stride[2];
+  a.Hs = (int)hs;
+  a.Ws = (int)ws;
+  a.Cin = (int)x->c;
+  a.Cin8 = (int)((x->c + 7) / 8);
+  a.nchunk = (int)((x->c + 31) / 32);
+  FD_REQUIRE(x->stride[2] >= a.Cin8 * 8 || x->w == 1, "conv2d: pixel pitch %lld < padded Cin %d",
+             (long long)x->stride[2], a.Cin8 * 8);
+  a.w = static_cast<const unsigned short*>(w_packed);
+  a.ntile_total = (cout + 15) / 16;
+  a.CoutW = cout;
+  a.bias = bias;
+  a.pro_mode = 0;
+  a.p_act = FD_ACT_NONE;
+  if (pro) {
+    FD_REQUIRE(pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU || pro->act == FD_ACT_LEAKY02,
+               "conv2d: prologue activation %d", pro->act);
+    a.p_act = pro->act;
+    if (pro->mean) {
+      FD_REQUIRE(pro->var, "conv2d: prologue mean without var");
+      a.pro_mode = 2;
+      a.p_mean = pro->mean;
+      a.p_var = pro->var;
+      a.p_gamma = pro->gamma;
+      a.p_beta = pro->beta;
+      a.eps = pro->eps;
+      a.momentum = pro->momentum;
+      a.run_mean = pro->running_mean;
+      a.run_var = pro->running_var;
+      a.nbt = reinterpret_cast<long long*>(pro->num_batches_tracked);
+      FD_REQUIRE(!pro->running_mean || pro->running_var, "conv2d: running_mean without running_var");
+      a.unbias = pro->count > 1 ? (float)((double)pro->count / (double)(pro->count - 1)) : 1.f;
+    } else if (pro->act != FD_ACT_NONE || pool) {
+      a.pro_mode = 1;
+    }
+  }
+  a.y = y->ptr;
+  a.Ho = (int)ho;
+  a.Wo = (int)wo;
+  a.Cout = (int)y->c;
+  FD_REQUIRE(y->c <= ((cout + 15) / 16) * 16 && y->c >= 1, "conv2d: y->c=%lld vs cout=%d", (long long)y->c, cout);
+  a.e_act = d->epilogue_act;
+  a.upsample = d->upsample2 ? 1 : 0;
+  a.pad = d->pad;
+  if (y->dtype == FD_F32) {
+    // NCHW fp32: strides given as n, h, w, c element strides
+    a.out_nchw_f32 = 1;
+    a.y_sn = y->stride[0];
+    a.y_sh = (int)y->stride[1];
+    a.y_sw = (int)y->stride[2];
+    a.y_sc = y->stride[3];
+  } else {
+    FD_REQUIRE(y->dtype == FD_BF16, "conv2d: y dtype %d", y->dtype);
+    FD_REQUIRE(y->stride[3] == 1 && y->stride[2] % 4 == 0 && y->stride[1] % 4 == 0 && y->stride[0] % 4 == 0,
+               "conv2d: y strides must be channel-contiguous, multiples of 4 elements");
+    FD_REQUIRE(((uintptr_t)y->ptr & 7) == 0, "conv2d: y pointer must be 8-byte aligned");
+    a.out_nchw_f32 = 0;
+    a.y_sn = y->stride[0];
+    a.y_sh = (int)y->stride[1];
+    a.y_sw = (int)y->stride[2];
+    a.y_sc = 1;
+  }
+  a.stats = stats ? stats->partial : nullptr;
+  nimg = x->n;
+  return FD_OK;
+}
+
+extern "C" int fdgan_conv2d_fwd_info(const FdTensor* x, const FdTensor* y, int cout, const FdConvDesc* d,
+                                     const FdPrologue* pro, FdConvInfo* info) {
+  FD_REQUIRE(info, "conv2d_fwd_info: NULL info");
+  ConvArgs a;
+  long long nimg;
+  bool pool;
+  int rc = conv_setup(x, nullptr, nullptr, pro, y, cout, nullptr, d, a, nimg, pool);
+  if (rc != FD_OK) return rc;
+  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, info, -1, true, nullptr);
+}
+
+extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const float* bias,
+                                const FdPrologue* pro, const FdTensor* y, const FdStats* stats,
+                                const FdConvDesc* d, FdStream stream) {
+  FD_REQUIRE(w_packed, "conv2d_fwd: NULL weights");
+  FD_REQUIRE(((uintptr_t)w_packed & 15) == 0, "conv2d_fwd: packed weights must be 16-byte aligned");
+  ConvArgs a;
+  long long nimg;
+  bool pool;
+  FD_REQUIRE(d && y, "conv2d_fwd: NULL descriptor/output");
+  const int cout = d->cout > 0 ? d->cout : (int)y->c;
+  int rc = conv_setup(x, w_packed, bias, pro, y, cout, stats, d, a, nimg, pool);
+  if (rc != FD_OK) return rc;
+  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, nullptr,
+                       stats ? stats->capacity_floats : -1, false, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,17 @@
+// 4x4 convolutions of the discriminators (stride 2 and stride 1, dehaze1113.py:196,214,222).
+#include "conv_igemm.h"
+
+int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
+                     long long stats_cap, bool dry, hipStream_t stream) {
+  const bool narrow = cout_total <= 32;
+  if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
+  if (stride == 1) {
+    if (narrow) FD_CONV_DISPATCH(4, 1, 0, 4, 2, 4, 1, 4, "conv4x4_bn32");
+    FD_CONV_DISPATCH(4, 1, 0, 4, 8, 4, 1, 1, "conv4x4_bn128");
+  }
+  if (stride == 2) {
+    if (narrow) FD_CONV_DISPATCH(4, 2, 0, 2, 2, 4, 1, 4, "conv4x4s2_bn32");
+    FD_CONV_DISPATCH(4, 2, 0, 2, 8, 4, 1, 1, "conv4x4s2_bn128");
+  }
+  FD_FAIL(FD_EUNSUPPORTED, "4x4 conv with stride %d", stride);
+}

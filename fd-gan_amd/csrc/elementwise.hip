@@ -1,0 +1,266 @@
+// elementwise.hip -- the small HBM-bound kernels around the convolutions:
+// weight packing, train-mode BatchNorm statistics finalisation, layout conversion,
+// channel-slice copy.  gfx950; 16-byte vector accesses wherever the layout allows.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------
+// weight packing: fp32 OIHW / IOHW -> bf16 MFMA fragment order
+//   packed[((chunk*KK + tap)*ntile + tile)*512 + lane*8 + e]
+//     = W[cout = tile*16 + (lane&15)][cin = chunk*32 + (lane>>4)*8 + e][tap]
+// ---------------------------------------------------------------------------------
+struct PackArgs {
+  const float* w;
+  unsigned short* out;
+  int cout, cin, kk, ks, ntile, nchunk, transposed, flip;
+  long long nunits;
+};
+
+__global__ void pack_weight_kernel(PackArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.nunits) return;
+  const int lane = (int)(u & 63);
+  long long r = u >> 6;
+  const int tile = (int)(r % a.ntile);
+  r /= a.ntile;
+  const int tap = (int)(r % a.kk);
+  const int chunk = (int)(r / a.kk);
+  const int co = tile * 16 + (lane & 15);
+  const int ci0 = chunk * 32 + (lane >> 4) * 8;
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ci0 + e;
+    float x = 0.f;
+    if (co < a.cout && ci < a.cin) {
+      // logical filter F[co][ci][tap]; source tensor S is OIHW (or IOHW if transposed).
+      // flip: F[co][ci][tap] = S'[ci][co][kk-1-tap] (data-gradient filter)
+      int o = co, i = ci, t = tap;
+      if (a.flip) {
+        o = ci;
+        i = co;
+        t = a.kk - 1 - tap;
+      }
+      const int d0 = a.flip ? a.cin : a.cout, d1 = a.flip ? a.cout : a.cin;  // S' logical dims (O', I')
+      long long idx = a.transposed ? ((long long)i * d0 + o) * a.kk + t : ((long long)o * d1 + i) * a.kk + t;
+      x = a.w[idx];
+    }
+    v[e] = x;
+  }
+  *reinterpret_cast<u32x4*>(a.out + u * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+}
+
+extern "C" size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize) {
+  if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;
+  const size_t ntile = (cout + 15) / 16, nchunk = (cin + 31) / 32;
+  return nchunk * (size_t)ksize * ksize * ntile * 1024;
+}
+
+extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
+                                      void* packed, size_t packed_bytes, FdStream stream) {
+  FD_REQUIRE(w && packed, "pack_conv_weight: NULL pointer");
+  FD_REQUIRE(cout > 0 && cin > 0 && ksize > 0, "pack_conv_weight: bad shape");
+  FD_REQUIRE(packed_bytes >= fdgan_packed_weight_bytes(cout, cin, ksize), "pack_conv_weight: buffer too small");
+  FD_REQUIRE(((uintptr_t)packed & 15) == 0, "pack_conv_weight: packed must be 16-byte aligned");
+  PackArgs a;
+  a.w = w;
+  a.out = static_cast<unsigned short*>(packed);
+  a.cout = cout;
+  a.cin = cin;
+  a.ks = ksize;
+  a.kk = ksize * ksize;
+  a.ntile = (cout + 15) / 16;
+  a.nchunk = (cin + 31) / 32;
+  a.transposed = transposed;
+  a.flip = flip;
+  a.nunits = (long long)a.nchunk * a.kk * a.ntile * 64;
+  const unsigned nb = (unsigned)((a.nunits + 255) / 256);
+  return fd_launch(&pack_weight_kernel, "pack_weight", dim3(nb), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNorm statistics: partial[rows][cpad][2] -> mean, biased var
+// (nn.BatchNorm2d train mode).  One workgroup per 32 channels;
+// 8 row groups x 32 channels; accumulation in fp64.
+// ---------------------------------------------------------------------------------
+struct BnFinArgs {
+  const float* partial;
+  long long rows, cpad, channels;
+  double inv_count;
+  float *mean, *var;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const long long c = (long long)blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < a.channels) {
+    const float2* p = reinterpret_cast<const float2*>(a.partial) + c;
+    long long r = rg;
+    for (; r + 24 < a.rows; r += 32) {  // 4 independent loads in flight
+      const float2 v0 = p[r * a.cpad], v1 = p[(r + 8) * a.cpad], v2 = p[(r + 16) * a.cpad], v3 = p[(r + 24) * a.cpad];
+      s1 += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+      s2 += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+    }
+    for (; r < a.rows; r += 8) {
+      const float2 v = p[r * a.cpad];
+      s1 += v.x;
+      s2 += v.y;
+    }
+  }
+  sh[0][rg][cl] = s1;
+  sh[1][rg][cl] = s2;
+  __syncthreads();
+  if (rg == 0 && c < a.channels) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      t1 += sh[0][g][cl];
+      t2 += sh[1][g][cl];
+    }
+    const double mean = t1 * a.inv_count;
+    double var = t2 * a.inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    a.mean[c] = (float)mean;
+    a.var[c] = (float)var;
+  }
+}
+
+extern "C" int fdgan_bn_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels,
+                                 int64_t count, float* mean, float* var, FdStream stream) {
+  FD_REQUIRE(partial && mean && var, "bn_finalize: NULL pointer");
+  FD_REQUIRE(rows > 0 && channels > 0 && cpad >= channels && count > 0, "bn_finalize: bad sizes");
+  BnFinArgs a{partial, rows, cpad, channels, 1.0 / (double)count, mean, var};
+  return fd_launch(&bn_finalize_kernel, "bn_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC bf16 (zero-padded channels); one thread per (pixel, 8-channel group)
+// ---------------------------------------------------------------------------------
+struct ToNhwcArgs {
+  const float* x;
+  unsigned short* y;
+  long long n, c, h, w, y_sn, y_sh, y_sw;
+  int groups;  // 8-channel groups to write per pixel
+  long long total;
+};
+
+__global__ void nchw_to_nhwc_kernel(ToNhwcArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  // pixel-fastest so the fp32 plane reads are coalesced
+  long long r = u;
+  const long long px = r % a.w;
+  r /= a.w;
+  const long long py = r % a.h;
+  r /= a.h;
+  const int g = (int)(r % a.groups);
+  const long long n = r / a.groups;
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const long long c = g * 8 + e;
+    v[e] = c < a.c ? a.x[((n * a.c + c) * a.h + py) * a.w + px] : 0.f;
+  }
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) =
+      __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+}
+
+extern "C" int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
+                                           const FdTensor* y, FdStream stream) {
+  FD_REQUIRE(x && y && y->ptr, "nchw_f32_to_nhwc_bf16: NULL pointer");
+  FD_REQUIRE(y->dtype == FD_BF16 && y->stride[3] == 1, "nchw_f32_to_nhwc_bf16: y must be NHWC bf16");
+  FD_REQUIRE(y->n == n && y->h == h && y->w == w && y->c >= c && y->c % 8 == 0,
+             "nchw_f32_to_nhwc_bf16: y shape mismatch (y->c must be a multiple of 8 >= c)");
+  FD_REQUIRE(y->stride[2] % 8 == 0 && y->stride[1] % 8 == 0 && y->stride[0] % 8 == 0 && ((uintptr_t)y->ptr & 15) == 0,
+             "nchw_f32_to_nhwc_bf16: y alignment");
+  ToNhwcArgs a;
+  a.x = x;
+  a.y = static_cast<unsigned short*>(y->ptr);
+  a.n = n;
+  a.c = c;
+  a.h = h;
+  a.w = w;
+  a.y_sn = y->stride[0];
+  a.y_sh = y->stride[1];
+  a.y_sw = y->stride[2];
+  a.groups = (int)(y->c / 8);
+  a.total = n * a.groups * h * w;
+  return fd_launch(&nchw_to_nhwc_kernel, "nchw_f32_to_nhwc_bf16", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
+                   0, a, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// NHWC bf16 -> NCHW fp32; one thread per (n, c, pixel): coalesced fp32 writes
+// ---------------------------------------------------------------------------------
+struct ToNchwArgs {
+  const unsigned short* x;
+  float* y;
+  long long n, c, h, w, x_sn, x_sh, x_sw;
+  long long total;
+};
+
+__global__ void nhwc_to_nchw_kernel(ToNchwArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  const long long px = r % a.w;
+  r /= a.w;
+  const long long py = r % a.h;
+  r /= a.h;
+  const long long c = r % a.c;
+  const long long n = r / a.c;
+  const unsigned short b = a.x[n * a.x_sn + py * a.x_sh + px * a.x_sw + c];
+  a.y[u] = __uint_as_float((unsigned)b << 16);
+}
+
+extern "C" int fdgan_nhwc_bf16_to_nchw_f32(const FdTensor* x, float* y, FdStream stream) {
+  FD_REQUIRE(x && x->ptr && y, "nhwc_bf16_to_nchw_f32: NULL pointer");
+  FD_REQUIRE(x->dtype == FD_BF16 && x->stride[3] == 1, "nhwc_bf16_to_nchw_f32: x must be NHWC bf16");
+  ToNchwArgs a{static_cast<const unsigned short*>(x->ptr), y, x->n, x->c, x->h, x->w,
+               x->stride[0], x->stride[1], x->stride[2], x->n * x->c * x->h * x->w};
+  return fd_launch(&nhwc_to_nchw_kernel, "nhwc_bf16_to_nchw_f32", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
+                   0, a, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// channel-slice copy between NHWC bf16 views (16 B per thread)
+// ---------------------------------------------------------------------------------
+struct CopyArgs {
+  const unsigned short* s;
+  unsigned short* d;
+  long long h, w, s_sn, s_sh, s_sw, d_sn, d_sh, d_sw;
+  int groups;
+  long long total;
+};
+
+__global__ void copy_nhwc_kernel(CopyArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  const int g = (int)(r % a.groups);
+  r /= a.groups;
+  const long long px = r % a.w;
+  r /= a.w;
+  const long long py = r % a.h;
+  const long long n = r / a.h;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(a.s + n * a.s_sn + py * a.s_sh + px * a.s_sw + g * 8);
+  *reinterpret_cast<u32x4*>(a.d + n * a.d_sn + py * a.d_sh + px * a.d_sw + g * 8) = v;
+}
+
+extern "C" int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream) {
+  FD_REQUIRE(src && dst && src->ptr && dst->ptr, "copy_nhwc: NULL pointer");
+  FD_REQUIRE(src->dtype == FD_BF16 && dst->dtype == FD_BF16 && src->stride[3] == 1 && dst->stride[3] == 1,
+             "copy_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(src->n == dst->n && src->h == dst->h && src->w == dst->w && src->c == dst->c && src->c % 8 == 0,
+             "copy_nhwc: shape mismatch or c not a multiple of 8");
+  FD_REQUIRE((((uintptr_t)src->ptr | (uintptr_t)dst->ptr) & 15) == 0, "copy_nhwc: 16-byte alignment");
+  for (int i = 0; i < 3; ++i)
+    FD_REQUIRE(src->stride[i] % 8 == 0 && dst->stride[i] % 8 == 0, "copy_nhwc: strides must be multiples of 8");
+  CopyArgs a{static_cast<const unsigned short*>(src->ptr), static_cast<unsigned short*>(dst->ptr), src->h, src->w,
+             src->stride[0], src->stride[1], src->stride[2], dst->stride[0], dst->stride[1], dst->stride[2],
+             (int)(src->c / 8), src->n * src->h * src->w * (src->c / 8)};
+  return fd_launch(&copy_nhwc_kernel, "copy_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,193 @@
+"""Host-side engine: device buffers (torch tensors as raw memory), NHWC views, thin
+wrappers of the C-ABI ops and the plan recorder used by the nn.Module surface.
+
+Nothing here computes: every function marshals pointers/sizes into
+libfdgan_hip.so.  torch provides the allocator and the current HIP stream only.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("%s: the FD-GAN HIP path needs a tensor on an MI355X (`cuda`) device; "
+                           "there is no CPU fallback" % what)
+
+
+class View:
+    """Channel slice [c0, c0+c) of an NHWC bf16 buffer of shape (N,H,W,C)."""
+    __slots__ = ("buf", "c0", "c", "fd")
+
+    def __init__(self, buf, c0=0, c=None):
+        assert buf.dtype == torch.bfloat16 and buf.dim() == 4 and buf.is_contiguous()
+        n, h, w, ctot = buf.shape
+        c = ctot - c0 if c is None else c
+        assert 0 <= c0 and c0 + c <= ctot and c > 0
+        self.buf, self.c0, self.c = buf, c0, c
+        t = L.FdTensor()
+        t.ptr = buf.data_ptr() + 2 * c0
+        t.n, t.h, t.w, t.c = n, h, w, c
+        t.stride[0], t.stride[1], t.stride[2], t.stride[3] = h * w * ctot, w * ctot, ctot, 1
+        t.dtype = L.FD_BF16
+        self.fd = t
+
+    @property
+    def shape(self):
+        n, h, w, _ = self.buf.shape
+        return n, h, w, self.c
+
+    def torch_nchw(self):
+        """fp32 NCHW copy (debug / tests)."""
+        return self.buf[..., self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
+
+
+def nchw_f32_view(t):
+    """FdTensor describing a contiguous NCHW fp32 torch tensor (strides n,h,w,c)."""
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4
+    n, c, h, w = t.shape
+    fd = L.FdTensor()
+    fd.ptr = t.data_ptr()
+    fd.n, fd.h, fd.w, fd.c = n, h, w, c
+    fd.stride[0], fd.stride[1], fd.stride[2], fd.stride[3] = c * h * w, w, 1, h * w
+    fd.dtype = L.FD_F32
+    return fd
+
+
+def new_act(n, h, w, c, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((n, h, w, c), dtype=torch.bfloat16, device=device)
+
+
+class PackedWeight:
+    """bf16 MFMA-fragment image of one conv filter + the recipe to refresh it."""
+
+    def __init__(self, param, cout, cin, k, transposed=False, flip=False):
+        lib = L.load()
+        self.param, self.cout, self.cin, self.k = param, cout, cin, k
+        self.transposed, self.flip = int(transposed), int(flip)
+        self.nbytes = lib.fdgan_packed_weight_bytes(cout, cin, k)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=param.device)
+
+    def pack(self):
+        lib = L.load()
+        p = self.param.detach()
+        assert p.dtype == torch.float32 and p.is_contiguous()
+        L.check(lib.fdgan_pack_conv_weight(p.data_ptr(), self.cout, self.cin, self.k, self.transposed, self.flip,
+                                           self.buf.data_ptr(), self.nbytes, stream_ptr()), "pack_conv_weight")
+
+
+def make_prologue(act=L.ACT_NONE, pool=False, mean=None, var=None, gamma=None, beta=None, eps=1e-5,
+                  momentum=0.1, running_mean=None, running_var=None, nbt=None, count=0):
+    p = L.FdPrologue()
+    p.mean = mean.data_ptr() if mean is not None else None
+    p.var = var.data_ptr() if var is not None else None
+    p.gamma = gamma.data_ptr() if gamma is not None else None
+    p.beta = beta.data_ptr() if beta is not None else None
+    p.eps, p.act, p.pool2, p.momentum = eps, act, int(bool(pool)), momentum
+    p.running_mean = running_mean.data_ptr() if running_mean is not None else None
+    p.running_var = running_var.data_ptr() if running_var is not None else None
+    p.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
+    p.count = count
+    return p
+
+
+def conv_desc(k, stride=1, pad=0, e_act=L.ACT_NONE, upsample=False, cout=0):
+    d = L.FdConvDesc()
+    d.ksize, d.stride, d.pad, d.epilogue_act, d.upsample2, d.cout = k, stride, pad, e_act, int(bool(upsample)), cout
+    return d
+
+
+def conv_info(x_fd, y_fd, cout, desc, pro=None):
+    info = L.FdConvInfo()
+    L.check(L.load().fdgan_conv2d_fwd_info(C.byref(x_fd), C.byref(y_fd), cout, C.byref(desc),
+                                           C.byref(pro) if pro is not None else None, C.byref(info)), "conv2d_fwd_info")
+    return info
+
+
+def conv2d(x_fd, w, bias, pro, y_fd, desc, stats_buf=None):
+    """Enqueue (or record) one fused convolution.  Returns FdConvInfo when stats are produced."""
+    lib = L.load()
+    st, info = None, None
+    if stats_buf is not None:
+        st = L.FdStats()
+        st.partial, st.capacity_floats = stats_buf.data_ptr(), stats_buf.numel()
+        info = conv_info(x_fd, y_fd, desc.cout if desc.cout else y_fd.c, desc, pro)
+    L.check(lib.fdgan_conv2d_fwd(C.byref(x_fd), w.buf.data_ptr() if isinstance(w, PackedWeight) else w,
+                                 bias.data_ptr() if bias is not None else None,
+                                 C.byref(pro) if pro is not None else None, C.byref(y_fd),
+                                 C.byref(st) if st is not None else None, C.byref(desc), stream_ptr()), "conv2d_fwd")
+    return info
+
+
+def bn_finalize(stats_buf, info, channels, count, mean, var, c0=0):
+    """mean/var are fp32 tensors; results land at [c0, c0+channels)."""
+    L.check(L.load().fdgan_bn_finalize(stats_buf.data_ptr(), info.stats_rows, info.stats_cpad, channels, count,
+                                       mean.data_ptr() + 4 * c0, var.data_ptr() + 4 * c0, stream_ptr()), "bn_finalize")
+
+
+def to_nhwc(x_nchw_f32, view):
+    n, c, h, w = x_nchw_f32.shape
+    L.check(L.load().fdgan_nchw_f32_to_nhwc_bf16(x_nchw_f32.data_ptr(), n, c, h, w, C.byref(view.fd), stream_ptr()),
+            "nchw_f32_to_nhwc_bf16")
+
+
+def to_nchw(view, out_f32):
+    L.check(L.load().fdgan_nhwc_bf16_to_nchw_f32(C.byref(view.fd), out_f32.data_ptr(), stream_ptr()),
+            "nhwc_bf16_to_nchw_f32")
+
+
+def copy_nhwc(src, dst):
+    L.check(L.load().fdgan_copy_nhwc(C.byref(src.fd), C.byref(dst.fd), stream_ptr()), "copy_nhwc")
+
+
+class Plan:
+    """RAII wrapper of FdPlan: `with plan.record(): <op calls>` then plan.launch()."""
+
+    def __init__(self):
+        self.lib = L.load()
+        self.h = C.c_void_p(self.lib.fdgan_plan_create())
+        if not self.h:
+            raise MemoryError("fdgan_plan_create")
+        self.graph = False
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.fdgan_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    class _Rec:
+        def __init__(self, plan):
+            self.plan = plan
+
+        def __enter__(self):
+            L.check(self.plan.lib.fdgan_plan_begin(self.plan.h), "plan_begin")
+
+        def __exit__(self, *exc):
+            L.check(self.plan.lib.fdgan_plan_end(self.plan.h), "plan_end")
+            return False
+
+    def record(self):
+        return Plan._Rec(self)
+
+    def launch(self):
+        L.check(self.lib.fdgan_plan_launch(self.h, stream_ptr()), "plan_launch")
+
+    def instantiate_graph(self):
+        L.check(self.lib.fdgan_plan_instantiate_graph(self.h, stream_ptr()), "plan_instantiate_graph")
+        self.graph = True
+
+    def __len__(self):
+        return int(self.lib.fdgan_plan_num_launches(self.h))
+
+    def kernel_names(self):
+        return [self.lib.fdgan_plan_kernel_name(self.h, i).decode() for i in range(len(self))]

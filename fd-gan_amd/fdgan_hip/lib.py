@@ -1,0 +1,110 @@
+"""ctypes binding of libfdgan_hip.so (include/fdgan_hip.h).
+
+This is the ONLY way the Python host code reaches the GPU kernels: plain pointers,
+sizes and a hipStream_t cross the boundary; torch is used for device memory and
+streams, never for the math.  There is no CPU fallback: if the shared library is
+missing the import of any product module fails loudly (FdganLibraryError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdgan_hip.so")
+
+FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
+FD_BF16, FD_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ABI_VERSION = 1
+
+
+class FdganLibraryError(RuntimeError):
+    pass
+
+
+class FdTensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64), ("h", C.c_int64), ("w", C.c_int64), ("c", C.c_int64),
+                ("stride", C.c_int64 * 4), ("dtype", C.c_int32), ("_pad", C.c_int32)]
+
+
+class FdPrologue(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("eps", C.c_float), ("act", C.c_int32), ("pool2", C.c_int32), ("momentum", C.c_float),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("count", C.c_int64)]
+
+
+class FdConvDesc(C.Structure):
+    _fields_ = [("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("epilogue_act", C.c_int32),
+                ("upsample2", C.c_int32), ("cout", C.c_int32)]
+
+
+class FdStats(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("capacity_floats", C.c_int64)]
+
+
+class FdConvInfo(C.Structure):
+    _fields_ = [("stats_rows", C.c_int64), ("stats_cpad", C.c_int64), ("grid_x", C.c_int64), ("grid_y", C.c_int64),
+                ("lds_bytes", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/fdgan_hip.h declares.
+SIGNATURES = {
+    "fdgan_last_error": (C.c_char_p, []),
+    "fdgan_version": (C.c_int, []),
+    "fdgan_device_arch": (C.c_char_p, []),
+    "fdgan_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
+    "fdgan_conv2d_fwd_info": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_int, C.POINTER(FdConvDesc),
+                                        C.POINTER(FdPrologue), C.POINTER(FdConvInfo)]),
+    "fdgan_conv2d_fwd": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdPrologue),
+                                   C.POINTER(FdTensor), C.POINTER(FdStats), C.POINTER(FdConvDesc), C.c_void_p]),
+    "fdgan_bn_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "fdgan_nchw_f32_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                              C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_nhwc_bf16_to_nchw_f32": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p]),
+    "fdgan_copy_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_plan_create": (C.c_void_p, []),
+    "fdgan_plan_destroy": (None, [C.c_void_p]),
+    "fdgan_plan_begin": (C.c_int, [C.c_void_p]),
+    "fdgan_plan_end": (C.c_int, [C.c_void_p]),
+    "fdgan_plan_num_launches": (C.c_int64, [C.c_void_p]),
+    "fdgan_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fdgan_plan_instantiate_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fdgan_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int64]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libfdgan_hip.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FdganLibraryError(
+            "%s not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "The FD-GAN hot path has no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise FdganLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise FdganLibraryError("%s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fdgan_version() != ABI_VERSION:
+        raise FdganLibraryError("ABI version mismatch: library %d, binding %d" % (lib.fdgan_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != FD_OK:
+        msg = load().fdgan_last_error()
+        raise RuntimeError("libfdgan_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,120 @@
+"""NetPlan: builds the static launch sequence of one network forward for one input
+shape.  Ops are collected as closures, the shared statistics workspace is sized from
+`fdgan_conv2d_fwd_info`, then everything is recorded once into an FdPlan (native
+launch list / hipGraph) and replayed per step.
+
+Train-mode BatchNorm (reference: never `.eval()`, README.md:38) is split in two:
+the PRODUCER conv's epilogue emits per-workgroup (sum, sum^2) partials which
+`fdgan_bn_finalize` reduces to (mean, var) per channel ONCE; every CONSUMER conv
+folds (gamma, beta, mean, var) into a per-channel scale/shift in its prologue and
+updates that norm's running statistics.  Inside a dense block the statistics of a
+channel never change once produced, so the concat buffer is normalised without ever
+being re-read by a BatchNorm kernel (SURVEY section 7 "hard parts").
+"""
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import lib as L
+
+
+class ChanStats:
+    """Per-channel batch mean / biased variance of an NHWC buffer (fp32)."""
+
+    def __init__(self, channels, device):
+        self.mean = torch.zeros(channels, dtype=torch.float32, device=device)
+        self.var = torch.ones(channels, dtype=torch.float32, device=device)
+
+
+class NetPlan:
+    def __init__(self, device):
+        self.device = device
+        self.weights = []          # PackedWeight, refreshed by pack_plan
+        self._ops = []             # (closure, stats_floats)
+        self.ws = None             # stats partial workspace
+        self.main = None
+        self.packp = None
+        self.keep = []             # anything that must outlive the plan
+        self._param_versions = None
+
+    # ---- registration -----------------------------------------------------------
+    def weight(self, param, cout, cin, k, transposed=False):
+        w = E.PackedWeight(param, cout, cin, k, transposed)
+        self.weights.append(w)
+        return w
+
+    def bn_prologue(self, bn, src_stats, count, act=L.ACT_RELU, pool=False):
+        """Prologue of a conv whose input passes through BatchNorm `bn` (+activation)."""
+        if bn.training or not bn.track_running_stats:
+            assert src_stats is not None
+            return E.make_prologue(act=act, pool=pool, mean=src_stats.mean, var=src_stats.var, gamma=bn.weight,
+                                   beta=bn.bias, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                   running_mean=bn.running_mean if bn.track_running_stats else None,
+                                   running_var=bn.running_var if bn.track_running_stats else None,
+                                   nbt=bn.num_batches_tracked if bn.track_running_stats else None, count=count)
+        return E.make_prologue(act=act, pool=pool, mean=bn.running_mean, var=bn.running_var, gamma=bn.weight,
+                               beta=bn.bias, eps=bn.eps)
+
+    def conv(self, x, w, y, k, pad=0, stride=1, bias=None, pro=None, e_act=L.ACT_NONE, upsample=False,
+             stats=None, stats_c0=0, y_fd=None):
+        """x, y: engine.View (y_fd overrides for NCHW fp32 output).  stats: ChanStats to
+        receive the batch statistics of the `w.cout` stored channels at [stats_c0, ...)."""
+        yfd = y_fd if y_fd is not None else y.fd
+        desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=w.cout)
+        need = 0
+        info = None
+        if stats is not None:
+            info = E.conv_info(x.fd, yfd, w.cout, desc, pro)
+            need = info.stats_rows * info.stats_cpad * 2
+            n, h, ww, _ = (yfd.n, yfd.h, yfd.w, yfd.c)
+            count = n * h * ww
+
+        def run():
+            E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None)
+            if stats is not None:
+                E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
+        self._ops.append((run, need))
+        self.keep += [x, y, w, bias, pro, yfd, desc, stats]
+
+    def copy(self, src, dst):
+        self._ops.append((lambda: E.copy_nhwc(src, dst), 0))
+        self.keep += [src, dst]
+
+    def op(self, fn):
+        self._ops.append((fn, 0))
+
+    # ---- build / run ------------------------------------------------------------------
+    def finish(self):
+        need = max([n for _, n in self._ops] + [2])
+        self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        self.packp = E.Plan()
+        with self.packp.record():
+            for w in self.weights:
+                w.pack()
+        self.main = E.Plan()
+        with self.main.record():
+            for fn, _ in self._ops:
+                fn()
+        self._ops = None
+        return self
+
+    def _versions(self):
+        return tuple(w.param._version for w in self.weights)
+
+    def refresh_weights(self, force=False):
+        v = self._versions()
+        if force or v != self._param_versions:
+            self.packp.launch()
+            self._param_versions = v
+
+    def launch(self):
+        self.refresh_weights()
+        self.main.launch()
+
+    def param_ptrs(self):
+        return tuple(w.param.data_ptr() for w in self.weights)
+
+
+def bn_flags(module):
+    """Cache key part: the train/eval state of every BatchNorm under `module`."""
+    return tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))

@@ -1,0 +1,382 @@
+"""MI355X-native `models.dehaze1113`: the FD-GAN generator `FDGAN`, the
+Fusion-discriminator `D` and the decoder blocks, behind the reference's nn.Module
+surface (class names, constructor signatures, forward I/O, state_dict keys --
+/root/reference/models/dehaze1113.py:188-230, :256-275, :358-370, :702-801).
+
+The modules own fp32 master parameters exactly like the reference; `forward` does not
+call any torch.nn math.  It builds, per input shape, a static plan of hand-written
+gfx950 kernels (libfdgan_hip.so, include/fdgan_hip.h): NHWC bf16 implicit-GEMM
+convolutions on MFMA with BatchNorm(+ReLU/LeakyReLU), 2x2 average pooling, concat,
+nearest upsampling, bias, tanh/sigmoid folded into their prologues/epilogues.
+Inputs must live on the GPU; there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from fdgan_hip import engine as E
+from fdgan_hip import lib as L
+from fdgan_hip.netplan import ChanStats, NetPlan, bn_flags
+
+from . import tv_densenet121 as _tv
+
+
+class _PlannedModule(nn.Module):
+    """Caches one NetPlan per (shape, BN train/eval flags, parameter storage)."""
+
+    def _plan_for(self, x):
+        E.require_gpu(x, type(self).__name__ + ".forward")
+        if x.dim() != 4:
+            raise ValueError("expected a BxCxHxW tensor, got %s" % (tuple(x.shape),))
+        cache = self.__dict__.setdefault("_plans", {})
+        key = (tuple(x.shape), x.device.index, bn_flags(self))
+        plan = cache.get(key)
+        if plan is not None and plan.param_ptrs() != plan._built_ptrs:
+            plan = None                                   # parameters were moved / re-allocated
+        if plan is None:
+            for p in self.parameters():
+                if p.device != x.device:
+                    raise RuntimeError("module parameters are on %s but the input is on %s" % (p.device, x.device))
+            plan = self._build_plan(tuple(x.shape), x.device)
+            plan._built_ptrs = plan.param_ptrs()
+            cache[key] = plan
+        return plan
+
+    def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
+        self.__dict__.pop("_plans", None)
+        return super()._apply(fn, *a, **k)
+
+    def hip_plan(self, x):
+        """The NetPlan serving inputs shaped like `x` (for benchmarks / profiling)."""
+        return self._plan_for(x)
+
+
+# ---------------------------------------------------------------------------------------
+# decoder blocks
+# ---------------------------------------------------------------------------------------
+class BottleneckBlockdy(_PlannedModule):
+    """dehaze1113.py:256-275.  cat([relu(x), conv2(relu(conv1(relu(x))))], 1); the
+    reference's in-place ReLU also overwrites the caller's `x`, reproduced here.
+    bn1/bn2 are registered but unused, as in the reference (:260,:264)."""
+
+    def __init__(self, in_planes, out_planes, dropRate=0.0):
+        super().__init__()
+        inter = out_planes * 4
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(in_planes, inter, 1, 1, 0, bias=False)
+        self.bn2 = nn.BatchNorm2d(inter)
+        self.conv2 = nn.Conv2d(inter, out_planes, 3, 1, 1, bias=False)
+        self.droprate = dropRate
+        if dropRate > 0:
+            raise NotImplementedError("dropRate > 0 is never used by FDGAN (dehaze1113.py:731-739)")
+        self.in_planes, self.inter, self.out_planes = in_planes, inter, out_planes
+
+    def emit(self, P, blk, tmp):
+        """blk: View of the (in+out)-channel buffer whose first `in_planes` channels hold x."""
+        cin, cout = self.in_planes, self.out_planes
+        w1 = P.weight(self.conv1.weight, self.inter, cin, 1)
+        w2 = P.weight(self.conv2.weight, cout, self.inter, 3)
+        relu = E.make_prologue(act=L.ACT_RELU)
+        P.conv(E.View(blk.buf, blk.c0, cin), w1, tmp, 1, pro=relu)
+        P.conv(tmp, w2, E.View(blk.buf, blk.c0 + cin, cout), 3, pad=1, pro=relu)
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != self.in_planes:
+            raise ValueError("expected %d input channels, got %d" % (self.in_planes, c))
+        P = NetPlan(dev)
+        P.blk = E.new_act(n, h, w, c + self.out_planes, dev)
+        P.tmp = E.new_act(n, h, w, self.inter, dev)
+        self.emit(P, E.View(P.blk), E.View(P.tmp))
+        return P.finish()
+
+    def forward(self, x):
+        P = self._plan_for(x)
+        with torch.no_grad():
+            x.relu_()                                               # reference aliasing (:261)
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.blk, 0, self.in_planes))
+            P.launch()
+            out = torch.empty((x.shape[0], self.in_planes + self.out_planes) + tuple(x.shape[2:]),
+                              dtype=torch.float32, device=x.device)
+            E.to_nchw(E.View(P.blk), out)
+        return out
+
+
+class TransitionBlockdy(_PlannedModule):
+    """dehaze1113.py:358-370: relu (in place) -> ConvTranspose2d 1x1 (weight
+    (Cin,Cout,1,1), no bias) -> nearest x2 upsample."""
+
+    def __init__(self, in_planes, out_planes, dropRate=0.0):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.ConvTranspose2d(in_planes, out_planes, 1, 1, 0, bias=False)
+        self.droprate = dropRate
+        if dropRate > 0:
+            raise NotImplementedError("dropRate > 0 is never used by FDGAN")
+        self.in_planes, self.out_planes = in_planes, out_planes
+
+    def emit(self, P, x, y):
+        w = P.weight(self.conv1.weight, self.out_planes, self.in_planes, 1, transposed=True)
+        P.conv(x, w, y, 1, pro=E.make_prologue(act=L.ACT_RELU), upsample=True)
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != self.in_planes:
+            raise ValueError("expected %d input channels, got %d" % (self.in_planes, c))
+        P = NetPlan(dev)
+        P.xin = E.new_act(n, h, w, (c + 7) // 8 * 8, dev)
+        P.yout = E.new_act(n, 2 * h, 2 * w, (self.out_planes + 7) // 8 * 8, dev)
+        self.emit(P, E.View(P.xin, 0, c), E.View(P.yout, 0, self.out_planes))
+        return P.finish()
+
+    def forward(self, x):
+        P = self._plan_for(x)
+        with torch.no_grad():
+            x.relu_()
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
+            P.launch()
+            out = torch.empty((x.shape[0], self.out_planes, 2 * x.shape[2], 2 * x.shape[3]), dtype=torch.float32,
+                              device=x.device)
+            E.to_nchw(E.View(P.yout, 0, self.out_planes), out)
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# generator
+# ---------------------------------------------------------------------------------------
+def _emit_dense_block(P, block, blk_buf, stats, bott_buf, count):
+    """torchvision _DenseBlock on a pre-allocated concat buffer: layer i reads channels
+    [0, cin_i) and writes its 32 new channels at [cin_i, cin_i+32)."""
+    bott = E.View(bott_buf)
+    bstats = ChanStats(_tv.BN_SIZE * _tv.GROWTH, P.device)
+    P.keep.append(bstats)
+    cin = block.cin
+    for layer in block.values():
+        w1 = P.weight(layer.conv1.weight, _tv.BN_SIZE * _tv.GROWTH, cin, 1)
+        w2 = P.weight(layer.conv2.weight, _tv.GROWTH, _tv.BN_SIZE * _tv.GROWTH, 3)
+        P.conv(E.View(blk_buf, 0, cin), w1, bott, 1, pro=P.bn_prologue(layer.norm1, stats, count),
+               stats=bstats if layer.norm2.training else None)
+        P.conv(bott, w2, E.View(blk_buf, cin, _tv.GROWTH), 3, pad=1, pro=P.bn_prologue(layer.norm2, bstats, count),
+               stats=stats, stats_c0=cin)
+        cin += _tv.GROWTH
+
+
+def _emit_transition(P, trans, x, stats, y, count, out_stats=None, out_c0=0):
+    """torchvision _Transition: BN -> ReLU -> 1x1 conv -> AvgPool2.  The bias-free 1x1
+    conv commutes with the average pool, so the pool runs in the prologue (4x fewer MACs)."""
+    cin, cout = trans.conv.in_channels, trans.conv.out_channels
+    w = P.weight(trans.conv.weight, cout, cin, 1)
+    P.conv(x, w, y, 1, pro=P.bn_prologue(trans.norm, stats, count, pool=True), stats=out_stats, stats_c0=out_c0)
+
+
+class FDGAN(_PlannedModule):
+    """dehaze1113.py:702-801.  forward: (B,3,H,W) float in [0,1] -> (B,3,H,W) in (-1,1);
+    H and W multiples of 8.  Default mode is train (batch-statistics BatchNorm), which
+    the reference also uses for inference (README.md:38)."""
+
+    def __init__(self):
+        super().__init__()
+        feats = _tv.densenet121(pretrained=True).features
+        self.conv0 = feats.conv0                       # registered, never called (:709)
+        self.relu0 = feats.relu0
+        self.dense_block1 = feats.denseblock1
+        self.trans_block1 = feats.transition1
+        self.dense_block2 = feats.denseblock2
+        self.trans_block2 = feats.transition2
+        self.dense_block3 = feats.denseblock3
+        self.trans_block3 = feats.transition3
+        self.dense_block31 = feats.denseblock4        # registered, never called (:725)
+        self.dense_norm31 = feats.norm5                # registered, never called (:728)
+        self.dense_block4 = BottleneckBlockdy(512, 256)
+        self.trans_block4 = TransitionBlockdy(768, 128)
+        self.dense_block5 = BottleneckBlockdy(384, 128)
+        self.trans_block5 = TransitionBlockdy(512, 64)
+        self.dense_block6 = BottleneckBlockdy(64, 32)
+        self.trans_block6 = TransitionBlockdy(96, 16)
+        self.conv_refin1 = nn.Conv2d(3, 64, 3, 1, 1)
+        self.conv_refin6 = nn.Conv2d(640, 512, 3, 1, 1)
+        self.conv_refin5 = nn.Conv2d(256, 128, 1, 1, 0)
+        self.tanh = nn.Tanh()
+        self.conv_refin3 = nn.Conv2d(16, 3, kernel_size=3, stride=1, padding=1)
+        self.conv_refin2 = nn.Conv2d(64, 32, kernel_size=1, stride=1, padding=0)
+        self.conv_refine4 = nn.Conv2d(160, 128, kernel_size=3, stride=1, padding=1)
+
+    # The plan mirrors forward() of the reference line by line (:758-801).
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != 3:
+            raise ValueError("FDGAN expects 3 input channels, got %d" % c)
+        if h % 8 or w % 8:
+            raise ValueError("FDGAN needs H and W to be multiples of 8 (skip concats), got %dx%d" % (h, w))
+        P = NetPlan(dev)
+        h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
+        A = lambda hh, ww, cc: E.new_act(n, hh, ww, cc, dev)
+        P.in8 = E.new_act(n, h, w, 8, dev, zero=True)
+        blk1, bott1, cat1 = A(h, w, 256), A(h, w, 128), A(h2, w2, 160)
+        blk2, bott2 = A(h2, w2, 512), A(h2, w2, 128)
+        blk3, bott3 = A(h4, w4, 1024), A(h4, w4, 128)
+        cat6, blk4, tmp4 = A(h8, w8, 640), A(h8, w8, 768), A(h8, w8, 1024)
+        blk5, tmp5 = A(h4, w4, 512), A(h4, w4, 512)
+        blk6, tmp6 = A(h2, w2, 96), A(h2, w2, 128)
+        x6 = A(h, w, 16)
+        P.x6 = x6
+        st1, st2, st3 = ChanStats(256, dev), ChanStats(512, dev), ChanStats(1024, dev)
+        P.keep += [st1, st2, st3]
+        P.taps = {"x0": E.View(blk1, 0, 64), "x01": E.View(cat1, 0, 32), "x1": E.View(cat1, 32, 128),
+                  "x10": E.View(blk2, 0, 128), "x2": E.View(blk3, 0, 256), "x3": E.View(cat6, 0, 512),
+                  "x22": E.View(cat6, 512, 128), "x4": E.View(blk5, 0, 128), "x5": E.View(blk6, 0, 64),
+                  "x6": E.View(x6)}
+        cnt1, cnt2, cnt3 = n * h * w, n * h2 * w2, n * h4 * w4
+        train = self.training
+
+        # x0 = relu0(conv_refin1(x))                                              (:760)
+        P.conv(E.View(P.in8, 0, 3), P.weight(self.conv_refin1.weight, 64, 3, 3), E.View(blk1, 0, 64), 3, pad=1,
+               bias=self.conv_refin1.bias, e_act=L.ACT_RELU, stats=st1)
+        # x01 = conv_refin2(avg_pool2d(x0, 2))                                    (:763)
+        P.conv(E.View(blk1, 0, 64), P.weight(self.conv_refin2.weight, 32, 64, 1), E.View(cat1, 0, 32), 1,
+               bias=self.conv_refin2.bias, pro=E.make_prologue(pool=True))
+        # x1 = trans_block1(dense_block1(x0))                                     (:767-769)
+        _emit_dense_block(P, self.dense_block1, blk1, st1, bott1, cnt1)
+        _emit_transition(P, self.trans_block1, E.View(blk1), st1, E.View(cat1, 32, 128), cnt1)
+        # x10 = conv_refine4(cat[x01, x1])                                        (:773)
+        P.conv(E.View(cat1), P.weight(self.conv_refine4.weight, 128, 160, 3), E.View(blk2, 0, 128), 3, pad=1,
+               bias=self.conv_refine4.bias, stats=st2)
+        # x2 = trans_block2(dense_block2(x10))                                    (:774)
+        _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt2)
+        _emit_transition(P, self.trans_block2, E.View(blk2), st2, E.View(blk3, 0, 256), cnt2, out_stats=st3)
+        P.copy(E.View(blk3, 0, 256), E.View(blk5, 128, 256))                      # x2 half of x42 (:786)
+        # x3 = trans_block3(dense_block3(x2))                                     (:778)
+        _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt3)
+        _emit_transition(P, self.trans_block3, E.View(blk3), st3, E.View(cat6, 0, 512), cnt3)
+        # x22 = conv_refin5(avg_pool2d(x2, 2))                                    (:780)
+        P.conv(E.View(blk3, 0, 256), P.weight(self.conv_refin5.weight, 128, 256, 1), E.View(cat6, 512, 128), 1,
+               bias=self.conv_refin5.bias, pro=E.make_prologue(pool=True))
+        # x4 = trans_block4(dense_block4(conv_refin6(cat[x3, x22])))              (:783)
+        P.conv(E.View(cat6), P.weight(self.conv_refin6.weight, 512, 640, 3), E.View(blk4, 0, 512), 3, pad=1,
+               bias=self.conv_refin6.bias)
+        self.dense_block4.emit(P, E.View(blk4), E.View(tmp4))
+        self.trans_block4.emit(P, E.View(blk4), E.View(blk5, 0, 128))
+        # x5 = trans_block5(dense_block5(cat[x4, x2]))                            (:786-790)
+        self.dense_block5.emit(P, E.View(blk5), E.View(tmp5))
+        self.trans_block5.emit(P, E.View(blk5), E.View(blk6, 0, 64))
+        # x6 = trans_block6(dense_block6(x5))                                     (:795)
+        self.dense_block6.emit(P, E.View(blk6), E.View(tmp6))
+        self.trans_block6.emit(P, E.View(blk6), E.View(x6))
+        # dehaze = tanh(conv_refin3(x6)) is launched per call into a fresh output  (:799)
+        P.w_last = P.weight(self.conv_refin3.weight, 3, 16, 3)
+        P.last_desc = E.conv_desc(3, 1, 1, L.ACT_TANH, False, cout=3)
+        del train
+        return P.finish()
+
+    def forward(self, x):
+        P = self._plan_for(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _fdgan_autograd(self, P, x)
+        return self._forward_plan(P, x)
+
+    def _forward_plan(self, P, x):
+        with torch.no_grad():
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.in8))
+            P.launch()
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            E.conv2d(E.View(P.x6).fd, P.w_last, self.conv_refin3.bias, None, E.nchw_f32_view(out), P.last_desc)
+        return out
+
+
+def _fdgan_autograd(model, P, x):
+    raise NotImplementedError(
+        "FDGAN backward through the HIP plan is not built yet (round-1 scope: forward). Call under "
+        "torch.no_grad(), as /root/reference/demo.py does (volatile=True, demo.py:112-113).")
+
+
+# ---------------------------------------------------------------------------------------
+# Fusion-discriminator
+# ---------------------------------------------------------------------------------------
+class _Named(nn.Sequential):
+    """Parameter container keeping the reference's nested key names
+    (`main.layer2.layer2.conv.weight`)."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            self.add_module(k, v)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("container only; the math runs in the enclosing network's HIP plan")
+
+
+def blockUNet1(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
+    """dehaze1113.py:29-43 (3x3 stride-1 block).  Only the form `D` uses is supported on
+    the HIP path: conv (not transposed), no dropout."""
+    if transposed or dropout:
+        raise NotImplementedError("blockUNet1(transposed/dropout) is unused by FD-GAN's D")
+    kids = {"relu" if relu else "leakyrelu": nn.ReLU(inplace=True) if relu else nn.LeakyReLU(0.2, inplace=True),
+            "conv": nn.Conv2d(in_c, out_c, 3, 1, 1, bias=False)}
+    if bn:
+        kids["bn"] = nn.BatchNorm2d(out_c)
+    return _Named(**{name: _Named(**kids)})
+
+
+class D(_PlannedModule):
+    """dehaze1113.py:188-230.  (B,nc,H,W) -> (B,1,H/2-2,W/2-2) sigmoid map."""
+
+    def __init__(self, nc, nf):
+        super().__init__()
+        self.nc, self.nf = nc, nf
+        self.main = _Named(
+            layer1=_Named(conv=nn.Conv2d(nc, nf, 4, 2, 1, bias=False)),
+            layer2=blockUNet1(nf, nf * 2, "layer2", transposed=False, bn=True, relu=False, dropout=False),
+            layer3=blockUNet1(nf * 2, nf * 4, "layer3", transposed=False, bn=True, relu=False, dropout=False),
+            layer4=_Named(leakyrelu=nn.LeakyReLU(0.2, inplace=True), conv=nn.Conv2d(nf * 4, nf * 8, 4, 1, 1, bias=False)),
+            layer5=_Named(leakyrelu=nn.LeakyReLU(0.2, inplace=True), conv=nn.Conv2d(nf * 8, 1, 4, 1, 1, bias=False),
+                          sigmoid=nn.Sigmoid()))
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != self.nc:
+            raise ValueError("D expects %d input channels, got %d" % (self.nc, c))
+        nf = self.nf
+        r8 = lambda v: (v + 7) // 8 * 8
+        P = NetPlan(dev)
+        h1, w1 = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
+        h4, w4 = h1 - 1, w1 - 1
+        h5, w5 = h4 - 1, w4 - 1
+        if h5 < 1 or w5 < 1:
+            raise ValueError("input %dx%d too small for D" % (h, w))
+        P.xin = E.new_act(n, h, w, r8(c), dev, zero=True)
+        a1 = E.new_act(n, h1, w1, r8(nf), dev)
+        a2 = E.new_act(n, h1, w1, r8(2 * nf), dev)
+        a3 = E.new_act(n, h1, w1, r8(4 * nf), dev)
+        a4 = E.new_act(n, h4, w4, r8(8 * nf), dev)
+        P.out_shape = (n, 1, h5, w5)
+        m = self.main
+        l2, l3 = m.layer2.layer2, m.layer3.layer3
+        s2, s3 = ChanStats(r8(2 * nf), dev), ChanStats(r8(4 * nf), dev)
+        cnt = n * h1 * w1
+        lrelu = E.make_prologue(act=L.ACT_LEAKY02)
+        # views carry the 8-padded channel count: padded channels are stored as zeros
+        P.conv(E.View(P.xin, 0, c), P.weight(m.layer1.conv.weight, nf, c, 4), E.View(a1), 4, pad=1, stride=2)
+        P.conv(E.View(a1, 0, nf), P.weight(l2.conv.weight, 2 * nf, nf, 3), E.View(a2), 3, pad=1, pro=lrelu,
+               stats=s2 if l2.bn.training else None)
+        P.conv(E.View(a2, 0, 2 * nf), P.weight(l3.conv.weight, 4 * nf, 2 * nf, 3), E.View(a3), 3, pad=1,
+               pro=P.bn_prologue(l2.bn, s2, cnt, act=L.ACT_LEAKY02), stats=s3 if l3.bn.training else None)
+        P.conv(E.View(a3, 0, 4 * nf), P.weight(m.layer4.conv.weight, 8 * nf, 4 * nf, 4), E.View(a4), 4, pad=1,
+               pro=P.bn_prologue(l3.bn, s3, cnt, act=L.ACT_LEAKY02))
+        P.a4 = a4
+        P.w_last = P.weight(m.layer5.conv.weight, 1, 8 * nf, 4)
+        P.last_desc = E.conv_desc(4, 1, 1, L.ACT_SIGMOID, False, cout=1)
+        P.keep += [s2, s3, a1, a2, a3]
+        return P.finish()
+
+    def forward(self, x):
+        P = self._plan_for(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("D backward through the HIP plan is not built yet; call under torch.no_grad()")
+        with torch.no_grad():
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
+            P.launch()
+            out = torch.empty(P.out_shape, dtype=torch.float32, device=x.device)
+            E.conv2d(E.View(P.a4, 0, 8 * self.nf).fd, P.w_last, None, E.make_prologue(act=L.ACT_LEAKY02),
+                     E.nchw_f32_view(out), P.last_desc)
+        return out

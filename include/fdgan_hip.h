@@ -1,0 +1,188 @@
+/* fdgan_hip.h -- C ABI of libfdgan_hip.so: the MI355X (gfx950) hot path of FD-GAN.
+ *
+ * The reference (WeilanAnnn/FD-GAN) has no FFI/plugin boundary: its hot path is
+ * stock torch.nn ops called from models/dehaze1113.py, models/dehaze22.py and
+ * myutils/vgg16.py.  This header is therefore the
+ * boundary a maintainer binds INSTEAD of those torch.nn calls; every entry point
+ * names the reference call site(s) it replaces.  INTEGRATION.md shows the ctypes
+ * binding.
+ *
+ * Conventions
+ *  - Plain C: raw device pointers, sizes, a hipStream_t passed as void*.  No torch
+ *    or C++ types.  The caller owns every buffer; the library never allocates or
+ *    frees device memory and retains no pointer after a call returns -- except
+ *    inside an FdPlan, which retains the pointers recorded into it until destroyed.
+ *  - All work is enqueued on the caller's stream, asynchronously, with no implicit
+ *    synchronisation.  Re-entrant; one process per GPU in data-parallel runs.
+ *  - Return value: FD_OK (0) or a negative FD_E* code; the message is available from
+ *    fdgan_last_error() (thread-local).  Nothing throws or aborts across the ABI.
+ *  - Activations are NHWC bf16 "views": element (n,h,w,c) lives at
+ *    ptr + n*stride[0] + h*stride[1] + w*stride[2] + c (stride[3] must be 1), so a
+ *    view can be a channel slice of a wider dense-block / concat buffer
+ *    (torch.cat, dehaze1113.py:275,773,783,786, is never materialised).
+ *    stride[2] (the pixel pitch) must be a multiple of 8 elements and ptr 16-byte
+ *    aligned.  Network input / output may be NCHW fp32 (dtype FD_F32).
+ */
+#ifndef FDGAN_HIP_H
+#define FDGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDGAN_ABI_VERSION 1
+
+enum FdStatus {
+  FD_OK = 0,
+  FD_EINVAL = -1,       /* bad argument (shape, stride, alignment, NULL) */
+  FD_EUNSUPPORTED = -2, /* valid request the library has no kernel for   */
+  FD_ELAUNCH = -3,      /* HIP launch / runtime error                    */
+  FD_ESTATE = -4        /* plan API misuse                               */
+};
+
+enum FdDtype { FD_BF16 = 0, FD_F32 = 1 };
+
+enum FdAct {
+  FD_ACT_NONE = 0,
+  FD_ACT_RELU = 1,    /* nn.ReLU            dehaze1113.py:239,261; vgg16.py:28-46      */
+  FD_ACT_LEAKY02 = 2, /* nn.LeakyReLU(0.2)  dehaze1113.py:34,213,221                   */
+  FD_ACT_TANH = 3,    /* nn.Tanh            dehaze1113.py:799                          */
+  FD_ACT_SIGMOID = 4  /* nn.Sigmoid         dehaze1113.py:223                          */
+};
+
+typedef void* FdStream; /* hipStream_t */
+
+typedef struct FdTensor {
+  void* ptr;
+  int64_t n, h, w, c;
+  int64_t stride[4]; /* element strides of n, h, w, c */
+  int32_t dtype;     /* FdDtype */
+  int32_t _pad;
+} FdTensor;
+
+/* Input-side fusion of a convolution: what the reference runs as separate modules
+ * *before* the conv.  a = act(x * scale[c] + shift[c]) with
+ *   scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+ * i.e. nn.BatchNorm2d followed by ReLU/LeakyReLU (torchvision _DenseLayer
+ * norm1/relu1, norm2/relu2; _Transition norm/relu; dehaze1113.py:238-239).  Train
+ * mode passes the batch statistics produced by fdgan_bn_finalize; eval mode passes
+ * running_mean / running_var.  mean == NULL means no affine (plain activation, the
+ * `*dy` blocks' in-place ReLU, dehaze1113.py:269,272,367).
+ * pool2 != 0 additionally averages each 2x2 window of `a` (F.avg_pool2d(.,2),
+ * dehaze1113.py:763,780; _Transition.pool commuted in front of the bias-free 1x1
+ * conv) -- only valid for 1x1 convolutions.
+ * If running_mean != NULL the launch also performs BatchNorm's train-mode side
+ * effects for this norm: running <- (1-momentum)*running +
+ * momentum*batch (unbiased variance via `count`), num_batches_tracked += 1. */
+typedef struct FdPrologue {
+  const float* mean;
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int32_t act;   /* FdAct: NONE, RELU or LEAKY02 */
+  int32_t pool2; /* 0 / 1 */
+  float momentum;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  int64_t count; /* N*H*W of the normalised tensor (for the unbiased running_var) */
+} FdPrologue;
+
+typedef struct FdConvDesc {
+  int32_t ksize;        /* 1, 3 or 4 (square)                                         */
+  int32_t stride;       /* 1 or 2                                                     */
+  int32_t pad;          /* zero padding, applied to the *activated* input             */
+  int32_t epilogue_act; /* FdAct applied to conv(+bias) before it is stored           */
+  int32_t upsample2;    /* 1: nearest x2 of the result (F.upsample_nearest :370)      */
+  int32_t cout;         /* the filter's output channels (0: y->c); y->c may exceed it
+                           up to the next multiple of 16 -- extra channels store zeros */
+} FdConvDesc;
+
+/* Per-output-channel batch statistics of what the conv stores (post bias/act,
+ * pre rounding): the producer half of train-mode BatchNorm.  `partial` receives
+ * rows x cpad x {sum, sum of squares} fp32; rows / cpad come from
+ * fdgan_conv2d_fwd_info.  Reduce with fdgan_bn_finalize. */
+typedef struct FdStats {
+  float* partial;
+  int64_t capacity_floats;
+} FdStats;
+
+typedef struct FdConvInfo {
+  int64_t stats_rows;     /* rows the launch writes into FdStats.partial  */
+  int64_t stats_cpad;     /* channels per row (Cout rounded up)           */
+  int64_t grid_x, grid_y; /* for the record                               */
+  int64_t lds_bytes;
+} FdConvInfo;
+
+const char* fdgan_last_error(void);
+int fdgan_version(void); /* == FDGAN_ABI_VERSION */
+/* Name of the device the library sees (e.g. "gfx950"); NULL without a GPU. */
+const char* fdgan_device_arch(void);
+
+/* ---- weights ------------------------------------------------------------- */
+/* Bytes of the MFMA-fragment-ordered bf16 image of a (cout, cin, k, k) filter. */
+size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize);
+/* fp32 OIHW (nn.Conv2d.weight) or, with transposed != 0, IOHW
+ * (nn.ConvTranspose2d.weight, dehaze1113.py:363 -- a 1x1 stride-1 transposed conv
+ * is a 1x1 conv with the weight indexed (Cin,Cout)) -> packed bf16.
+ * With flip != 0 the filter is additionally rotated 180 degrees and its in/out
+ * channels swapped (the data-gradient filter). */
+int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
+                           void* packed, size_t packed_bytes, FdStream stream);
+
+/* ---- convolution ---------------------------------------------------------- */
+/* Replaces nn.Conv2d / nn.ConvTranspose2d(1x1) forward and the BN/ReLU/pool/cat/
+ * upsample/tanh/sigmoid modules fused around it:
+ *   y = act_e( conv_k,s,p( pool?( act_p( bn?(x) ) ) ) + bias )   [nearest x2]
+ * x: NHWC bf16 view with c = Cin.  y: NHWC bf16 view, or NCHW fp32, with c = Cout.
+ * w_packed: from fdgan_pack_conv_weight(cout, cin, ksize).  bias: fp32[Cout] or NULL.
+ * Call sites replaced: torchvision _DenseLayer.conv1/conv2, _Transition.conv,
+ * dehaze1113.py:262,265,363 (dy blocks), :744-755 (refine convs), :196-222 (D),
+ * vgg16.py:9-21. */
+int fdgan_conv2d_fwd_info(const FdTensor* x, const FdTensor* y, int cout, const FdConvDesc* d,
+                          const FdPrologue* pro, FdConvInfo* info);
+int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const float* bias,
+                     const FdPrologue* pro, const FdTensor* y, const FdStats* stats,
+                     const FdConvDesc* d, FdStream stream);
+
+/* ---- batch-norm statistics -------------------------------------------------- */
+/* partial[rows][cpad][2] -> mean[c], var[c] (biased, as nn.BatchNorm2d normalises
+ * with in train mode), c < channels; `count` = N*H*W. */
+int fdgan_bn_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels,
+                      int64_t count, float* mean, float* var, FdStream stream);
+
+/* ---- layout helpers --------------------------------------------------------- */
+/* NCHW fp32 (n,c,h,w contiguous) -> NHWC bf16 view y (y->c >= c; channels c..y->c-1
+ * are written as zeros). */
+int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
+                                const FdTensor* y, FdStream stream);
+/* NHWC bf16 view -> NCHW fp32 contiguous. */
+int fdgan_nhwc_bf16_to_nchw_f32(const FdTensor* x, float* y, FdStream stream);
+/* Channel-slice copy between NHWC bf16 views of equal n,h,w,c (c multiple of 8). */
+int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
+
+/* ---- plan: record once, replay many ----------------------------------------- */
+/* Between fdgan_plan_begin and fdgan_plan_end every launching entry point above,
+ * called from the same thread, is recorded into the plan instead of being
+ * enqueued.  fdgan_plan_launch replays the recorded kernels in order on `stream`
+ * (as a hipGraph once fdgan_plan_instantiate_graph succeeded).  The plan retains
+ * the recorded device pointers: keep those buffers alive and in place. */
+typedef struct FdPlan FdPlan;
+FdPlan* fdgan_plan_create(void);
+void fdgan_plan_destroy(FdPlan* p);
+int fdgan_plan_begin(FdPlan* p);
+int fdgan_plan_end(FdPlan* p);
+int64_t fdgan_plan_num_launches(const FdPlan* p);
+int fdgan_plan_launch(FdPlan* p, FdStream stream);
+int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream);
+/* Name of the k-th recorded kernel (for profiles/tests); NULL if out of range. */
+const char* fdgan_plan_kernel_name(const FdPlan* p, int64_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDGAN_HIP_H */

@@ -1,0 +1,66 @@
+"""Helpers for the GPU parity tests: an fp32/fp64 torch-CPU statement of exactly what
+one fused conv launch computes (including where the kernel rounds to bf16), used
+as the per-kernel checker.  Test infrastructure only."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def act(t, a):
+    if a == ACT_RELU:
+        return torch.relu(t)
+    if a == ACT_LEAKY02:
+        return F.leaky_relu(t, 0.2)
+    if a == ACT_TANH:
+        return torch.tanh(t)
+    if a == ACT_SIGMOID:
+        return torch.sigmoid(t)
+    return t
+
+
+def fused_conv_ref(x, w, bias=None, k=1, stride=1, pad=0, p_act=ACT_NONE, bn=None, pool=False, e_act=ACT_NONE,
+                   upsample=False, transposed=False):
+    """x: NCHW fp32 holding bf16-representable values.  w: fp32 OIHW (IOHW if transposed).
+    bn: None or dict(mean, var, gamma, beta, eps).  Returns (y_fp32_unrounded, mean, var)."""
+    a = x.float()
+    if bn is not None:
+        sc = (bn["gamma"] / torch.sqrt(bn["var"] + bn["eps"])).float()
+        sh = (bn["beta"] - bn["mean"] * sc).float()
+        a = a * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    a = act(a, p_act)
+    if pool:
+        a = F.avg_pool2d(a, 2)
+    a = bf16_round(a)
+    wf = w.float()
+    if transposed:
+        wf = wf.permute(1, 0, 2, 3)
+    wf = bf16_round(wf)
+    y = F.conv2d(a.double(), wf.double(), None, stride, pad).float()
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    y = act(y, e_act)
+    mean = y.double().mean(dim=(0, 2, 3))
+    var = y.double().var(dim=(0, 2, 3), unbiased=False)
+    if upsample:
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    return y, mean.float(), var.float()
+
+
+def rel_rms(a, b):
+    return float(torch.sqrt(((a - b) ** 2).mean()) / (torch.sqrt((b ** 2).mean()) + 1e-20))
+
+
+def psnr(a, b, peak=2.0):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 10.0 * np.log10(peak * peak / max(mse, 1e-30))
+
+
+def seeded(shape, seed, lo=-1.0, hi=1.0):
+    a = np.random.default_rng(seed).random(shape) * (hi - lo) + lo
+    return torch.from_numpy(a.astype(np.float32))

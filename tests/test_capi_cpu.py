@@ -1,0 +1,100 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/fdgan_hip.h
+declares, host-only entry points behave, and the nn.Module surface is key-compatible
+with the reference (via the oracle) and fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fdgan_hip import lib as L
+    hdr = open(os.path.join(ROOT, "include", "fdgan_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fdgan_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.load()
+    raw = C.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert lib.fdgan_version() == L.ABI_VERSION
+
+
+def test_host_only_entry_points():
+    from fdgan_hip import engine as E
+    from fdgan_hip import lib as L
+    lib = L.load()
+    assert lib.fdgan_packed_weight_bytes(32, 128, 3) == 4 * 9 * 2 * 1024          # chunks*taps*tiles KiB
+    assert lib.fdgan_packed_weight_bytes(3, 16, 3) == 1 * 9 * 1 * 1024
+    assert lib.fdgan_packed_weight_bytes(0, 16, 3) == 0
+    # fwd_info is a dry run (no HIP call): grid of the headline shape B=16 @256^2, 128->32 3x3
+    x = torch.empty((16, 256, 256, 128), dtype=torch.bfloat16, device="meta")
+
+    def fd(n, h, w, c, pitch):
+        t = L.FdTensor()
+        t.ptr, t.n, t.h, t.w, t.c = 4096, n, h, w, c
+        t.stride[0], t.stride[1], t.stride[2], t.stride[3] = h * w * pitch, w * pitch, pitch, 1
+        t.dtype = L.FD_BF16
+        return t
+    info = E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1))
+    assert (info.grid_x, info.grid_y, info.stats_rows, info.stats_cpad) == (4096, 1, 4096, 32)
+    assert info.lds_bytes <= 80 * 1024                                              # two workgroups per CU
+    info = E.conv_info(fd(16, 256, 256, 256, 256), fd(16, 128, 128, 128, 160), 128, E.conv_desc(1),
+                       E.make_prologue(pool=True))
+    assert (info.grid_x, info.grid_y) == (16 * 16 * 8, 1)
+    # argument validation crosses the ABI as an error code + message, never an abort
+    bad = fd(1, 8, 8, 16, 12)
+    rc = lib.fdgan_conv2d_fwd_info(C.byref(bad), C.byref(fd(1, 8, 8, 16, 16)), 16, C.byref(E.conv_desc(3, 1, 1)), None,
+                                   C.byref(L.FdConvInfo()))
+    assert rc == L.FD_EINVAL and b"multiples of 8" in lib.fdgan_last_error()
+    rc = lib.fdgan_conv2d_fwd_info(C.byref(fd(1, 8, 8, 16, 16)), C.byref(fd(1, 8, 8, 16, 16)), 16,
+                                   C.byref(E.conv_desc(5, 1, 2)), None, C.byref(L.FdConvInfo()))
+    assert rc == L.FD_EINVAL
+    # plan API misuse
+    p = lib.fdgan_plan_create()
+    assert lib.fdgan_plan_end(p) == L.FD_ESTATE
+    assert lib.fdgan_plan_begin(p) == L.FD_OK and lib.fdgan_plan_begin(p) == L.FD_ESTATE
+    assert lib.fdgan_plan_launch(p, None) == L.FD_ESTATE
+    assert lib.fdgan_plan_end(p) == L.FD_OK and lib.fdgan_plan_num_launches(p) == 0
+    lib.fdgan_plan_destroy(p)
+
+
+def test_module_surface_is_reference_compatible():
+    import models.dehaze1113 as net
+    from oracle import dehaze1113_ref as ref
+    g, og = net.FDGAN(), ref.FDGAN()
+    assert list(g.state_dict().keys()) == list(og.state_dict().keys())
+    for (k, a), (_, b) in zip(g.state_dict().items(), og.state_dict().items()):
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+    assert g.training and sum(p.numel() for p in g.parameters()) == 13980691
+    d, od = net.D(9, 36), ref.D(9, 36)
+    assert list(d.state_dict().keys()) == list(od.state_dict().keys())
+    assert sum(p.numel() for p in d.parameters()) == 790416
+    b = net.BottleneckBlockdy(64, 32)
+    assert set(b.state_dict()) == set(ref.BottleneckBlockdy(64, 32).state_dict())
+    assert tuple(net.TransitionBlockdy(96, 16).conv1.weight.shape) == (96, 16, 1, 1)
+
+
+def test_no_cpu_fallback():
+    import models.dehaze1113 as net
+    g = net.FDGAN()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.D(9, 36)(torch.zeros(1, 9, 64, 64))
+    with pytest.raises(RuntimeError):
+        g.dense_block1.denselayer1(torch.zeros(1, 64, 8, 8))       # containers never compute
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under fd-gan_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "fd-gan_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, fn)

@@ -1,0 +1,164 @@
+"""GPU parity of the nn.Module surface (models.dehaze1113) against the CPU oracle and
+the committed golden vectors (which came from the real reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hiputil import psnr, rel_rms
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _report(name, d):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "parity_%s.json" % name), "w") as f:
+            json.dump(d, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def nets():
+    import models.dehaze1113 as net
+    from oracle import dehaze1113_ref as ref
+    return net, ref
+
+
+def test_fdgan_train_mode_matches_oracle_and_golden(nets, golden_dir):
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    g = net.FDGAN()
+    assert list(g.state_dict().keys()) == list(og.state_dict().keys())
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    assert g.training
+    x = det_input((2, 3, 64, 64), seed=1234)
+    taps = {}
+    with torch.no_grad():
+        y_ref = og(x.clone(), taps)
+        y = g(x.to(DEV))
+    torch.cuda.synchronize()
+    y = y.cpu()
+    gold = np.load(os.path.join(golden_dir, "fdgan_2x64.npz"))
+    rep = {"psnr_vs_oracle": psnr(y, y_ref), "psnr_vs_golden": psnr(y, torch.from_numpy(gold["y"])),
+           "max_abs": float((y - y_ref).abs().max()), "taps": {}}
+    P = g.hip_plan(x.to(DEV))
+    for k, v in taps.items():
+        rep["taps"][k] = rel_rms(P.taps[k].torch_nchw().cpu(), v)
+    _report("fdgan_train", rep)
+    for k, e in rep["taps"].items():
+        assert e < 0.05, (k, e)
+    assert rep["psnr_vs_oracle"] > 38.0, rep
+    assert rep["psnr_vs_golden"] > 38.0, rep
+    # train-mode BatchNorm side effects
+    sd, osd = g.state_dict(), og.state_dict()
+    for name in ("dense_block1.denselayer1.norm1", "dense_block2.denselayer12.norm2", "trans_block3.norm",
+                 "dense_block3.denselayer24.norm1"):
+        assert int(sd[name + ".num_batches_tracked"]) == 1
+        rm, rv = sd[name + ".running_mean"].cpu(), sd[name + ".running_var"].cpu()
+        assert (rm - osd[name + ".running_mean"]).abs().max() < 5e-3, name
+        assert ((rv - osd[name + ".running_var"]).abs() / osd[name + ".running_var"]).max() < 2e-2, name
+    # never-called modules keep their buffers (dehaze1113.py:709,725,728)
+    assert int(sd["dense_norm31.num_batches_tracked"]) == 0
+    assert int(sd["dense_block4.bn1.num_batches_tracked"]) == 0
+    # second call: statistics advance again, output unchanged
+    with torch.no_grad():
+        y2 = g(x.to(DEV)).cpu()
+    assert int(g.state_dict()["trans_block3.norm.num_batches_tracked"]) == 2
+    assert torch.equal(y, y2)
+
+
+def test_fdgan_eval_mode_matches_golden(nets, golden_dir):
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN().eval()
+    fill_state_dict(og, seed=0)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV).eval()
+    x = det_input((2, 3, 64, 64), seed=1234)
+    with torch.no_grad():
+        y = g(x.to(DEV)).cpu()
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, "fdgan_2x64_eval.npz"))["y"])
+    rep = {"psnr_vs_golden": psnr(y, gold), "max_abs": float((y - gold).abs().max())}
+    _report("fdgan_eval", rep)
+    assert rep["psnr_vs_golden"] > 38.0, rep
+    assert int(g.state_dict()["trans_block3.norm.num_batches_tracked"]) == 0
+
+
+def test_fdgan_other_shapes_and_errors(nets):
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    x = det_input((1, 3, 40, 72), seed=5)          # multiples of 8, ragged tiles
+    with torch.no_grad():
+        y_ref = og(x.clone())
+        y = g(x.to(DEV)).cpu()
+    assert y.shape == (1, 3, 40, 72)
+    assert psnr(y, y_ref) > 36.0
+    with pytest.raises(ValueError):
+        g(torch.zeros(1, 3, 36, 64, device=DEV))
+    with pytest.raises(RuntimeError):
+        g(torch.zeros(1, 3, 64, 64))               # CPU tensor: no fallback
+
+
+def test_dy_blocks_match_golden(nets, golden_dir):
+    net, _ = nets
+    from oracle import dehaze1113_ref as ref
+    from oracle.detweights import det_input, fill_state_dict
+    gold = np.load(os.path.join(golden_dir, "dyblocks.npz"))
+    ob = ref.BottleneckBlockdy(64, 32)
+    fill_state_dict(ob, seed=3)
+    b = net.BottleneckBlockdy(64, 32)
+    b.load_state_dict(ob.state_dict())
+    b = b.to(DEV)
+    x = det_input((2, 64, 16, 16), seed=5, lo=-1.0, hi=1.0).to(DEV)
+    y = b(x)
+    assert torch.equal(x.cpu(), torch.from_numpy(gold["x_after"]))          # caller's tensor is relu'd in place
+    assert rel_rms(y.cpu(), torch.from_numpy(gold["y_bottleneck"])) < 8e-3
+    ot = ref.TransitionBlockdy(96, 16)
+    fill_state_dict(ot, seed=4)
+    t = net.TransitionBlockdy(96, 16)
+    t.load_state_dict(ot.state_dict())
+    t = t.to(DEV)
+    z = t(torch.from_numpy(gold["y_bottleneck"]).to(DEV))
+    assert z.shape == (2, 16, 32, 32)
+    assert rel_rms(z.cpu(), torch.from_numpy(gold["y_transition"])) < 8e-3
+
+
+def test_fusion_d_matches_golden(nets, golden_dir):
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    od = ref.D(9, 36)
+    fill_state_dict(od, seed=1)
+    d = net.D(9, 36)
+    assert list(d.state_dict().keys()) == list(od.state_dict().keys())
+    d.load_state_dict(od.state_dict())
+    d = d.to(DEV)
+    x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y = d(x.to(DEV)).cpu()
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, "d_2x64.npz"))["y"])
+    assert y.shape == (2, 1, 30, 30)
+    rep = {"max_abs": float((y - gold).abs().max()), "rel_rms": rel_rms(y, gold)}
+    _report("fusion_d", rep)
+    assert rep["max_abs"] < 2e-2 and rep["rel_rms"] < 1e-2, rep
+    # odd output sizes as at 256x256 (128 -> 127 -> 126): 72 -> 36 -> 35 -> 34
+    x2 = det_input((1, 9, 72, 56), seed=78, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y_ref = od(x2.clone())
+        y2 = d(x2.to(DEV)).cpu()
+    assert y2.shape == y_ref.shape == (1, 1, 34, 26)
+    assert float((y2 - y_ref).abs().max()) < 2e-2
