@@ -61,6 +61,10 @@ extern "C" void fdgan_plan_destroy(FdPlan* p) {
   if (g_recording == p) g_recording = nullptr;
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
+  for (auto& pr : p->pairs) {
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
   delete p;
 }
 
@@ -88,10 +92,34 @@ extern "C" const char* fdgan_plan_kernel_name(const FdPlan* p, int64_t k) {
   return p->launches[(size_t)k].name;
 }
 
+static int timed_launch(FdPlan* p, hipStream_t s) {
+  // eager replay with a hipEvent pair around every marked launch (events are recorded on the
+  // same stream the kernels run on; pairs accumulate until fdgan_plan_read_timing)
+  size_t m = 0;
+  for (size_t k = 0; k < p->launches.size(); ++k) {
+    const bool marked = m < p->marked.size() && p->marked[m] == (int64_t)k;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (marked) {
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        FD_FAIL(FD_ELAUNCH, "hipEventCreate failed");
+      hipEventRecord(e0, s);
+    }
+    int rc = do_launch(p->launches[k], s);
+    if (marked) {
+      hipEventRecord(e1, s);
+      p->pairs.push_back({e0, e1});
+      ++m;
+    }
+    if (rc != FD_OK) return rc;
+  }
+  return FD_OK;
+}
+
 extern "C" int fdgan_plan_launch(FdPlan* p, FdStream stream) {
   FD_REQUIRE(p, "plan_launch: NULL plan");
   if (p->recording) FD_FAIL(FD_ESTATE, "plan_launch: plan is still recording");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!p->marked.empty()) return timed_launch(p, s);
   if (p->exec) {
     hipError_t e = hipGraphLaunch(p->exec, s);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
@@ -108,9 +136,17 @@ extern "C" int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream) {
   FD_REQUIRE(p, "plan_instantiate_graph: NULL plan");
   if (p->recording) FD_FAIL(FD_ESTATE, "plan_instantiate_graph: plan is still recording");
   if (p->exec) return FD_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  // Capture never executes anything, so it runs on a private stream: the caller's stream may be
+  // the legacy NULL stream, which cannot be captured.
+  (void)stream;
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+  e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    hipStreamDestroy(s);
+    FD_FAIL(FD_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  }
   int rc = FD_OK;
   for (const FdLaunch& L : p->launches) {
     rc = do_launch(L, s);
@@ -118,6 +154,7 @@ extern "C" int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream) {
   }
   hipGraph_t g = nullptr;
   e = hipStreamEndCapture(s, &g);
+  hipStreamDestroy(s);
   if (rc != FD_OK) {
     if (g) hipGraphDestroy(g);
     return rc;
@@ -132,4 +169,72 @@ extern "C" int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream) {
   p->graph = g;
   p->exec = ex;
   return FD_OK;
+}
+
+extern "C" int fdgan_plan_time_launches(FdPlan* p, const int64_t* idx, int64_t n) {
+  FD_REQUIRE(p, "plan_time_launches: NULL plan");
+  FD_REQUIRE(n == 0 || idx, "plan_time_launches: NULL index list");
+  p->marked.clear();
+  for (int64_t i = 0; i < n; ++i) {
+    FD_REQUIRE(idx[i] >= 0 && idx[i] < (int64_t)p->launches.size(), "plan_time_launches: index %lld out of range",
+               (long long)idx[i]);
+    FD_REQUIRE(i == 0 || idx[i] > idx[i - 1], "plan_time_launches: indices must be strictly increasing");
+    p->marked.push_back(idx[i]);
+  }
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* launches) {
+  FD_REQUIRE(p && total_ms && launches, "plan_read_timing: NULL argument");
+  double tot = 0.0;
+  int64_t cnt = 0;
+  int rc = FD_OK;
+  for (auto& pr : p->pairs) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(pr.second);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+    if (e != hipSuccess) {
+      fd_set_error("plan_read_timing: %s", hipGetErrorString(e));
+      rc = FD_ELAUNCH;
+    } else {
+      tot += ms;
+      ++cnt;
+    }
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  p->pairs.clear();
+  *total_ms = tot;
+  *launches = cnt;
+  return rc;
+}
+
+extern "C" int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n) {
+  FD_REQUIRE(p && ms_out, "plan_profile: NULL argument");
+  if (p->recording) FD_FAIL(FD_ESTATE, "plan_profile: plan is still recording");
+  FD_REQUIRE(n == (int64_t)p->launches.size(), "plan_profile: ms_out holds %lld entries, plan has %zu launches",
+             (long long)n, p->launches.size());
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(p->launches.size() + 1, nullptr);
+  int rc = FD_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) rc = FD_ELAUNCH;
+  if (rc == FD_OK) {
+    hipEventRecord(ev[0], s);
+    for (size_t k = 0; k < p->launches.size() && rc == FD_OK; ++k) {
+      rc = do_launch(p->launches[k], s);
+      hipEventRecord(ev[k + 1], s);
+    }
+    hipStreamSynchronize(s);
+    for (size_t k = 0; k < p->launches.size() && rc == FD_OK; ++k)
+      if (hipEventElapsedTime(&ms_out[k], ev[k], ev[k + 1]) != hipSuccess) {
+        fd_set_error("plan_profile: hipEventElapsedTime failed at launch %zu", k);
+        rc = FD_ELAUNCH;
+      }
+  } else {
+    fd_set_error("plan_profile: hipEventCreate failed");
+  }
+  for (auto& e : ev)
+    if (e) hipEventDestroy(e);
+  return rc;
 }

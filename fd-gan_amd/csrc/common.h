@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fdgan_hip.h"
@@ -42,6 +43,8 @@ struct FdPlan {
   bool recording = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  std::vector<int64_t> marked;                            // launch indices bracketed by events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;  // recorded, not yet read
 };
 
 // Enqueue on `stream`, or append to the plan being recorded by this thread.

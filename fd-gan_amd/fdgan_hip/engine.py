@@ -191,3 +191,18 @@ class Plan:
 
     def kernel_names(self):
         return [self.lib.fdgan_plan_kernel_name(self.h, i).decode() for i in range(len(self))]
+
+    def time_launches(self, idx):
+        arr = (C.c_int64 * len(idx))(*sorted(idx))
+        L.check(self.lib.fdgan_plan_time_launches(self.h, arr, len(idx)), "plan_time_launches")
+
+    def read_timing(self):
+        tot, cnt = C.c_double(0.0), C.c_int64(0)
+        L.check(self.lib.fdgan_plan_read_timing(self.h, C.byref(tot), C.byref(cnt)), "plan_read_timing")
+        return tot.value, cnt.value
+
+    def profile(self):
+        n = len(self)
+        ms = (C.c_float * n)()
+        L.check(self.lib.fdgan_plan_profile(self.h, stream_ptr(), ms, n), "plan_profile")
+        return list(ms)

@@ -56,7 +56,7 @@ class NetPlan:
                                beta=bn.bias, eps=bn.eps)
 
     def conv(self, x, w, y, k, pad=0, stride=1, bias=None, pro=None, e_act=L.ACT_NONE, upsample=False,
-             stats=None, stats_c0=0, y_fd=None):
+             stats=None, stats_c0=0, y_fd=None, label=None):
         """x, y: engine.View (y_fd overrides for NCHW fp32 output).  stats: ChanStats to
         receive the batch statistics of the `w.cout` stored channels at [stats_c0, ...)."""
         yfd = y_fd if y_fd is not None else y.fd
@@ -73,28 +73,45 @@ class NetPlan:
             E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None)
             if stats is not None:
                 E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
-        self._ops.append((run, need))
+        # algorithmic work of this launch: every conv reads its input once and
+        # writes its output once; MACs counted on the reference's formulation (conv before pool)
+        up = 2 if upsample else 1
+        ho, wo = yfd.h // up, yfd.w // up
+        pool = bool(pro is not None and pro.pool2)
+        macs_px = ho * wo * (4 if pool else 1)
+        out_bytes = yfd.n * yfd.h * yfd.w * w.cout * (4 if yfd.dtype == L.FD_F32 else 2)
+        self._ops.append((run, need, dict(
+            label=label or "conv%dx%d_%d_%d" % (k, k, w.cin, w.cout), k=k, cin=w.cin, cout=w.cout,
+            n=yfd.n, h_out=yfd.h, w_out=yfd.w, flops=2.0 * yfd.n * macs_px * w.cout * w.cin * k * k,
+            flops_done=2.0 * yfd.n * ho * wo * w.cout * w.cin * k * k,
+            bytes=x.fd.n * x.fd.h * x.fd.w * w.cin * 2 + out_bytes)))
         self.keep += [x, y, w, bias, pro, yfd, desc, stats]
 
     def copy(self, src, dst):
-        self._ops.append((lambda: E.copy_nhwc(src, dst), 0))
+        self._ops.append((lambda: E.copy_nhwc(src, dst), 0, dict(label="copy", flops=0.0, flops_done=0.0,
+                                                                   bytes=4 * src.fd.n * src.fd.h * src.fd.w * src.c)))
         self.keep += [src, dst]
 
     def op(self, fn):
-        self._ops.append((fn, 0))
+        self._ops.append((fn, 0, dict(label="op", flops=0.0, flops_done=0.0, bytes=0)))
 
     # ---- build / run ------------------------------------------------------------------
     def finish(self):
-        need = max([n for _, n in self._ops] + [2])
+        need = max([o[1] for o in self._ops] + [2])
         self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
         self.packp = E.Plan()
         with self.packp.record():
             for w in self.weights:
                 w.pack()
         self.main = E.Plan()
+        self.meta = []             # one entry per op: launch index range + algorithmic work
         with self.main.record():
-            for fn, _ in self._ops:
+            for fn, _, meta in self._ops:
+                first = len(self.main)
                 fn()
+                meta = dict(meta)
+                meta["launches"] = list(range(first, len(self.main)))
+                self.meta.append(meta)
         self._ops = None
         return self
 

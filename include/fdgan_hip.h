@@ -181,6 +181,15 @@ int fdgan_plan_launch(FdPlan* p, FdStream stream);
 int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream);
 /* Name of the k-th recorded kernel (for profiles/tests); NULL if out of range. */
 const char* fdgan_plan_kernel_name(const FdPlan* p, int64_t k);
+/* Measurement (bench.py): mark launches (strictly increasing indices; n == 0 clears).
+ * While marks exist fdgan_plan_launch replays eagerly and brackets every marked launch
+ * with a hipEvent pair recorded on the launch stream.  fdgan_plan_read_timing waits
+ * for the recorded pairs, returns their summed elapsed milliseconds and count, and
+ * resets.  fdgan_plan_profile replays once with an event after every launch,
+ * synchronises the stream and fills ms_out[n == number of launches]. */
+int fdgan_plan_time_launches(FdPlan* p, const int64_t* idx, int64_t n);
+int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* launches);
+int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
 
 #ifdef __cplusplus
 }
