@@ -1,0 +1,280 @@
+// conv1x1_xs.hip -- 1x1 convolution, "x-stream" form (the dense-layer bottlenecks, the
+// transitions with their pooled BN+ReLU prologue, the decoder 1x1s).
+//
+// A 1x1 conv is a plain GEMM  D[cout][pixel] = W[cout][cin] * A[cin][pixel]  whose pixel
+// operand is used by exactly ONE wave (waves split the pixel dimension, every wave covers
+// all BN output channels).  So the activations never need LDS:
+//   * each lane loads its MFMA B-fragment straight from HBM: lane (m = l&15, g = l>>4) reads
+//     32 contiguous bytes (channels g*16 .. g*16+15) of pixel m per 64-channel k-step, so
+//     4 lanes consume one full 128-byte line per pixel; the BatchNorm affine + ReLU (and
+//     the 2x2 average of the transition) run on those registers;
+//   * the k-index mapping inside a fragment is free as long as the filter uses the same
+//     one, so the filter is packed for exactly this mapping ("x64" layout) and is loaded
+//     ONCE per workgroup into LDS, where all four waves read it (lane-linear, 16 B/lane);
+//   * workgroups are persistent: they walk pixel tiles with a grid stride, keep the
+//     filter and the BN scale/shift resident, prefetch the next k-step's fragments while
+//     the MFMAs of the current one run, and emit ONE row of batch-statistics partials
+//     per workgroup (<= 512 rows for fdgan_bn_finalize instead of one per tile).
+// No barrier inside the tile loop.
+#include "conv_igemm.h"
+
+template <int POOL, int PT, int CT>
+struct XsCfg {
+  static constexpr int NT = 256, NW = 4;
+  static constexpr int WPX = PT * 16;          // pixels per wave per tile
+  static constexpr int TILE_PX = NW * WPX;
+  static constexpr int BN = CT * 16;
+  static constexpr int NL = POOL ? 4 : 1;      // source pixels per output pixel
+  __host__ __device__ static unsigned w_bytes(int nks) { return (unsigned)nks * 2 * CT * 1024; }
+  __host__ __device__ static unsigned lds_bytes(int nks) { return w_bytes(nks) + nks * 64 * 8 + NW * BN * 2 * 4; }
+};
+
+template <int POOL, int PT, int CT>
+__global__ __launch_bounds__(256, 2) void conv1x1_xs_kernel(ConvArgs a) {
+  using C = XsCfg<POOL, PT, CT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w_lds = smem;                                                   // [nks][2][CT][1 KiB]
+  float* sc_lds = reinterpret_cast<float*>(smem + C::w_bytes(a.nks));    // [nks*64]
+  float* sh_lds = sc_lds + a.nks * 64;
+  float* red = sh_lds + a.nks * 64;                                     // [NW][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int by = blockIdx.y;
+
+  // ---- once per workgroup: BN fold, filter -> LDS, zero the statistics accumulators
+  fd_fold_bn(a, sc_lds, sh_lds, a.nks * 64, tid, C::NT);
+  {
+    const int nunits = a.nks * 2 * CT * 64;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int u = tid; u < nunits; u += C::NT) {
+      const int kj = u / (CT * 64), rem = u - kj * (CT * 64);
+      const int tile16 = by * CT + (rem >> 6);
+      const bool ok = tile16 < a.ntile_total;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(
+          a.w + (ok ? ((long long)kj * a.ntile_total + tile16) * 512 + (rem & 63) * 8 : 0));
+      lds_write16(w_lds + u * 16, ok ? v : z4);
+    }
+  }
+  for (int i = tid; i < C::NW * C::BN * 2; i += C::NT) red[i] = 0.f;
+  __syncthreads();
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const char* wfrag = w_lds + lane * 16;
+  const int cmax = a.Cin8 * 8;
+  const unsigned HW = (unsigned)a.Ho * (unsigned)a.Wo;
+  const int up = a.upsample ? 2 : 1;
+
+  for (unsigned tile = blockIdx.x; tile < (unsigned)a.ntiles; tile += gridDim.x) {
+    // ---- this lane's PT pixels: 32-bit pixel arithmetic, once per tile for source and destination.
+    // A pixel past the end is clamped to pixel 0 (always a valid address) and masked by `pok`.
+    long long xoff[PT], yoff[PT];
+    bool pok[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const unsigned px = tile * C::TILE_PX + wave * C::WPX + p * 16 + m;
+      pok[p] = px < a.P;
+      const unsigned q = pok[p] ? px : 0u;
+      const unsigned n = q / HW, r = q - n * HW;
+      const unsigned oy = r / (unsigned)a.Wo, ox = r - oy * (unsigned)a.Wo;
+      xoff[p] = (long long)n * a.x_sn + (long long)(POOL ? 2 * oy : oy) * a.x_sh + (POOL ? 2 * ox : ox) * a.x_sw +
+                g * 16;
+      yoff[p] = (long long)n * a.y_sn + (long long)(up * oy) * a.y_sh + (long long)(up * ox) * a.y_sw;
+    }
+    f32x4 acc[PT][CT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 raw[PT][2][C::NL];
+    auto load = [&](int ks, int j) {   // half a k-step: this lane's j-th 16 bytes of every pixel
+      const int cb = ks * 64 + g * 16 + j * 8;
+      const int coff = cb < cmax ? ks * 64 + j * 8 : -g * 16;   // past Cin: re-read channel 0 (masked)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const unsigned short* src = a.x + xoff[p] + coff;
+        raw[p][j][0] = *reinterpret_cast<const u32x4*>(src);
+        if (POOL) {
+          raw[p][j][1] = *reinterpret_cast<const u32x4*>(src + a.x_sw);
+          raw[p][j][2] = *reinterpret_cast<const u32x4*>(src + a.x_sh);
+          raw[p][j][3] = *reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw);
+        }
+      }
+    };
+
+    load(0, 0);
+    load(0, 1);
+    for (int ks = 0; ks < a.nks; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // registers -> activated bf16 fragments; the freed registers take the next k-step's loads,
+        // which stay in flight while the MFMAs below run
+        bf16x8 xf[PT];
+        const int cb = ks * 64 + g * 16 + j * 8;
+        const bool cok = cb < cmax;
+        const float* sc = sc_lds + cb;
+        const float* sh = sh_lds + cb;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          u32x4 v;
+          if (a.pro_mode == 0 && !POOL) {   // uniform: no transform at all
+            v = raw[p][j][0];
+          } else {
+            f32x8 f = fd_affine_act(raw[p][j][0], sc, sh, a.p_slope);
+            if (POOL) {
+              f += fd_affine_act(raw[p][j][1], sc, sh, a.p_slope);
+              f += fd_affine_act(raw[p][j][2], sc, sh, a.p_slope);
+              f += fd_affine_act(raw[p][j][3], sc, sh, a.p_slope);
+              f *= 0.25f;
+            }
+            v = fd_pack8(f);
+          }
+          // a pixel past the end / a channel group past Cin must contribute exactly zero
+          xf[p] = __builtin_bit_cast(bf16x8, (pok[p] && cok) ? v : zero4);
+        }
+        if (ks + 1 < a.nks) load(ks + 1, j);
+        constexpr int CH = CT > 4 ? 4 : CT;  // filter fragments live at a time
+#pragma unroll
+        for (int c0 = 0; c0 < CT; c0 += CH) {
+          bf16x8 wf[CH];
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+            wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + ((ks * 2 + j) * CT + c0 + c) * 1024));
+#pragma unroll
+          for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+              acc[p][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[p][c0 + c], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue: bias, activation, statistics, store (4 consecutive channels per lane)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int cout0 = by * C::BN + c * 16 + g * 4;
+      float bv[4], s1[4], s2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
+        s1[r] = s2[r] = 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[p][c][r] + bv[r];
+          v[r] = fmaxf(t, a.e_slope * t);
+          s1[r] += pok[p] ? v[r] : 0.f;
+          s2[r] += pok[p] ? v[r] * v[r] : 0.f;
+        }
+        if (pok[p] && cout0 < a.Cout) fd_store4(a, yoff[p], cout0, v);
+      }
+      if (a.stats != nullptr) {
+        // sum over the 16 pixels of the fragment row, then accumulate into this wave's LDS slot
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1[r] = fd_row_sum16(s1[r]);
+          s2[r] = fd_row_sum16(s2[r]);
+        }
+        if (m == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = red + ((wave * C::BN) + c * 16 + g * 4 + r) * 2;
+            d[0] += s1[r];
+            d[1] += s2[r];
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats != nullptr) {
+    __syncthreads();
+    for (int cl = tid; cl < C::BN; cl += C::NT) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < C::NW; ++w_) {
+        t1 += red[(w_ * C::BN + cl) * 2];
+        t2 += red[(w_ * C::BN + cl) * 2 + 1];
+      }
+      float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + by * C::BN + cl) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+#define FD_XS_DISPATCH(POOL_, PT_, CT_, NAME_)                                                                   \
+  do {                                                                                                          \
+    using C = XsCfg<POOL_, PT_, CT_>;                                                                            \
+    const unsigned lds = C::lds_bytes(a.nks);                                                                   \
+    a.ntiles = (int)((a.P + C::TILE_PX - 1) / C::TILE_PX);                                                      \
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;                                                                \
+    const int ncu = dry ? 256 : num_cus();                                                                      \
+    const unsigned gy = (unsigned)((cout_total + C::BN - 1) / C::BN);                                           \
+    long long gx = (long long)per_cu * ncu / gy;                                                                \
+    if (gx < 1) gx = 1;                                                                                         \
+    if (gx > a.ntiles) gx = a.ntiles;                                                                           \
+    dim3 grid((unsigned)gx, gy, 1), block(256, 1, 1);                                                           \
+    a.stats_cpad = gy * C::BN;                                                                                  \
+    if (info) {                                                                                                 \
+      info->stats_rows = grid.x;                                                                                \
+      info->stats_cpad = a.stats_cpad;                                                                          \
+      info->grid_x = grid.x;                                                                                    \
+      info->grid_y = grid.y;                                                                                    \
+      info->lds_bytes = lds;                                                                                    \
+    }                                                                                                           \
+    if (dry) return FD_OK;                                                                                      \
+    auto kfn = &conv1x1_xs_kernel<POOL_, PT_, CT_>;                                                             \
+    static bool attr_done = false;                                                                              \
+    if (!attr_done) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+      if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(%s): %s", NAME_, hipGetErrorString(e));     \
+      attr_done = true;                                                                                         \
+    }                                                                                                           \
+    if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)                                     \
+      FD_FAIL(FD_EINVAL, "stats workspace too small: need %lld floats, have %lld",                              \
+              (long long)grid.x * a.stats_cpad * 2, stats_cap);                                                 \
+    return fd_launch(kfn, NAME_, grid, block, lds, a, stream);                                                  \
+  } while (0)
+
+bool conv1x1_xs_fits(int cout_total, int cin) {
+  const int nks = (cin + 63) / 64;
+  const int ct = cout_total <= 32 ? 2 : (cout_total <= 64 ? 4 : 8);
+  const long long lds = (long long)nks * 2 * ct * 1024 + nks * 64 * 8 + 4 * ct * 16 * 2 * 4;
+  return lds <= 156 * 1024;
+}
+
+int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, FdConvInfo* info,
+                        long long stats_cap, bool dry, hipStream_t stream) {
+  a.nks = (a.Cin + 63) / 64;
+  const long long P64 = nimg * (long long)a.Ho * a.Wo;
+  if (P64 >= (1ll << 31)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: more than 2^31 output pixels");
+  a.P = (unsigned)P64;
+  if (!conv1x1_xs_fits(cout_total, a.Cin)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: filter does not fit LDS");
+  if (pool) {
+    if (cout_total <= 32) FD_XS_DISPATCH(1, 2, 2, "conv1x1_xs_pool_bn32");
+    if (cout_total <= 64) FD_XS_DISPATCH(1, 2, 4, "conv1x1_xs_pool_bn64");
+    FD_XS_DISPATCH(1, 2, 8, "conv1x1_xs_pool_bn128");
+  }
+  if (cout_total <= 32) FD_XS_DISPATCH(0, 4, 2, "conv1x1_xs_bn32");
+  if (cout_total <= 64) FD_XS_DISPATCH(0, 4, 4, "conv1x1_xs_bn64");
+  FD_XS_DISPATCH(0, 4, 8, "conv1x1_xs_bn128");
+}

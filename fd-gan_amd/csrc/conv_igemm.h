@@ -1,4 +1,4 @@
-// conv_igemm.hip -- NHWC bf16 implicit-GEMM convolution on gfx950 MFMA.
+// conv_igemm.h -- NHWC bf16 implicit-GEMM convolution on gfx950 MFMA.
 //
 //   y = act_e( conv( pool?( act_p( bn?(x) ) ) ) + bias )  [nearest x2]  (+ batch statistics)
 //
@@ -18,6 +18,10 @@
 //     its LDS image is lane-linear: lane l reads its fragment at base + 16*l;
 //   * both stagings are double-buffered: loads for step s+1 are issued before the
 //     MFMAs of step s and written to LDS after them (one barrier per step).
+// Prologue and epilogue are branch-free: BatchNorm is an always-applied per-channel
+// (scale, shift) pair (1, 0 without a norm) and ReLU / LeakyReLU / identity are
+// max(v, slope*v) with slope 0 / 0.2 / 1.  tanh / sigmoid run as a separate
+// elementwise pass (elementwise.hip) -- they only follow the two tiny final convs.
 //
 // Reference call sites replaced: see include/fdgan_hip.h (fdgan_conv2d_fwd).
 #pragma once
@@ -36,7 +40,7 @@ struct ConvArgs {
   const float* bias;
   // prologue
   int pro_mode;  // 0 raw, 1 activation only, 2 affine + activation
-  int p_act;
+  float p_slope; // max(v, p_slope*v): 1 identity, 0 ReLU, 0.2 LeakyReLU
   const float *p_mean, *p_var, *p_gamma, *p_beta;
   float eps, momentum, unbias;
   float *run_mean, *run_var;
@@ -48,39 +52,113 @@ struct ConvArgs {
   int Ho, Wo;  // conv output size (before the optional x2 upsample)
   int Cout;    // channels to store (view->c)
   int CoutW;   // the filter's true output channels (bias length)
-  int e_act, out_nchw_f32, upsample;
+  float e_slope;
+  int out_nchw_f32, upsample;
   float* stats;
   int stats_cpad;
   int tiles_x, tiles_y;
   int pad;
+  // x-stream 1x1 kernel (conv1x1_xs.hip)
+  unsigned P;   // output pixels N*Ho*Wo
+  int ntiles;   // pixel tiles walked by the persistent workgroups
+  int nks;      // 64-channel k-steps
 };
 
 __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void lds_write16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// bf16x8 (as 4 dwords) -> act(x*sc+sh) -> bf16x8.  sc/sh point at 8 floats in LDS.
-__device__ __forceinline__ f32x8 fd_affine_act(u32x4 raw, const float* sc, const float* sh, int mode, int act) {
+// bf16x8 (as 4 dwords) -> max(t, slope*t), t = x*sc+sh.  sc/sh point at 8 floats in LDS.
+__device__ __forceinline__ f32x8 fd_affine_act(u32x4 raw, const float* sc, const float* sh, float slope) {
   f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, raw), f32x8);
-  if (mode == 2) {
-    f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
-    f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      f[e] = fmaf(f[e], s0[e], h0[e]);
-      f[e + 4] = fmaf(f[e + 4], s1[e], h1[e]);
-    }
+  for (int e = 0; e < 4; ++e) {
+    f[e] = fmaf(f[e], s0[e], h0[e]);
+    f[e + 4] = fmaf(f[e + 4], s1[e], h1[e]);
   }
-  if (act == FD_ACT_RELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-  } else if (act == FD_ACT_LEAKY02) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.2f * f[e]);
-  }
+  for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], slope * f[e]);
   return f;
 }
 __device__ __forceinline__ u32x4 fd_pack8(f32x8 f) {
   return __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+}
+
+// Once per workgroup: BatchNorm -> per-channel (scale, shift) in LDS for channels [0, nch);
+// (1, 0) when the conv has no norm.  Workgroup (0,0) also applies the train-mode side
+// effects of the norm (running statistics, num_batches_tracked).
+__device__ __forceinline__ void fd_fold_bn(const ConvArgs& a, float* sc_lds, float* sh_lds, int nch, int tid, int nt) {
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int c = tid; c < nch; c += nt) {
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      sc = 0.f;
+      if (c < a.Cin) {
+        const float mean = a.p_mean[c], var = a.p_var[c];
+        const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
+        sc = g / sqrtf(var + a.eps);
+        sh = b - mean * sc;
+        if (a.run_mean != nullptr && first) {
+          a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
+          a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * var * a.unbias;
+        }
+      }
+    }
+    sc_lds[c] = sc;
+    sh_lds[c] = sh;
+  }
+  if (a.pro_mode == 2 && a.nbt != nullptr && first && tid == 0) *a.nbt += 1;
+}
+
+// Sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA result row): 4 VALU adds with
+// row_ror modifiers, no LDS traffic.  Every lane of the row ends with the full sum.
+template <int CTRL>
+__device__ __forceinline__ float fd_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fd_row_sum16(float v) {
+  v += fd_dpp<0x128>(v);  // row_ror:8
+  v += fd_dpp<0x124>(v);  // row_ror:4
+  v += fd_dpp<0x122>(v);  // row_ror:2
+  v += fd_dpp<0x121>(v);  // row_ror:1
+  return v;
+}
+
+// Store 4 consecutive output channels (cout0 .. cout0+3) of one pixel; `off` is the element
+// offset of the pixel (n, up*oy, up*ox) in y.  Handles NCHW fp32 / NHWC bf16, the 2x2
+// replication of the nearest upsample and the ragged last channel group.
+__device__ __forceinline__ void fd_store4(const ConvArgs& a, long long off, int cout0, const float (&v)[4]) {
+  if (!a.out_nchw_f32) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((ext_vector_type(4))) float f4_t;
+    const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[0], v[1], v[2], v[3]}, bf16x4_t));
+    unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + off + cout0;
+    if (cout0 + 4 <= a.Cout && !a.upsample) {  // the common case
+      *reinterpret_cast<u32x2*>(yp) = bits;
+      return;
+    }
+    const int nrep = a.upsample ? 4 : 1;
+    for (int q = 0; q < nrep; ++q) {
+      unsigned short* d = yp + (q >> 1) * a.y_sh + (q & 1) * a.y_sw;
+      if (cout0 + 4 <= a.Cout) {
+        *reinterpret_cast<u32x2*>(d) = bits;
+      } else {
+        if (cout0 + 0 < a.Cout) d[0] = (unsigned short)(bits[0] & 0xffffu);
+        if (cout0 + 1 < a.Cout) d[1] = (unsigned short)(bits[0] >> 16);
+        if (cout0 + 2 < a.Cout) d[2] = (unsigned short)(bits[1] & 0xffffu);
+      }
+    }
+  } else {
+    float* yp = reinterpret_cast<float*>(a.y) + off + (long long)cout0 * a.y_sc;
+    const int nrep = a.upsample ? 4 : 1;
+    for (int q = 0; q < nrep; ++q) {
+      float* d = yp + (q >> 1) * a.y_sh + (q & 1) * a.y_sw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (cout0 + r < a.Cout) d[r * a.y_sc] = v[r];
+    }
+  }
 }
 
 template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS>
@@ -129,30 +207,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   const int by = blockIdx.y;
   const int oy0 = ty * C::TH, ox0 = tx * C::TW;
 
-  // ---- preamble: fold BatchNorm into per-channel scale/shift (+ train-mode side effects)
-  if (a.pro_mode == 2) {
-    for (int c = tid; c < a.nchunk * 32; c += C::NT) {
-      float sc = 0.f, sh = 0.f;
-      if (c < a.Cin) {
-        const float mean = a.p_mean[c], var = a.p_var[c];
-        const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
-        sc = g / sqrtf(var + a.eps);
-        sh = b - mean * sc;
-        if (a.run_mean != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
-          a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
-          a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * var * a.unbias;
-        }
-      }
-      sc_lds[c] = sc;
-      sh_lds[c] = sh;
-    }
-    if (a.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.nbt += 1;
-  }
+  fd_fold_bn(a, sc_lds, sh_lds, a.nchunk * 32, tid, C::NT);
 
-  // ---- per-thread staging maps (fixed across the K loop)
+  // ---- per-thread staging maps (fixed across the K loop).  Every unit always loads from a
+  // valid address (clamped to the image origin) and is zeroed by a select when it lies outside
+  // the image / past Cin: no divergent branch around the loads.
   const unsigned short* xn = a.x + (long long)n * a.x_sn;
-  int goff[C::IN_UPT];  // element offset of the unit's first source pixel, -1: outside the image
-  int ukg[C::IN_UPT];   // 8-channel group of the unit, -1: unit does not exist
+  int goff[C::IN_UPT];   // element offset of the unit's first source pixel (0 when clamped)
+  int ukg[C::IN_UPT];    // 8-channel group of the unit; -1: outside the image; -2: unit does not exist
 #pragma unroll
   for (int i = 0; i < C::IN_UPT; ++i) {
     const int u = tid + i * C::NT;
@@ -170,19 +232,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       gx = ox0 * STRIDE - a.pad + px;
       inb = gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws;
     }
-    ukg[i] = exists ? kg : -1;
-    goff[i] = (exists && inb) ? gy * a.x_sh + gx * a.x_sw + kg * 8 : -1;
+    ukg[i] = exists ? (inb ? kg : -1) : -2;
+    goff[i] = (exists && inb) ? gy * a.x_sh + gx * a.x_sw + kg * 8 : 0;
   }
   const unsigned short* wsrc[C::W_UPT];
+  bool wok[C::W_UPT];
 #pragma unroll
   for (int i = 0; i < C::W_UPT; ++i) {
     const int j = tid + i * C::NT;
     const int t = j / (C::CTB * 64), rem = j - t * (C::CTB * 64);
     const int tl = rem >> 6, ln = rem & 63;
     const int tile16 = by * C::CTB + tl;
-    wsrc[i] = (j < C::W_UNITS && tile16 < a.ntile_total)
-                  ? a.w + ((long long)t * a.ntile_total + tile16) * 512 + ln * 8
-                  : nullptr;
+    wok[i] = j < C::W_UNITS && tile16 < a.ntile_total;
+    wsrc[i] = wok[i] ? a.w + ((long long)t * a.ntile_total + tile16) * 512 + ln * 8 : a.w;
   }
 
   u32x4 rin[C::IN_UPT][C::NLOAD];
@@ -192,53 +254,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   auto load_in = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < C::IN_UPT; ++i) {
-      const bool ok = goff[i] >= 0 && (chunk * 4 + ukg[i]) < a.Cin8;
+      const bool ok = ukg[i] >= 0 && (chunk * 4 + ukg[i]) < a.Cin8;
       const unsigned short* p = xn + (ok ? goff[i] + chunk * 32 : 0);
+      rin[i][0] = *reinterpret_cast<const u32x4*>(p);
       if (POOL) {
-        rin[i][0] = ok ? *reinterpret_cast<const u32x4*>(p) : zero4;
-        rin[i][1] = ok ? *reinterpret_cast<const u32x4*>(p + a.x_sw) : zero4;
-        rin[i][2] = ok ? *reinterpret_cast<const u32x4*>(p + a.x_sh) : zero4;
-        rin[i][3] = ok ? *reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw) : zero4;
-      } else {
-        rin[i][0] = ok ? *reinterpret_cast<const u32x4*>(p) : zero4;
+        rin[i][1] = *reinterpret_cast<const u32x4*>(p + a.x_sw);
+        rin[i][2] = *reinterpret_cast<const u32x4*>(p + a.x_sh);
+        rin[i][3] = *reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw);
       }
     }
   };
   auto store_in = [&](char* buf, int chunk) {
 #pragma unroll
     for (int i = 0; i < C::IN_UPT; ++i) {
-      if (ukg[i] < 0) continue;
-      const bool ok = goff[i] >= 0 && (chunk * 4 + ukg[i]) < a.Cin8;
-      u32x4 v = zero4;
-      if (ok) {
-        const float* sc = sc_lds + chunk * 32 + ukg[i] * 8;
-        const float* sh = sh_lds + chunk * 32 + ukg[i] * 8;
+      if (ukg[i] == -2) continue;
+      const bool ok = ukg[i] >= 0 && (chunk * 4 + ukg[i]) < a.Cin8;
+      const int cb = chunk * 32 + (ok ? ukg[i] : 0) * 8;
+      u32x4 v;
+      if (a.pro_mode == 0 && !POOL) {  // uniform: plain copy
+        v = rin[i][0];
+      } else {
+        f32x8 f = fd_affine_act(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
         if (POOL) {
-          f32x8 f = fd_affine_act(rin[i][0], sc, sh, a.pro_mode, a.p_act);
-          f += fd_affine_act(rin[i][1], sc, sh, a.pro_mode, a.p_act);
-          f += fd_affine_act(rin[i][2], sc, sh, a.pro_mode, a.p_act);
-          f += fd_affine_act(rin[i][3], sc, sh, a.pro_mode, a.p_act);
-          v = fd_pack8(f * 0.25f);
-        } else if (a.pro_mode != 0) {
-          v = fd_pack8(fd_affine_act(rin[i][0], sc, sh, a.pro_mode, a.p_act));
-        } else {
-          v = rin[i][0];
+          f += fd_affine_act(rin[i][1], sc_lds + cb, sh_lds + cb, a.p_slope);
+          f += fd_affine_act(rin[i][2], sc_lds + cb, sh_lds + cb, a.p_slope);
+          f += fd_affine_act(rin[i][3], sc_lds + cb, sh_lds + cb, a.p_slope);
+          f *= 0.25f;
         }
+        v = fd_pack8(f);
       }
-      lds_write16(buf + (tid + i * C::NT) * 16, v);
+      lds_write16(buf + (tid + i * C::NT) * 16, ok ? v : zero4);   // zero padding is post-activation
     }
   };
   auto load_w = [&](int chunk, int tg) {
     const long long off = ((long long)chunk * C::KK + tg * TPS) * a.ntile_total * 512;
 #pragma unroll
-    for (int i = 0; i < C::W_UPT; ++i)
-      rw[i] = wsrc[i] ? *reinterpret_cast<const u32x4*>(wsrc[i] + off) : zero4;
+    for (int i = 0; i < C::W_UPT; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + (wok[i] ? off : 0));
   };
   auto store_w = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < C::W_UPT; ++i) {
       const int j = tid + i * C::NT;
-      if (j < C::W_UNITS) lds_write16(buf + j * 16, rw[i]);
+      if (j < C::W_UNITS) lds_write16(buf + j * 16, wok[i] ? rw[i] : zero4);
     }
   };
 
@@ -302,120 +359,67 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
 
   // ---- epilogue: bias, activation, batch statistics, store
   const int col = ox0 + m;
-  float ssum[CT][4], ssq[CT][4];
+  const int up = a.upsample ? 2 : 1;
+  long long yoff[PT];  // element offset of this lane's pixel in y, -1: outside the image
 #pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ssum[c][r] = ssq[c][r] = 0.f;
-
+  for (int p = 0; p < PT; ++p) {
+    const int row = oy0 + wm * PT + p;
+    yoff[p] = (row < a.Ho && col < a.Wo) ? (long long)n * a.y_sn + (long long)(up * row) * a.y_sh + (up * col) * a.y_sw
+                                         : -1;
+  }
+  float* red = reinterpret_cast<float*>(smem);  // [waves][CT*16][2]; the K loop ended with a barrier
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     const int cout0 = by * C::BN + (wn * CT + c) * 16 + kgl * 4;
-    float bv[4];
+    float bv[4], s1[4], s2[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
+      s1[r] = s2[r] = 0.f;
+    }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-      const int row = oy0 + wm * PT + p;
-      const bool valid = row < a.Ho && col < a.Wo;
+      const bool valid = yoff[p] >= 0;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = fd_act(acc[p][c][r] + bv[r], a.e_act);
-        if (valid) {
-          ssum[c][r] += v[r];
-          ssq[c][r] += v[r] * v[r];
-        }
+        const float t = acc[p][c][r] + bv[r];
+        v[r] = fmaxf(t, a.e_slope * t);
+        s1[r] += valid ? v[r] : 0.f;
+        s2[r] += valid ? v[r] * v[r] : 0.f;
       }
-      if (!valid || cout0 >= a.Cout) continue;
-      if (a.out_nchw_f32) {
-        float* yp = reinterpret_cast<float*>(a.y) + (long long)n * a.y_sn + (long long)cout0 * a.y_sc;
+      if (valid && cout0 < a.Cout) fd_store4(a, yoff[p], cout0, v);
+    }
+    if (a.stats != nullptr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (cout0 + r < a.Cout) {
-            if (a.upsample) {
-              float* q = yp + r * a.y_sc + (long long)(2 * row) * a.y_sh + (2 * col) * a.y_sw;
-              q[0] = v[r];
-              q[a.y_sw] = v[r];
-              q[a.y_sh] = v[r];
-              q[a.y_sh + a.y_sw] = v[r];
-            } else {
-              yp[r * a.y_sc + (long long)row * a.y_sh + col * a.y_sw] = v[r];
-            }
-          }
-      } else {
-        unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + (long long)n * a.y_sn + cout0;
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        typedef __attribute__((ext_vector_type(4))) float f4;
-        const bf16x4 pk = __builtin_convertvector((f4){v[0], v[1], v[2], v[3]}, bf16x4);
-        const u32x2 bits = __builtin_bit_cast(u32x2, pk);
-        if (cout0 + 4 <= a.Cout) {
-          if (a.upsample) {
-            unsigned short* q = yp + (long long)(2 * row) * a.y_sh + (2 * col) * a.y_sw;
-            *reinterpret_cast<u32x2*>(q) = bits;
-            *reinterpret_cast<u32x2*>(q + a.y_sw) = bits;
-            *reinterpret_cast<u32x2*>(q + a.y_sh) = bits;
-            *reinterpret_cast<u32x2*>(q + a.y_sh + a.y_sw) = bits;
-          } else {
-            *reinterpret_cast<u32x2*>(yp + (long long)row * a.y_sh + col * a.y_sw) = bits;
-          }
-        } else {
-          const unsigned short* hs = reinterpret_cast<const unsigned short*>(&bits);
-          for (int r = 0; r < 4; ++r)
-            if (cout0 + r < a.Cout) {
-              if (a.upsample) {
-                unsigned short* q = yp + r + (long long)(2 * row) * a.y_sh + (2 * col) * a.y_sw;
-                q[0] = hs[r];
-                q[a.y_sw] = hs[r];
-                q[a.y_sh] = hs[r];
-                q[a.y_sh + a.y_sw] = hs[r];
-              } else {
-                yp[r + (long long)row * a.y_sh + col * a.y_sw] = hs[r];
-              }
-            }
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = fd_row_sum16(s1[r]);
+        s2[r] = fd_row_sum16(s2[r]);
+      }
+      if (m == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = (wave * CT * 16 + c * 16 + kgl * 4 + r) * 2;
+          red[idx] = s1[r];
+          red[idx + 1] = s2[r];
         }
       }
     }
   }
 
   if (a.stats != nullptr) {
-    // reduce over the 16 pixels of a fragment row (lanes sharing lane>>4), then over waves
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = ssum[c][r], s2 = ssq[c][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
-        ssum[c][r] = s1;
-        ssq[c][r] = s2;
-      }
-    float* red = reinterpret_cast<float*>(smem);  // [WM*WN waves][CT*16][2]; K loop ended with a barrier
-    if (m == 0) {
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int idx = (wave * CT * 16 + c * 16 + kgl * 4 + r) * 2;
-          red[idx] = ssum[c][r];
-          red[idx + 1] = ssq[c][r];
-        }
-    }
     __syncthreads();
     for (int cl = tid; cl < C::BN; cl += C::NT) {
       const int wn_ = cl / (CT * 16), idx = cl - wn_ * (CT * 16);
-      float s1 = 0.f, s2 = 0.f;
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WM; ++w_) {
-        s1 += red[((w_ * WN + wn_) * CT * 16 + idx) * 2];
-        s2 += red[((w_ * WN + wn_) * CT * 16 + idx) * 2 + 1];
+        t1 += red[((w_ * WN + wn_) * CT * 16 + idx) * 2];
+        t2 += red[((w_ * WN + wn_) * CT * 16 + idx) * 2 + 1];
       }
       float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + by * C::BN + cl) * 2;
-      dst[0] = s1;
-      dst[1] = s2;
+      dst[0] = t1;
+      dst[1] = t2;
     }
   }
 }
@@ -458,11 +462,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
     return fd_launch(kfn, NAME_, grid, block, lds, a, stream);                                                  \
   } while (0)
 
-
-// one translation unit per kernel size (parallel compilation)
+// one translation unit per kernel family (parallel compilation)
 int conv_dispatch_k1(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
+bool conv1x1_xs_fits(int cout_total, int cin);
+int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, FdConvInfo* info,
+                        long long stats_cap, bool dry, hipStream_t stream);
 int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
 int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
+// tanh / sigmoid applied in place on what a conv stored (elementwise.hip)
+int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream);

@@ -1,9 +1,23 @@
 // conv_igemm.hip -- argument validation and the C-ABI entry points of the fused convolution.
 // Kernel: conv_igemm.h; instantiations: conv_k1.hip, conv_k3.hip, conv_k4.hip.
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 
+extern "C" int fdgan_conv_weight_layout(int cout, int cin, int ksize, int stride) {
+  // 1x1 stride-1 filters that fit LDS run on the x-stream kernel (conv1x1_xs.hip), which
+  // consumes the "x64" fragment order; everything else uses the 32-channel chunk order.
+  if (ksize == 1 && stride == 1 && cout > 0 && cin > 0 && conv1x1_xs_fits(cout, cin)) return FD_WLAYOUT_X64;
+  return FD_WLAYOUT_CHUNK32;
+}
+
 static int conv_dispatch(ConvArgs& a, long long nimg, int cout_total, int ksize, int stride, bool pool,
-                         FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+                         int w_layout, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  if (w_layout == FD_WLAYOUT_X64) {
+    if (ksize != 1 || stride != 1) FD_FAIL(FD_EINVAL, "conv2d: the x64 weight layout is for 1x1 stride-1 convs");
+    return conv_dispatch_k1_xs(a, nimg, cout_total, pool, info, stats_cap, dry, stream);
+  }
+  if (w_layout != FD_WLAYOUT_CHUNK32) FD_FAIL(FD_EINVAL, "conv2d: unknown weight layout %d", w_layout);
   switch (ksize) {
     case 1: return conv_dispatch_k1(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
     case 3: return conv_dispatch_k3(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
@@ -52,11 +66,11 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
   a.CoutW = cout;
   a.bias = bias;
   a.pro_mode = 0;
-  a.p_act = FD_ACT_NONE;
+  a.p_slope = 1.f;
   if (pro) {
     FD_REQUIRE(pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU || pro->act == FD_ACT_LEAKY02,
                "conv2d: prologue activation %d", pro->act);
-    a.p_act = pro->act;
+    a.p_slope = pro->act == FD_ACT_RELU ? 0.f : (pro->act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
     if (pro->mean) {
       FD_REQUIRE(pro->var, "conv2d: prologue mean without var");
       a.pro_mode = 2;
@@ -80,7 +94,13 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
   a.Wo = (int)wo;
   a.Cout = (int)y->c;
   FD_REQUIRE(y->c <= ((cout + 15) / 16) * 16 && y->c >= 1, "conv2d: y->c=%lld vs cout=%d", (long long)y->c, cout);
-  a.e_act = d->epilogue_act;
+  FD_REQUIRE(d->epilogue_act >= FD_ACT_NONE && d->epilogue_act <= FD_ACT_SIGMOID, "conv2d: epilogue activation %d",
+             d->epilogue_act);
+  // ReLU / LeakyReLU are fused as max(v, slope*v); tanh / sigmoid run as a second, elementwise
+  // launch over what the conv stored (they only follow the two tiny final convolutions)
+  a.e_slope = d->epilogue_act == FD_ACT_RELU ? 0.f : (d->epilogue_act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
+  if (d->epilogue_act == FD_ACT_TANH || d->epilogue_act == FD_ACT_SIGMOID)
+    FD_REQUIRE(!stats, "conv2d: batch statistics are not available after a tanh/sigmoid epilogue");
   a.upsample = d->upsample2 ? 1 : 0;
   a.pad = d->pad;
   if (y->dtype == FD_F32) {
@@ -102,6 +122,10 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
     a.y_sc = 1;
   }
   a.stats = stats ? stats->partial : nullptr;
+  {  // measurement aid (tools only): FDGAN_DEBUG_NOSTORE=1 drops every output store
+    static const bool nostore = getenv("FDGAN_DEBUG_NOSTORE") != nullptr;
+    if (nostore) a.Cout = 0;
+  }
   nimg = x->n;
   return FD_OK;
 }
@@ -114,7 +138,7 @@ extern "C" int fdgan_conv2d_fwd_info(const FdTensor* x, const FdTensor* y, int c
   bool pool;
   int rc = conv_setup(x, nullptr, nullptr, pro, y, cout, nullptr, d, a, nimg, pool);
   if (rc != FD_OK) return rc;
-  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, info, -1, true, nullptr);
+  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, d->w_layout, info, -1, true, nullptr);
 }
 
 extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const float* bias,
@@ -129,6 +153,10 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
   const int cout = d->cout > 0 ? d->cout : (int)y->c;
   int rc = conv_setup(x, w_packed, bias, pro, y, cout, stats, d, a, nimg, pool);
   if (rc != FD_OK) return rc;
-  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, nullptr,
-                       stats ? stats->capacity_floats : -1, false, static_cast<hipStream_t>(stream));
+  rc = conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, d->w_layout, nullptr,
+                     stats ? stats->capacity_floats : -1, false, static_cast<hipStream_t>(stream));
+  if (rc != FD_OK) return rc;
+  if (d->epilogue_act == FD_ACT_TANH || d->epilogue_act == FD_ACT_SIGMOID)
+    return fd_act_inplace(y, d->epilogue_act, static_cast<hipStream_t>(stream));
+  return FD_OK;
 }

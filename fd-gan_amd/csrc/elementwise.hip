@@ -11,7 +11,7 @@
 struct PackArgs {
   const float* w;
   unsigned short* out;
-  int cout, cin, kk, ks, ntile, nchunk, transposed, flip;
+  int cout, cin, kk, ks, ntile, nchunk, transposed, flip, layout;
   long long nunits;
 };
 
@@ -22,10 +22,15 @@ __global__ void pack_weight_kernel(PackArgs a) {
   long long r = u >> 6;
   const int tile = (int)(r % a.ntile);
   r /= a.ntile;
-  const int tap = (int)(r % a.kk);
-  const int chunk = (int)(r / a.kk);
   const int co = tile * 16 + (lane & 15);
-  const int ci0 = chunk * 32 + (lane >> 4) * 8;
+  int tap, ci0;
+  if (a.layout == FD_WLAYOUT_X64) {  // r = ks*2 + j; lane group g owns channels ks*64 + g*16 + j*8 ..
+    tap = 0;
+    ci0 = (int)(r >> 1) * 64 + (lane >> 4) * 16 + (int)(r & 1) * 8;
+  } else {
+    tap = (int)(r % a.kk);
+    ci0 = (int)(r / a.kk) * 32 + (lane >> 4) * 8;
+  }
   f32x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -51,14 +56,17 @@ __global__ void pack_weight_kernel(PackArgs a) {
 
 extern "C" size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize) {
   if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;
-  const size_t ntile = (cout + 15) / 16, nchunk = (cin + 31) / 32;
+  const size_t ntile = (cout + 15) / 16, nchunk = (cin + 31) / 32, nks = (cin + 63) / 64;
+  if (ksize == 1) return nks * 2 * ntile * 1024;  // X64 (>= CHUNK32 for a 1x1)
   return nchunk * (size_t)ksize * ksize * ntile * 1024;
 }
 
 extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
-                                      void* packed, size_t packed_bytes, FdStream stream) {
+                                      int layout, void* packed, size_t packed_bytes, FdStream stream) {
   FD_REQUIRE(w && packed, "pack_conv_weight: NULL pointer");
   FD_REQUIRE(cout > 0 && cin > 0 && ksize > 0, "pack_conv_weight: bad shape");
+  FD_REQUIRE(layout == FD_WLAYOUT_CHUNK32 || (layout == FD_WLAYOUT_X64 && ksize == 1),
+             "pack_conv_weight: layout %d not valid for ksize %d", layout, ksize);
   FD_REQUIRE(packed_bytes >= fdgan_packed_weight_bytes(cout, cin, ksize), "pack_conv_weight: buffer too small");
   FD_REQUIRE(((uintptr_t)packed & 15) == 0, "pack_conv_weight: packed must be 16-byte aligned");
   PackArgs a;
@@ -72,7 +80,9 @@ extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksi
   a.nchunk = (cin + 31) / 32;
   a.transposed = transposed;
   a.flip = flip;
-  a.nunits = (long long)a.nchunk * a.kk * a.ntile * 64;
+  a.layout = layout;
+  a.nunits = layout == FD_WLAYOUT_X64 ? (long long)((cin + 63) / 64) * 2 * a.ntile * 64
+                                      : (long long)a.nchunk * a.kk * a.ntile * 64;
   const unsigned nb = (unsigned)((a.nunits + 255) / 256);
   return fd_launch(&pack_weight_kernel, "pack_weight", dim3(nb), dim3(256), 0, a, static_cast<hipStream_t>(stream));
 }
@@ -263,4 +273,56 @@ extern "C" int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStrea
              (int)(src->c / 8), src->n * src->h * src->w * (src->c / 8)};
   return fd_launch(&copy_nhwc_kernel, "copy_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// tanh / sigmoid in place over what a conv stored (nn.Tanh dehaze1113.py:799, nn.Sigmoid :223).
+// Generic strided view (NCHW fp32 or NHWC bf16): one thread per element, w fastest.
+// ---------------------------------------------------------------------------------
+struct ActArgs {
+  void* y;
+  long long n, c, h, w, sn, sc, sh, sw;
+  int dtype, act;
+  long long total;
+};
+
+__global__ void act_inplace_kernel(ActArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  long long i0, i1, i2, i3;  // fastest index first
+  if (a.dtype == FD_F32) {   // NCHW: w, h, c, n
+    i0 = r % a.w; r /= a.w; i1 = r % a.h; r /= a.h; i2 = r % a.c; i3 = r / a.c;
+    float* p = static_cast<float*>(a.y) + i3 * a.sn + i2 * a.sc + i1 * a.sh + i0 * a.sw;
+    const float v = *p;
+    *p = a.act == FD_ACT_TANH ? tanhf(v) : 1.f / (1.f + expf(-v));
+  } else {                   // NHWC: c, w, h, n
+    i0 = r % a.c; r /= a.c; i1 = r % a.w; r /= a.w; i2 = r % a.h; i3 = r / a.h;
+    unsigned short* p = static_cast<unsigned short*>(a.y) + i3 * a.sn + i2 * a.sh + i1 * a.sw + i0 * a.sc;
+    const float v = __uint_as_float((unsigned)(*p) << 16);
+    const float o = a.act == FD_ACT_TANH ? tanhf(v) : 1.f / (1.f + expf(-v));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){o, 0.f}, bf16x2_t));
+    *p = (unsigned short)(bits & 0xffffu);
+  }
+}
+
+int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream) {
+  FD_REQUIRE(y && y->ptr, "act_inplace: NULL tensor");
+  ActArgs a;
+  a.y = y->ptr;
+  a.n = y->n;
+  a.c = y->c;
+  a.h = y->h;
+  a.w = y->w;
+  a.sn = y->stride[0];
+  a.sh = y->stride[1];
+  a.sw = y->stride[2];
+  a.sc = y->stride[3];
+  a.dtype = y->dtype;
+  a.act = act;
+  a.total = y->n * y->c * y->h * y->w;
+  return fd_launch(&act_inplace_kernel, act == FD_ACT_TANH ? "tanh_inplace" : "sigmoid_inplace",
+                   dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, stream);
 }

@@ -68,10 +68,12 @@ def new_act(n, h, w, c, device, zero=False):
 class PackedWeight:
     """bf16 MFMA-fragment image of one conv filter + the recipe to refresh it."""
 
-    def __init__(self, param, cout, cin, k, transposed=False, flip=False):
+    def __init__(self, param, cout, cin, k, transposed=False, flip=False, stride=1, layout=None):
         lib = L.load()
         self.param, self.cout, self.cin, self.k = param, cout, cin, k
         self.transposed, self.flip = int(transposed), int(flip)
+        # the library names the fragment order its kernel for this conv consumes
+        self.layout = lib.fdgan_conv_weight_layout(cout, cin, k, stride) if layout is None else layout
         self.nbytes = lib.fdgan_packed_weight_bytes(cout, cin, k)
         self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=param.device)
 
@@ -80,7 +82,8 @@ class PackedWeight:
         p = self.param.detach()
         assert p.dtype == torch.float32 and p.is_contiguous()
         L.check(lib.fdgan_pack_conv_weight(p.data_ptr(), self.cout, self.cin, self.k, self.transposed, self.flip,
-                                           self.buf.data_ptr(), self.nbytes, stream_ptr()), "pack_conv_weight")
+                                           self.layout, self.buf.data_ptr(), self.nbytes, stream_ptr()),
+                "pack_conv_weight")
 
 
 def make_prologue(act=L.ACT_NONE, pool=False, mean=None, var=None, gamma=None, beta=None, eps=1e-5,
@@ -98,9 +101,10 @@ def make_prologue(act=L.ACT_NONE, pool=False, mean=None, var=None, gamma=None, b
     return p
 
 
-def conv_desc(k, stride=1, pad=0, e_act=L.ACT_NONE, upsample=False, cout=0):
+def conv_desc(k, stride=1, pad=0, e_act=L.ACT_NONE, upsample=False, cout=0, w_layout=L.WLAYOUT_CHUNK32):
     d = L.FdConvDesc()
     d.ksize, d.stride, d.pad, d.epilogue_act, d.upsample2, d.cout = k, stride, pad, e_act, int(bool(upsample)), cout
+    d.w_layout = w_layout
     return d
 
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfdgan_hip.so")
 FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
 ABI_VERSION = 1
 
 
@@ -35,7 +36,7 @@ class FdPrologue(C.Structure):
 
 class FdConvDesc(C.Structure):
     _fields_ = [("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("epilogue_act", C.c_int32),
-                ("upsample2", C.c_int32), ("cout", C.c_int32)]
+                ("upsample2", C.c_int32), ("cout", C.c_int32), ("w_layout", C.c_int32)]
 
 
 class FdStats(C.Structure):
@@ -53,8 +54,9 @@ SIGNATURES = {
     "fdgan_version": (C.c_int, []),
     "fdgan_device_arch": (C.c_char_p, []),
     "fdgan_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                         C.c_size_t, C.c_void_p]),
+    "fdgan_conv_weight_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdgan_conv2d_fwd_info": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_int, C.POINTER(FdConvDesc),
                                         C.POINTER(FdPrologue), C.POINTER(FdConvInfo)]),
     "fdgan_conv2d_fwd": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdPrologue),

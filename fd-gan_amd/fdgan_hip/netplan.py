@@ -38,8 +38,8 @@ class NetPlan:
         self._param_versions = None
 
     # ---- registration -----------------------------------------------------------
-    def weight(self, param, cout, cin, k, transposed=False):
-        w = E.PackedWeight(param, cout, cin, k, transposed)
+    def weight(self, param, cout, cin, k, transposed=False, stride=1):
+        w = E.PackedWeight(param, cout, cin, k, transposed, stride=stride)
         self.weights.append(w)
         return w
 
@@ -60,7 +60,7 @@ class NetPlan:
         """x, y: engine.View (y_fd overrides for NCHW fp32 output).  stats: ChanStats to
         receive the batch statistics of the `w.cout` stored channels at [stats_c0, ...)."""
         yfd = y_fd if y_fd is not None else y.fd
-        desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=w.cout)
+        desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=w.cout, w_layout=w.layout)
         need = 0
         info = None
         if stats is not None:

@@ -100,6 +100,7 @@ typedef struct FdConvDesc {
   int32_t upsample2;    /* 1: nearest x2 of the result (F.upsample_nearest :370)      */
   int32_t cout;         /* the filter's output channels (0: y->c); y->c may exceed it
                            up to the next multiple of 16 -- extra channels store zeros */
+  int32_t w_layout;     /* FdWeightLayout the filter was packed with                  */
 } FdConvDesc;
 
 /* Per-output-channel batch statistics of what the conv stores (post bias/act,
@@ -124,7 +125,15 @@ int fdgan_version(void); /* == FDGAN_ABI_VERSION */
 const char* fdgan_device_arch(void);
 
 /* ---- weights ------------------------------------------------------------- */
-/* Bytes of the MFMA-fragment-ordered bf16 image of a (cout, cin, k, k) filter. */
+/* Fragment orders of the packed bf16 filter image (1 KiB per 16 cout x 32 k fragment):
+ *   CHUNK32: k = 32-channel chunk-major, tap, then 8-channel groups (all kernels)
+ *   X64    : 1x1 only; 64-channel k-steps whose lane groups own 16 consecutive channels,
+ *            the order the x-stream kernel reads activations in (conv1x1_xs.hip).
+ * fdgan_conv_weight_layout names the order the library wants for a given conv; pack
+ * with it and pass it back in FdConvDesc.w_layout. */
+enum FdWeightLayout { FD_WLAYOUT_CHUNK32 = 0, FD_WLAYOUT_X64 = 1 };
+int fdgan_conv_weight_layout(int cout, int cin, int ksize, int stride);
+/* Bytes of the packed bf16 image of a (cout, cin, k, k) filter (upper bound over layouts). */
 size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize);
 /* fp32 OIHW (nn.Conv2d.weight) or, with transposed != 0, IOHW
  * (nn.ConvTranspose2d.weight, dehaze1113.py:363 -- a 1x1 stride-1 transposed conv
@@ -132,7 +141,7 @@ size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize);
  * With flip != 0 the filter is additionally rotated 180 degrees and its in/out
  * channels swapped (the data-gradient filter). */
 int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
-                           void* packed, size_t packed_bytes, FdStream stream);
+                           int layout, void* packed, size_t packed_bytes, FdStream stream);
 
 /* ---- convolution ---------------------------------------------------------- */
 /* Replaces nn.Conv2d / nn.ConvTranspose2d(1x1) forward and the BN/ReLU/pool/cat/

@@ -28,7 +28,7 @@ def E():
 
 def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitch_out=None, c0_out=0, bias=False,
          p_act=ACT_NONE, bn=False, pool=False, e_act=ACT_NONE, upsample=False, transposed=False, stats=False,
-         nchw_out=False, seed=0, running=False):
+         nchw_out=False, seed=0, running=False, layout=None):
     from fdgan_hip import lib as L
     dev = torch.device("cuda:0")
     pitch_in = pitch_in or (cin + 7) // 8 * 8
@@ -53,7 +53,7 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
         xbuf[..., c0_in + cin:c0_in + (cin + 7) // 8 * 8] = 0     # padded channels must be finite
     xv = E.View(xbuf, c0_in, cin)
     wparam = wt.to(dev).contiguous()
-    pw = E.PackedWeight(wparam, cout, cin, k, transposed)
+    pw = E.PackedWeight(wparam, cout, cin, k, transposed, stride=stride, layout=layout)
     pw.pack()
     bd = b.to(dev) if bias else None
     pro, run = None, None
@@ -75,7 +75,7 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
         ybuf = torch.full((n, ho * up, wo * up, pitch_out), 9.0, dtype=torch.bfloat16, device=dev)
         yv = E.View(ybuf, c0_out, cstore)
         yfd = yv.fd
-    desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=cout)
+    desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=cout, w_layout=pw.layout)
     ws = torch.zeros(1 << 22, dtype=torch.float32, device=dev) if stats else None
     info = E.conv2d(xv.fd, pw, bd, pro, yfd, desc, ws)
     out = {}
@@ -127,6 +127,29 @@ def test_conv3x3_128_to_32_bn_relu_stats(E):
 def test_conv1x1_prefix_to_128_bn_relu_stats(E):
     _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3)
     _run(E, 1, 16, 16, 992, 128, 1, pitch_in=1024, bn=True, p_act=ACT_RELU, stats=True, seed=4)
+
+
+def test_conv1x1_legacy_chunk32_path(E):
+    """1x1 convs whose filter does not fit LDS fall back to the LDS-tiled kernel (CHUNK32)."""
+    _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3, layout=0)
+    _run(E, 1, 16, 16, 992, 128, 1, pitch_in=1024, bn=True, p_act=ACT_RELU, stats=True, seed=4, layout=0)
+    _run(E, 1, 16, 32, 64, 32, 1, pool=True, bias=True, pitch_out=160, seed=6, layout=0)
+    _run(E, 2, 8, 8, 768, 128, 1, p_act=ACT_RELU, upsample=True, transposed=True, pitch_out=512, seed=8, layout=0)
+
+
+def test_conv1x1_xstream_shapes(E):
+    """x-stream kernel: ragged pixel counts, every BN width, NCHW fp32 output, many tiles per workgroup."""
+    from fdgan_hip import lib as L
+    assert L.load().fdgan_conv_weight_layout(128, 224, 1, 1) == L.WLAYOUT_X64
+    assert L.load().fdgan_conv_weight_layout(128, 992, 1, 1) == L.WLAYOUT_CHUNK32
+    assert L.load().fdgan_conv_weight_layout(32, 128, 3, 1) == L.WLAYOUT_CHUNK32
+    _run(E, 3, 19, 23, 224, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=21, running=True)
+    _run(E, 2, 10, 14, 160, 64, 1, bias=True, e_act=ACT_RELU, stats=True, seed=22)
+    _run(E, 1, 24, 40, 64, 32, 1, p_act=ACT_LEAKY02, seed=23)
+    _run(E, 2, 12, 12, 384, 512, 1, p_act=ACT_RELU, seed=24)                      # grid.y = 4
+    _run(E, 1, 16, 16, 40, 3, 1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=25)
+    _run(E, 8, 128, 128, 64, 128, 1, bn=True, p_act=ACT_RELU, stats=True, seed=26)  # > 1 tile per workgroup
+    _run(E, 2, 36, 20, 512, 256, 1, bn=True, p_act=ACT_RELU, pool=True, stats=True, seed=27)
 
 
 def test_transition_pool_prologue(E):
