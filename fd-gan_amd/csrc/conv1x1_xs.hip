@@ -13,30 +13,35 @@
 //     ONCE per workgroup into LDS, where all four waves read it (lane-linear, 16 B/lane);
 //   * workgroups are persistent: they walk pixel tiles with a grid stride, keep the
 //     filter and the BN scale/shift resident, prefetch the next k-step's fragments while
-//     the MFMAs of the current one run, and emit ONE row of batch-statistics partials
-//     per workgroup (<= 512 rows for fdgan_bn_finalize instead of one per tile).
+//     the MFMAs of the current one run AND the next tile's first k-step while the epilogue
+//     of the current tile runs, and emit ONE row of batch-statistics partials per
+//     workgroup (<= 512 rows for fdgan_bn_finalize instead of one per tile).
 // No barrier inside the tile loop.
 #include "conv_igemm.h"
 
-template <int POOL, int PT, int CT>
+template <int POOL, int PT, int CT, int NW_>
 struct XsCfg {
-  static constexpr int NT = 256, NW = 4;
+  static constexpr int NW = NW_, NT = 64 * NW_;
+  static constexpr int SC = CT > 4 ? 4 : CT;   // channel tiles per row-store pass (<= one 128-byte line)
   static constexpr int WPX = PT * 16;          // pixels per wave per tile
   static constexpr int TILE_PX = NW * WPX;
   static constexpr int BN = CT * 16;
   static constexpr int NL = POOL ? 4 : 1;      // source pixels per output pixel
   __host__ __device__ static unsigned w_bytes(int nks) { return (unsigned)nks * 2 * CT * 1024; }
-  __host__ __device__ static unsigned lds_bytes(int nks) { return w_bytes(nks) + nks * 64 * 8 + NW * BN * 2 * 4; }
+  __host__ __device__ static unsigned lds_bytes(int nks) {
+    return w_bytes(nks) + nks * 64 * 8 + NW * BN * 2 * 4 + NW * RowStore<SC>::BYTES;
+  }
 };
 
-template <int POOL, int PT, int CT>
-__global__ __launch_bounds__(256, 2) void conv1x1_xs_kernel(ConvArgs a) {
-  using C = XsCfg<POOL, PT, CT>;
+template <int POOL, int PT, int CT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
+  using C = XsCfg<POOL, PT, CT, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w_lds = smem;                                                   // [nks][2][CT][1 KiB]
   float* sc_lds = reinterpret_cast<float*>(smem + C::w_bytes(a.nks));    // [nks*64]
   float* sh_lds = sc_lds + a.nks * 64;
   float* red = sh_lds + a.nks * 64;                                     // [NW][BN][2]
+  char* tb = reinterpret_cast<char*>(red + C::NW * C::BN * 2) + (threadIdx.x >> 6) * RowStore<C::SC>::BYTES;  // row-store staging
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -64,52 +69,66 @@ __global__ __launch_bounds__(256, 2) void conv1x1_xs_kernel(ConvArgs a) {
   const int cmax = a.Cin8 * 8;
   const unsigned HW = (unsigned)a.Ho * (unsigned)a.Wo;
   const int up = a.upsample ? 2 : 1;
+  const bool plain_epi = a.bias == nullptr && a.e_slope == 1.f;
 
-  for (unsigned tile = blockIdx.x; tile < (unsigned)a.ntiles; tile += gridDim.x) {
-    // ---- this lane's PT pixels: 32-bit pixel arithmetic, once per tile for source and destination.
-    // A pixel past the end is clamped to pixel 0 (always a valid address) and masked by `pok`.
-    long long xoff[PT], yoff[PT];
-    bool pok[PT];
+  // pixel -> element offsets.  A pixel past the end is clamped to pixel 0 (a valid address).
+  auto x_offset = [&](unsigned px) -> unsigned {
+    const unsigned q = px < a.P ? px : 0u;
+    if (a.x_dense) return q * (unsigned)a.x_sw + g * 16;
+    const unsigned n = q / HW, r = q - n * HW;
+    const unsigned oy = r / (unsigned)a.Wo, ox = r - oy * (unsigned)a.Wo;
+    return (unsigned)(n * (unsigned long long)a.x_sn) + (POOL ? 2 * oy : oy) * (unsigned)a.x_sh +
+           (POOL ? 2 * ox : ox) * (unsigned)a.x_sw + g * 16;
+  };
+  auto y_offset = [&](unsigned px) -> unsigned {
+    if (a.y_dense) return px * (unsigned)a.y_sw;
+    const unsigned n = px / HW, r = px - n * HW;
+    const unsigned oy = r / (unsigned)a.Wo, ox = r - oy * (unsigned)a.Wo;
+    return (unsigned)(n * (unsigned long long)a.y_sn) + (up * oy) * (unsigned)a.y_sh + (up * ox) * (unsigned)a.y_sw;
+  };
+
+  u32x4 raw[PT][2][C::NL];
+  unsigned xoff[PT];   // element offsets (< 2^32, checked on the host)
+  auto load = [&](int ks, int j) {   // half a k-step: this lane's j-th 16 bytes of every pixel
+    const int cb = ks * 64 + g * 16 + j * 8;
+    const int coff = cb < cmax ? ks * 64 + j * 8 : -g * 16;   // past Cin: re-read channel 0 (masked later)
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-      const unsigned px = tile * C::TILE_PX + wave * C::WPX + p * 16 + m;
-      pok[p] = px < a.P;
-      const unsigned q = pok[p] ? px : 0u;
-      const unsigned n = q / HW, r = q - n * HW;
-      const unsigned oy = r / (unsigned)a.Wo, ox = r - oy * (unsigned)a.Wo;
-      xoff[p] = (long long)n * a.x_sn + (long long)(POOL ? 2 * oy : oy) * a.x_sh + (POOL ? 2 * ox : ox) * a.x_sw +
-                g * 16;
-      yoff[p] = (long long)n * a.y_sn + (long long)(up * oy) * a.y_sh + (long long)(up * ox) * a.y_sw;
+      const unsigned short* src = a.x + xoff[p] + coff;
+      raw[p][j][0] = *reinterpret_cast<const u32x4*>(src);
+      if (POOL) {
+        raw[p][j][1] = *reinterpret_cast<const u32x4*>(src + a.x_sw);
+        raw[p][j][2] = *reinterpret_cast<const u32x4*>(src + a.x_sh);
+        raw[p][j][3] = *reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw);
+      }
     }
+  };
+
+  unsigned tile = blockIdx.x;
+  if (tile < (unsigned)a.ntiles) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p) xoff[p] = x_offset(tile * C::TILE_PX + wave * C::WPX + p * 16 + m);
+    load(0, 0);
+    load(0, 1);
+  }
+  for (; tile < (unsigned)a.ntiles; tile += gridDim.x) {
+    const unsigned px0 = tile * C::TILE_PX + wave * C::WPX + m;   // pixel of p = 0
+    const bool full = tile * C::TILE_PX + C::TILE_PX <= a.P;       // uniform: no ragged pixels in this tile
+    const unsigned tnext = tile + gridDim.x;
+    const bool has_next = tnext < (unsigned)a.ntiles;
+
     f32x4 acc[PT][CT];
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
       for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 raw[PT][2][C::NL];
-    auto load = [&](int ks, int j) {   // half a k-step: this lane's j-th 16 bytes of every pixel
-      const int cb = ks * 64 + g * 16 + j * 8;
-      const int coff = cb < cmax ? ks * 64 + j * 8 : -g * 16;   // past Cin: re-read channel 0 (masked)
-#pragma unroll
-      for (int p = 0; p < PT; ++p) {
-        const unsigned short* src = a.x + xoff[p] + coff;
-        raw[p][j][0] = *reinterpret_cast<const u32x4*>(src);
-        if (POOL) {
-          raw[p][j][1] = *reinterpret_cast<const u32x4*>(src + a.x_sw);
-          raw[p][j][2] = *reinterpret_cast<const u32x4*>(src + a.x_sh);
-          raw[p][j][3] = *reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw);
-        }
-      }
-    };
-
-    load(0, 0);
-    load(0, 1);
     for (int ks = 0; ks < a.nks; ++ks) {
+      const bool last = ks + 1 == a.nks;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        // registers -> activated bf16 fragments; the freed registers take the next k-step's loads,
-        // which stay in flight while the MFMAs below run
+        // registers -> activated bf16 fragments; the freed registers take the next loads (next k-step,
+        // or the next tile's first k-step), which stay in flight while the MFMAs / the epilogue run
         bf16x8 xf[PT];
         const int cb = ks * 64 + g * 16 + j * 8;
         const bool cok = cb < cmax;
@@ -118,22 +137,30 @@ __global__ __launch_bounds__(256, 2) void conv1x1_xs_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
           u32x4 v;
-          if (a.pro_mode == 0 && !POOL) {   // uniform: no transform at all
+          if (POOL) {
+            f32x8 f = fd_affine_act(raw[p][j][0], sc, sh, a.p_slope);
+            f += fd_affine_act(raw[p][j][1], sc, sh, a.p_slope);
+            f += fd_affine_act(raw[p][j][2], sc, sh, a.p_slope);
+            f += fd_affine_act(raw[p][j][3], sc, sh, a.p_slope);
+            v = fd_pack8(f * 0.25f);
+          } else if (a.pro_mode == 0) {   // uniform: no transform at all
             v = raw[p][j][0];
           } else {
-            f32x8 f = fd_affine_act(raw[p][j][0], sc, sh, a.p_slope);
-            if (POOL) {
-              f += fd_affine_act(raw[p][j][1], sc, sh, a.p_slope);
-              f += fd_affine_act(raw[p][j][2], sc, sh, a.p_slope);
-              f += fd_affine_act(raw[p][j][3], sc, sh, a.p_slope);
-              f *= 0.25f;
-            }
-            v = fd_pack8(f);
+            v = fd_xform8(raw[p][j][0], sc, sh, a.p_slope);
           }
           // a pixel past the end / a channel group past Cin must contribute exactly zero
-          xf[p] = __builtin_bit_cast(bf16x8, (pok[p] && cok) ? v : zero4);
+          const bool ok = cok && (full || px0 + p * 16 < a.P);
+          xf[p] = __builtin_bit_cast(bf16x8, ok ? v : zero4);
         }
-        if (ks + 1 < a.nks) load(ks + 1, j);
+        if (!last) {
+          load(ks + 1, j);
+        } else if (has_next) {
+          if (j == 0) {   // re-target the source offsets; this tile issues no further loads
+#pragma unroll
+            for (int p = 0; p < PT; ++p) xoff[p] = x_offset(tnext * C::TILE_PX + wave * C::WPX + p * 16 + m);
+          }
+          load(0, j);
+        }
         constexpr int CH = CT > 4 ? 4 : CT;  // filter fragments live at a time
 #pragma unroll
         for (int c0 = 0; c0 < CT; c0 += CH) {
@@ -150,41 +177,92 @@ __global__ __launch_bounds__(256, 2) void conv1x1_xs_kernel(ConvArgs a) {
       }
     }
 
-    // ---- epilogue: bias, activation, statistics, store (4 consecutive channels per lane)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int cout0 = by * C::BN + c * 16 + g * 4;
-      float bv[4], s1[4], s2[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
-        s1[r] = s2[r] = 0.f;
-      }
+    // ---- epilogue: bias, activation, row stores, statistics
+    const int cbase = by * C::BN;
+    const bool rowstore = a.y_vec16 && a.y_dense && cbase + C::BN <= a.Cout;   // uniform
+    if (plain_epi && rowstore) {
+      // fast path: no bias, identity activation, whole rows through the LDS staging area
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
-        float v[4];
+        const unsigned pxt = tile * C::TILE_PX + wave * C::WPX + p * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = acc[p][c][r] + bv[r];
-          v[r] = fmaxf(t, a.e_slope * t);
-          s1[r] += pok[p] ? v[r] : 0.f;
-          s2[r] += pok[p] ? v[r] * v[r] : 0.f;
+        for (int c0 = 0; c0 < CT; c0 += C::SC) {
+          float v[C::SC][4];
+#pragma unroll
+          for (int c = 0; c < C::SC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[c][r] = acc[p][c0 + c][r];
+          fd_store_row16<C::SC>(a, tb, v, lane, cbase + c0 * 16, [&](int q) -> long long {
+            return pxt + q < a.P ? (long long)(pxt + q) * a.y_sw : -1;
+          });
         }
-        if (pok[p] && cout0 < a.Cout) fd_store4(a, yoff[p], cout0, v);
       }
       if (a.stats != nullptr) {
-        // sum over the 16 pixels of the fragment row, then accumulate into this wave's LDS slot
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1[r] = fd_row_sum16(s1[r]);
-          s2[r] = fd_row_sum16(s2[r]);
-        }
-        if (m == 0) {
+        for (int c = 0; c < CT; ++c) {
+          float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int p = 0; p < PT; ++p) {
+            const bool pok = full || px0 + p * 16 < a.P;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = pok ? acc[p][c][r] : 0.f;
+              s1[r] += v;
+              s2[r] = fmaf(v, v, s2[r]);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* d = red + ((wave * C::BN) + c * 16 + g * 4 + r) * 2;
-            d[0] += s1[r];
-            d[1] += s2[r];
+            s1[r] = fd_row_sum16(s1[r]);
+            s2[r] = fd_row_sum16(s2[r]);
+          }
+          if (m == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* d = red + ((wave * C::BN) + c * 16 + g * 4 + r) * 2;
+              d[0] += s1[r];
+              d[1] += s2[r];
+            }
+          }
+        }
+      }
+    } else {
+      unsigned yoff[PT];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) yoff[p] = y_offset(px0 + p * 16 < a.P ? px0 + p * 16 : 0u);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int cout0 = cbase + c * 16 + g * 4;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          const bool pok = px0 + p * 16 < a.P;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float t = acc[p][c][r] + bv[r];
+            v[r] = fmaxf(t, a.e_slope * t);
+            s1[r] += pok ? v[r] : 0.f;
+            s2[r] += pok ? v[r] * v[r] : 0.f;
+          }
+          if (pok && cout0 < a.Cout) fd_store4(a, yoff[p], cout0, v);
+        }
+        if (a.stats != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[r] = fd_row_sum16(s1[r]);
+            s2[r] = fd_row_sum16(s2[r]);
+          }
+          if (m == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* d = red + ((wave * C::BN) + c * 16 + g * 4 + r) * 2;
+              d[0] += s1[r];
+              d[1] += s2[r];
+            }
           }
         }
       }
@@ -220,18 +298,18 @@ static int num_cus() {
   return g_num_cus;
 }
 
-#define FD_XS_DISPATCH(POOL_, PT_, CT_, NAME_)                                                                   \
+#define FD_XS_LAUNCH(POOL_, PT_, CT_, NW_, NAME_)                                                                   \
   do {                                                                                                          \
-    using C = XsCfg<POOL_, PT_, CT_>;                                                                            \
+    using C = XsCfg<POOL_, PT_, CT_, NW_>;                                                                       \
     const unsigned lds = C::lds_bytes(a.nks);                                                                   \
     a.ntiles = (int)((a.P + C::TILE_PX - 1) / C::TILE_PX);                                                      \
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;                                                                \
+    const int per_cu = (NW_ == 4 && lds <= 80 * 1024) ? 2 : 1;                                                  \
     const int ncu = dry ? 256 : num_cus();                                                                      \
     const unsigned gy = (unsigned)((cout_total + C::BN - 1) / C::BN);                                           \
     long long gx = (long long)per_cu * ncu / gy;                                                                \
     if (gx < 1) gx = 1;                                                                                         \
     if (gx > a.ntiles) gx = a.ntiles;                                                                           \
-    dim3 grid((unsigned)gx, gy, 1), block(256, 1, 1);                                                           \
+    dim3 grid((unsigned)gx, gy, 1), block(C::NT, 1, 1);                                                             \
     a.stats_cpad = gy * C::BN;                                                                                  \
     if (info) {                                                                                                 \
       info->stats_rows = grid.x;                                                                                \
@@ -241,7 +319,7 @@ static int num_cus() {
       info->lds_bytes = lds;                                                                                    \
     }                                                                                                           \
     if (dry) return FD_OK;                                                                                      \
-    auto kfn = &conv1x1_xs_kernel<POOL_, PT_, CT_>;                                                             \
+    auto kfn = &conv1x1_xs_kernel<POOL_, PT_, CT_, NW_>;                                                        \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                    \
@@ -255,11 +333,20 @@ static int num_cus() {
     return fd_launch(kfn, NAME_, grid, block, lds, a, stream);                                                  \
   } while (0)
 
+// 4 waves per workgroup (two workgroups per CU) while the LDS-resident filter leaves room for
+// two; otherwise ONE 8-wave workgroup per CU, so the CU still runs two waves per SIMD.
+#define FD_XS_DISPATCH(POOL_, PT_, CT_, NAME_)                                       \
+  do {                                                                              \
+    if (XsCfg<POOL_, PT_, CT_, 4>::lds_bytes(a.nks) <= 80 * 1024)                   \
+      FD_XS_LAUNCH(POOL_, PT_, CT_, 4, NAME_);                                      \
+    FD_XS_LAUNCH(POOL_, PT_, CT_, 8, NAME_ "_w8");                                  \
+  } while (0)
+
 bool conv1x1_xs_fits(int cout_total, int cin) {
   const int nks = (cin + 63) / 64;
-  const int ct = cout_total <= 32 ? 2 : (cout_total <= 64 ? 4 : 8);
-  const long long lds = (long long)nks * 2 * ct * 1024 + nks * 64 * 8 + 4 * ct * 16 * 2 * 4;
-  return lds <= 156 * 1024;
+  if (cout_total <= 32) return XsCfg<0, 4, 2, 8>::lds_bytes(nks) <= 158 * 1024;
+  if (cout_total <= 64) return XsCfg<0, 4, 4, 8>::lds_bytes(nks) <= 158 * 1024;
+  return XsCfg<0, 4, 8, 8>::lds_bytes(nks) <= 158 * 1024;
 }
 
 int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, FdConvInfo* info,
@@ -267,7 +354,12 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
   a.nks = (a.Cin + 63) / 64;
   const long long P64 = nimg * (long long)a.Ho * a.Wo;
   if (P64 >= (1ll << 31)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: more than 2^31 output pixels");
+  if (nimg * a.x_sn >= (1ll << 32) || nimg * a.y_sn >= (1ll << 32))
+    FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: tensors beyond 2^32 elements");
   a.P = (unsigned)P64;
+  a.x_dense = !pool && a.x_sh == (long long)a.Ws * a.x_sw && a.x_sn == (long long)a.Hs * a.x_sh;
+  a.y_dense = !a.upsample && !a.out_nchw_f32 && a.y_sh == (long long)a.Wo * a.y_sw &&
+              a.y_sn == (long long)a.Ho * a.y_sh;
   if (!conv1x1_xs_fits(cout_total, a.Cin)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: filter does not fit LDS");
   if (pool) {
     if (cout_total <= 32) FD_XS_DISPATCH(1, 2, 2, "conv1x1_xs_pool_bn32");

@@ -62,6 +62,9 @@ struct ConvArgs {
   unsigned P;   // output pixels N*Ho*Wo
   int ntiles;   // pixel tiles walked by the persistent workgroups
   int nks;      // 64-channel k-steps
+  int x_dense;  // x offset of pixel p is p * x_sw (no pooling, contiguous n/h/w)
+  int y_dense;  // y offset of pixel p is p * y_sw (no upsample, contiguous n/h/w, NHWC)
+  int y_vec16;  // NHWC bf16 output, 16-byte aligned rows, no upsample: row stores allowed
 };
 
 __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -83,6 +86,34 @@ __device__ __forceinline__ f32x8 fd_affine_act(u32x4 raw, const float* sc, const
 }
 __device__ __forceinline__ u32x4 fd_pack8(f32x8 f) {
   return __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+}
+
+// BatchNorm + ReLU on 8 bf16 channels in 20 VALU ops: 8 widening shifts/ands, 4 v_pk_fma_f32,
+// 4 v_cvt_pk_bf16_f32 and the ReLU as 4 v_pk_max_i16 on the packed result (a negative bf16 is a
+// negative int16; rounding is monotone, so relu(round(t)) == round(relu(t))).
+__device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const float* sh) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+  const f32x2_t sv[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
+  const f32x2_t hv[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
+  u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2_t f = {__uint_as_float(raw[i] << 16), __uint_as_float(raw[i] & 0xffff0000u)};
+    f = __builtin_elementwise_fma(f, sv[i], hv[i]);
+    const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+    out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
+  }
+  return out;
+}
+
+// prologue transform of one 8-channel unit (no pooling): uniform dispatch on the activation
+__device__ __forceinline__ u32x4 fd_xform8(u32x4 raw, const float* sc, const float* sh, float slope) {
+  if (slope == 0.f) return fd_bn_relu8(raw, sc, sh);
+  return fd_pack8(fd_affine_act(raw, sc, sh, slope));
 }
 
 // Once per workgroup: BatchNorm -> per-channel (scale, shift) in LDS for channels [0, nch);
@@ -159,6 +190,49 @@ __device__ __forceinline__ void fd_store4(const ConvArgs& a, long long off, int 
         if (cout0 + r < a.Cout) d[r * a.y_sc] = v[r];
     }
   }
+}
+
+// Full-row stores.  An MFMA result lane holds 4 channels (8 bytes) of one pixel, and a wave
+// instruction of such stores touches 16 pixels x 32 bytes: measured 2.2 TB/s write-only on
+// MI355X against 8 TB/s for 16-byte-per-lane row-contiguous stores (tools/ubench/patterns.hip).
+// So a 16-pixel x (CT*16)-channel result tile is transposed through a wave-private LDS
+// staging area (row pitch CT*32+16 bytes) and written back as whole rows: CT*2 lanes x 16 B
+// per pixel.  `pixoff(q)` returns the element offset of pixel q (0..15) of the tile in y, or a
+// negative value for a pixel outside the image.  LDS traffic of one wave is in program order;
+// the fences only stop the compiler from reordering the two phases.
+template <int CT>
+struct RowStore {
+  static constexpr int RB = CT * 32;             // bytes of one pixel's channels
+  static constexpr int PITCH = RB + 16;
+  static constexpr int BYTES = 16 * PITCH;       // staging bytes per wave
+  static constexpr int LPP = RB / 16;            // lanes per pixel on the way out
+  static constexpr int PPI = 64 / LPP;           // pixels per store instruction
+};
+template <int CT, typename F>
+__device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, const float (&v)[CT][4], int lane,
+                                              int cout_base, F pixoff) {
+  using R = RowStore<CT>;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  const int m = lane & 15, g = lane >> 4;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const u32x2 bits =
+        __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]}, bf16x4_t));
+    *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + g * 8) = bits;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int piece = lane % R::LPP, q0 = lane / R::LPP;
+#pragma unroll
+  for (int i = 0; i < 16 / R::PPI; ++i) {
+    const int q = i * R::PPI + q0;
+    const u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
+    const long long off = pixoff(q);
+    if (off >= 0)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8) = row;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS>
@@ -273,15 +347,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       u32x4 v;
       if (a.pro_mode == 0 && !POOL) {  // uniform: plain copy
         v = rin[i][0];
+      } else if (!POOL) {
+        v = fd_xform8(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
       } else {
         f32x8 f = fd_affine_act(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
-        if (POOL) {
-          f += fd_affine_act(rin[i][1], sc_lds + cb, sh_lds + cb, a.p_slope);
-          f += fd_affine_act(rin[i][2], sc_lds + cb, sh_lds + cb, a.p_slope);
-          f += fd_affine_act(rin[i][3], sc_lds + cb, sh_lds + cb, a.p_slope);
-          f *= 0.25f;
-        }
-        v = fd_pack8(f);
+        f += fd_affine_act(rin[i][1], sc_lds + cb, sh_lds + cb, a.p_slope);
+        f += fd_affine_act(rin[i][2], sc_lds + cb, sh_lds + cb, a.p_slope);
+        f += fd_affine_act(rin[i][3], sc_lds + cb, sh_lds + cb, a.p_slope);
+        v = fd_pack8(f * 0.25f);
       }
       lds_write16(buf + (tid + i * C::NT) * 16, ok ? v : zero4);   // zero padding is post-activation
     }
@@ -357,40 +430,64 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
     __syncthreads();
   }
 
-  // ---- epilogue: bias, activation, batch statistics, store
+  // ---- epilogue: bias, activation, store, batch statistics
   const int col = ox0 + m;
   const int up = a.upsample ? 2 : 1;
-  long long yoff[PT];  // element offset of this lane's pixel in y, -1: outside the image
+  // staging for the row stores: one RowStore<CT> area per wave at the start of LDS (the K loop
+  // ended with a barrier, so the input ring is free); statistics scratch behind it
+  char* tb = smem + wave * RowStore<CT>::BYTES;
+  float* red = reinterpret_cast<float*>(smem + WM * WN * RowStore<CT>::BYTES);  // [waves][CT*16][2]
+  const int cbase = by * C::BN + wn * CT * 16;
+  const bool rowstore = a.y_vec16 && cbase + CT * 16 <= a.Cout;   // uniform
+  float bv[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cbase + c * 16 + kgl * 4 + r;
+      bv[c][r] = (a.bias != nullptr && co < a.CoutW) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int row = oy0 + wm * PT + p;
-    yoff[p] = (row < a.Ho && col < a.Wo) ? (long long)n * a.y_sn + (long long)(up * row) * a.y_sh + (up * col) * a.y_sw
-                                         : -1;
-  }
-  float* red = reinterpret_cast<float*>(smem);  // [waves][CT*16][2]; the K loop ended with a barrier
+    float v[CT][4];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    const int cout0 = by * C::BN + (wn * CT + c) * 16 + kgl * 4;
-    float bv[4], s1[4], s2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
-      s1[r] = s2[r] = 0.f;
-    }
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-      const bool valid = yoff[p] >= 0;
-      float v[4];
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = acc[p][c][r] + bv[r];
-        v[r] = fmaxf(t, a.e_slope * t);
-        s1[r] += valid ? v[r] : 0.f;
-        s2[r] += valid ? v[r] * v[r] : 0.f;
+        const float t = acc[p][c][r] + bv[c][r];
+        v[c][r] = fmaxf(t, a.e_slope * t);
       }
-      if (valid && cout0 < a.Cout) fd_store4(a, yoff[p], cout0, v);
+    if (rowstore) {
+      fd_store_row16<CT>(a, tb, v, lane, cbase, [&](int q) -> long long {
+        return (row < a.Ho && ox0 + q < a.Wo)
+                   ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw
+                   : -1;
+      });
+    } else if (row < a.Ho && col < a.Wo) {
+      const long long off = (long long)n * a.y_sn + (long long)(up * row) * a.y_sh + (long long)(up * col) * a.y_sw;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int cout0 = cbase + c * 16 + kgl * 4;
+        if (cout0 < a.Cout) fd_store4(a, off, cout0, v[c]);
+      }
     }
-    if (a.stats != nullptr) {
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const bool valid = (oy0 + wm * PT + p) < a.Ho && col < a.Wo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[p][c][r] + bv[c][r];
+          const float v = fmaxf(t, a.e_slope * t);
+          s1[r] += valid ? v : 0.f;
+          s2[r] += valid ? v * v : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s1[r] = fd_row_sum16(s1[r]);

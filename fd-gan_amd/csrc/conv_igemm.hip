@@ -116,6 +116,8 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
                "conv2d: y strides must be channel-contiguous, multiples of 4 elements");
     FD_REQUIRE(((uintptr_t)y->ptr & 7) == 0, "conv2d: y pointer must be 8-byte aligned");
     a.out_nchw_f32 = 0;
+    a.y_vec16 = !d->upsample2 && ((uintptr_t)y->ptr & 15) == 0 && y->stride[2] % 8 == 0 && y->stride[1] % 8 == 0 &&
+                y->stride[0] % 8 == 0;
     a.y_sn = y->stride[0];
     a.y_sh = (int)y->stride[1];
     a.y_sw = (int)y->stride[2];
@@ -125,6 +127,8 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
   {  // measurement aid (tools only): FDGAN_DEBUG_NOSTORE=1 drops every output store
     static const bool nostore = getenv("FDGAN_DEBUG_NOSTORE") != nullptr;
     if (nostore) a.Cout = 0;
+    static const char* co = getenv("FDGAN_DEBUG_COALESCE");
+    if (co && d->ksize == 1) a.pad = atoi(co);
   }
   nimg = x->n;
   return FD_OK;

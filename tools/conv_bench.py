@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one fused conv launch through the C ABI (kernel tuning aid).
+
+  python tools/conv_bench.py --k 3 --cin 128 --cout 32 --n 16 --hw 256 --bn --stats --pitch-out 256
+Prints one JSON line per configuration: average launch time (hipEvents around each launch
+of a recorded plan), algorithmic GB/s and TFLOP/s.  `--suite netg` runs the netG hot shapes.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "fd-gan_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+from fdgan_hip import engine as E  # noqa: E402
+from fdgan_hip import lib as L  # noqa: E402
+
+
+def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pitch_in=None, pitch_out=None,
+        bias=False, layout=None, reps=20, upsample=False):
+    dev = torch.device("cuda:0")
+    pad = k // 2 if k == 3 else (1 if k == 4 else 0)
+    pitch_in = pitch_in or (cin + 7) // 8 * 8
+    ho, wo = (h // 2, w // 2) if pool else (h + 2 * pad - k + 1, w + 2 * pad - k + 1)
+    up = 2 if upsample else 1
+    pitch_out = pitch_out or (cout + 7) // 8 * 8
+    x = (torch.randn(n, h, w, pitch_in, device=dev) * 0.7).to(torch.bfloat16)
+    y = torch.empty(n, ho * up, wo * up, pitch_out, dtype=torch.bfloat16, device=dev)
+    wt = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
+    pw = E.PackedWeight(wt, cout, cin, k, layout=layout)
+    pw.pack()
+    b = torch.randn(cout, device=dev) if bias else None
+    pro = None
+    keep = []
+    if bn or relu or pool:
+        kw = dict(act=L.ACT_RELU if (relu or bn) else L.ACT_NONE, pool=pool)
+        if bn:
+            mean, var = torch.randn(cin, device=dev) * 0.1, torch.rand(cin, device=dev) + 0.5
+            g, bt = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
+            keep += [mean, var, g, bt]
+            kw.update(mean=mean, var=var, gamma=g, beta=bt)
+        pro = E.make_prologue(**kw)
+    ws = torch.empty(1 << 23, dtype=torch.float32, device=dev) if stats else None
+    desc = E.conv_desc(k, 1, pad, L.ACT_NONE, upsample, cout=cout, w_layout=pw.layout)
+    xv, yv = E.View(x, 0, cin), E.View(y, 0, (cout + 3) // 4 * 4 if (cout + 3) // 4 * 4 <= pitch_out else cout)
+    plan = E.Plan()
+    with plan.record():
+        for _ in range(reps):
+            E.conv2d(xv.fd, pw, b, pro, yv.fd, desc, ws)
+    for _ in range(2):
+        plan.launch()
+    torch.cuda.synchronize()
+    ms = plan.profile()
+    ms = sorted(ms)[len(ms) // 4: -len(ms) // 4 or None]          # inter-quartile mean
+    t = sum(ms) / len(ms) * 1e-3
+    byt = n * h * w * cin * 2 + n * ho * up * wo * up * cout * 2
+    fl = 2.0 * n * ho * wo * (4 if pool else 1) * cout * cin * k * k
+    return {"kernel": plan.kernel_names()[0], "shape": "%d->%d k%d @%dx%d n%d" % (cin, cout, k, h, w, n),
+            "us": round(t * 1e6, 2), "GB/s": round(byt / t / 1e9, 1), "TFLOP/s": round(fl / t / 1e12, 1),
+            "MB": round(byt / 1e6, 1)}
+
+
+SUITES = {
+    "netg": [
+        dict(k=3, cin=128, cout=32, n=16, h=256, w=256, bn=True, stats=True, pitch_out=256),
+        dict(k=3, cin=128, cout=32, n=16, h=128, w=128, bn=True, stats=True, pitch_out=512),
+        dict(k=3, cin=128, cout=32, n=16, h=64, w=64, bn=True, stats=True, pitch_out=1024),
+        dict(k=1, cin=64, cout=128, n=16, h=256, w=256, bn=True, stats=True, pitch_in=256),
+        dict(k=1, cin=128, cout=128, n=16, h=256, w=256, bn=True, stats=True, pitch_in=256),
+        dict(k=1, cin=224, cout=128, n=16, h=256, w=256, bn=True, stats=True, pitch_in=256),
+        dict(k=1, cin=480, cout=128, n=16, h=128, w=128, bn=True, stats=True, pitch_in=512),
+        dict(k=1, cin=992, cout=128, n=16, h=64, w=64, bn=True, stats=True, pitch_in=1024),
+        dict(k=1, cin=256, cout=128, n=16, h=256, w=256, bn=True, pool=True, pitch_out=160),
+        dict(k=3, cin=160, cout=128, n=16, h=128, w=128, bias=True, stats=True, pitch_out=512),
+        dict(k=3, cin=640, cout=512, n=16, h=32, w=32, bias=True, pitch_out=768),
+        dict(k=3, cin=1024, cout=256, n=16, h=32, w=32, relu=True, pitch_out=768),
+    ],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--suite", default="")
+    for nm in ("k", "cin", "cout", "n", "hw", "pitch-in", "pitch-out", "reps"):
+        ap.add_argument("--" + nm, type=int, default=None)
+    for nm in ("bn", "relu", "stats", "pool", "bias"):
+        ap.add_argument("--" + nm, action="store_true")
+    ap.add_argument("--layout", type=int, default=None)
+    a = ap.parse_args()
+    L.load()
+    if a.suite:
+        for cfg in SUITES[a.suite]:
+            print(json.dumps(run(**cfg)), flush=True)
+        return
+    print(json.dumps(run(a.k, a.cin, a.cout, a.n or 16, a.hw, a.hw, a.bn, a.relu, a.stats, a.pool, a.pitch_in,
+                         a.pitch_out, a.bias, a.layout, a.reps or 20)))
+
+
+if __name__ == "__main__":
+    main()
