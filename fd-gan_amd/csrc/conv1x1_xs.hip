@@ -27,9 +27,16 @@ struct XsCfg {
   static constexpr int TILE_PX = NW * WPX;
   static constexpr int BN = CT * 16;
   static constexpr int NL = POOL ? 4 : 1;      // source pixels per output pixel
-  __host__ __device__ static unsigned w_bytes(int nks) { return (unsigned)nks * 2 * CT * 1024; }
-  __host__ __device__ static unsigned lds_bytes(int nks) {
-    return w_bytes(nks) + nks * 64 * 8 + NW * BN * 2 * 4 + NW * RowStore<SC>::BYTES;
+  // LDS: [kgroup k-steps of the filter][scale, shift for all nks*64 channels][stats][row-store staging]
+  __host__ __device__ static unsigned w_bytes(int kgroup) { return (unsigned)kgroup * 2 * CT * 1024; }
+  __host__ __device__ static unsigned lds_bytes(int nks, int kgroup) {
+    return w_bytes(kgroup) + nks * 64 * 8 + NW * BN * 2 * 4 + NW * RowStore<SC>::BYTES;
+  }
+  // largest k-group (<= nks) whose filter slice fits next to the fixed parts
+  static int max_kgroup(int nks) {
+    const long long fixed = (long long)nks * 64 * 8 + NW * BN * 2 * 4 + NW * RowStore<SC>::BYTES;
+    long long g = (160ll * 1024 - fixed) / (2 * CT * 1024);
+    return (int)(g < nks ? g : nks);
   }
 };
 
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
   using C = XsCfg<POOL, PT, CT, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w_lds = smem;                                                   // [nks][2][CT][1 KiB]
-  float* sc_lds = reinterpret_cast<float*>(smem + C::w_bytes(a.nks));    // [nks*64]
+  float* sc_lds = reinterpret_cast<float*>(smem + C::w_bytes(a.kgroup)); // [nks*64]
   float* sh_lds = sc_lds + a.nks * 64;
   float* red = sh_lds + a.nks * 64;                                     // [NW][BN][2]
   char* tb = reinterpret_cast<char*>(red + C::NW * C::BN * 2) + (threadIdx.x >> 6) * RowStore<C::SC>::BYTES;  // row-store staging
@@ -49,18 +56,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
 
   // ---- once per workgroup: BN fold, filter -> LDS, zero the statistics accumulators
   fd_fold_bn(a, sc_lds, sh_lds, a.nks * 64, tid, C::NT);
-  {
-    const int nunits = a.nks * 2 * CT * 64;
+  // filter k-steps [k0, k0+cnt) -> LDS (lane-linear fragments); all threads
+  auto load_w = [&](int k0, int cnt) {
+    const int nunits = cnt * 2 * CT * 64;
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     for (int u = tid; u < nunits; u += C::NT) {
       const int kj = u / (CT * 64), rem = u - kj * (CT * 64);
       const int tile16 = by * CT + (rem >> 6);
       const bool ok = tile16 < a.ntile_total;
       const u32x4 v = *reinterpret_cast<const u32x4*>(
-          a.w + (ok ? ((long long)kj * a.ntile_total + tile16) * 512 + (rem & 63) * 8 : 0));
+          a.w + (ok ? ((long long)(k0 * 2 + kj) * a.ntile_total + tile16) * 512 + (rem & 63) * 8 : 0));
       lds_write16(w_lds + u * 16, ok ? v : z4);
     }
-  }
+  };
+  const bool resident = a.kgroup >= a.nks;   // the whole filter stays in LDS for every tile
+  if (resident) load_w(0, a.nks);
   for (int i = tid; i < C::NW * C::BN * 2; i += C::NT) red[i] = 0.f;
   __syncthreads();
 
@@ -125,6 +135,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
 
     for (int ks = 0; ks < a.nks; ++ks) {
       const bool last = ks + 1 == a.nks;
+      const int kl = resident ? ks : ks % a.kgroup;   // k-step index inside the LDS-resident slice
+      if (!resident && kl == 0) {                     // stream the next filter slice (uniform per workgroup)
+        __syncthreads();                              // every wave is done with the previous slice
+        const int left = a.nks - ks;
+        load_w(ks, left < a.kgroup ? left : a.kgroup);
+        __syncthreads();
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // registers -> activated bf16 fragments; the freed registers take the next loads (next k-step,
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
           bf16x8 wf[CH];
 #pragma unroll
           for (int c = 0; c < CH; ++c)
-            wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + ((ks * 2 + j) * CT + c0 + c) * 1024));
+            wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + ((kl * 2 + j) * CT + c0 + c) * 1024));
 #pragma unroll
           for (int p = 0; p < PT; ++p)
 #pragma unroll
@@ -298,12 +315,14 @@ static int num_cus() {
   return g_num_cus;
 }
 
-#define FD_XS_LAUNCH(POOL_, PT_, CT_, NW_, NAME_)                                                                   \
+#define FD_XS_LAUNCH(POOL_, PT_, CT_, NW_, PERCU_, NAME_)                                                                   \
   do {                                                                                                          \
     using C = XsCfg<POOL_, PT_, CT_, NW_>;                                                                       \
-    const unsigned lds = C::lds_bytes(a.nks);                                                                   \
+    a.kgroup = C::max_kgroup(a.nks);                                                                            \
+    if (a.kgroup < 1) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: Cin too large for LDS");                           \
+    const unsigned lds = C::lds_bytes(a.nks, a.kgroup);                                                         \
     a.ntiles = (int)((a.P + C::TILE_PX - 1) / C::TILE_PX);                                                      \
-    const int per_cu = (NW_ == 4 && lds <= 80 * 1024) ? 2 : 1;                                                  \
+    const int per_cu = PERCU_;                                                                                  \
     const int ncu = dry ? 256 : num_cus();                                                                      \
     const unsigned gy = (unsigned)((cout_total + C::BN - 1) / C::BN);                                           \
     long long gx = (long long)per_cu * ncu / gy;                                                                \
@@ -334,19 +353,12 @@ static int num_cus() {
   } while (0)
 
 // 4 waves per workgroup (two workgroups per CU) while the LDS-resident filter leaves room for
-// two; otherwise ONE 8-wave workgroup per CU, so the CU still runs two waves per SIMD.
-#define FD_XS_DISPATCH(POOL_, PT_, CT_, NAME_)                                       \
-  do {                                                                              \
-    if (XsCfg<POOL_, PT_, CT_, 4>::lds_bytes(a.nks) <= 80 * 1024)                   \
-      FD_XS_LAUNCH(POOL_, PT_, CT_, 4, NAME_);                                      \
-    FD_XS_LAUNCH(POOL_, PT_, CT_, 8, NAME_ "_w8");                                  \
-  } while (0)
-
+// two; otherwise ONE 8-wave workgroup per CU (still two waves per SIMD), with 32-pixel wave
+// tiles when there are too few pixels to give every CU a 512-pixel tile.  Filters larger than
+// LDS are streamed in k-groups (two barriers per group).
 bool conv1x1_xs_fits(int cout_total, int cin) {
-  const int nks = (cin + 63) / 64;
-  if (cout_total <= 32) return XsCfg<0, 4, 2, 8>::lds_bytes(nks) <= 158 * 1024;
-  if (cout_total <= 64) return XsCfg<0, 4, 4, 8>::lds_bytes(nks) <= 158 * 1024;
-  return XsCfg<0, 4, 8, 8>::lds_bytes(nks) <= 158 * 1024;
+  (void)cout_total;
+  return cin >= 1 && cin <= 4096;   // scale/shift for every input channel must fit LDS
 }
 
 int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, FdConvInfo* info,
@@ -361,12 +373,18 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
   a.y_dense = !a.upsample && !a.out_nchw_f32 && a.y_sh == (long long)a.Wo * a.y_sw &&
               a.y_sn == (long long)a.Ho * a.y_sh;
   if (!conv1x1_xs_fits(cout_total, a.Cin)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: filter does not fit LDS");
+  const int nks = a.nks;
+  const long long big_tiles = (a.P + 511) / 512;
+  const int ncu_ = dry ? 256 : num_cus();
   if (pool) {
-    if (cout_total <= 32) FD_XS_DISPATCH(1, 2, 2, "conv1x1_xs_pool_bn32");
-    if (cout_total <= 64) FD_XS_DISPATCH(1, 2, 4, "conv1x1_xs_pool_bn64");
-    FD_XS_DISPATCH(1, 2, 8, "conv1x1_xs_pool_bn128");
+    if (cout_total <= 32) FD_XS_LAUNCH(1, 2, 2, 4, 2, "conv1x1_xs_pool_bn32");
+    if (cout_total <= 64) FD_XS_LAUNCH(1, 2, 4, 4, 2, "conv1x1_xs_pool_bn64");
+    if (XsCfg<1, 2, 8, 4>::lds_bytes(nks, nks) <= 80 * 1024) FD_XS_LAUNCH(1, 2, 8, 4, 2, "conv1x1_xs_pool_bn128");
+    FD_XS_LAUNCH(1, 2, 8, 8, 1, "conv1x1_xs_pool_bn128_w8");
   }
-  if (cout_total <= 32) FD_XS_DISPATCH(0, 4, 2, "conv1x1_xs_bn32");
-  if (cout_total <= 64) FD_XS_DISPATCH(0, 4, 4, "conv1x1_xs_bn64");
-  FD_XS_DISPATCH(0, 4, 8, "conv1x1_xs_bn128");
+  if (cout_total <= 32) FD_XS_LAUNCH(0, 4, 2, 4, 2, "conv1x1_xs_bn32");
+  if (cout_total <= 64) FD_XS_LAUNCH(0, 4, 4, 4, 2, "conv1x1_xs_bn64");
+  if (XsCfg<0, 4, 8, 4>::lds_bytes(nks, nks) <= 80 * 1024) FD_XS_LAUNCH(0, 4, 8, 4, 2, "conv1x1_xs_bn128");
+  if (big_tiles >= ncu_) FD_XS_LAUNCH(0, 4, 8, 8, 1, "conv1x1_xs_bn128_w8");
+  FD_XS_LAUNCH(0, 2, 8, 8, 1, "conv1x1_xs_bn128_w8p2");
 }

@@ -62,9 +62,11 @@ struct ConvArgs {
   unsigned P;   // output pixels N*Ho*Wo
   int ntiles;   // pixel tiles walked by the persistent workgroups
   int nks;      // 64-channel k-steps
+  int kgroup;   // k-steps of the filter resident in LDS at a time (>= nks: whole filter)
   int x_dense;  // x offset of pixel p is p * x_sw (no pooling, contiguous n/h/w)
   int y_dense;  // y offset of pixel p is p * y_sw (no upsample, contiguous n/h/w, NHWC)
   int y_vec16;  // NHWC bf16 output, 16-byte aligned rows, no upsample: row stores allowed
+  unsigned long long* dbg;  // measurement aid: per-wave phase cycle totals of workgroup 0 (or NULL)
 };
 
 __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -106,6 +108,30 @@ __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const f
     f = __builtin_elementwise_fma(f, sv[i], hv[i]);
     const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
     out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
+  }
+  return out;
+}
+
+// Register-operand forms (scale/shift already fetched from LDS): used where one lane applies the
+// same 8 channels to several units, so the 4 LDS reads are paid once instead of per unit.
+__device__ __forceinline__ u32x4 fd_xform8_r(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 h0, f32x4 h1, float slope) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+  const f32x2_t sv[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
+  const f32x2_t hv[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
+  u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2_t f = {__uint_as_float(raw[i] << 16), __uint_as_float(raw[i] & 0xffff0000u)};
+    f = __builtin_elementwise_fma(f, sv[i], hv[i]);
+    if (slope == 0.f) {   // uniform: ReLU on the packed result
+      const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+      out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
+    } else {
+      f = __builtin_elementwise_max(f, f * slope);
+      out[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+    }
   }
   return out;
 }
@@ -567,7 +593,11 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
                         long long stats_cap, bool dry, hipStream_t stream);
 int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
+bool conv3x3_pw_fits(int cout_total, int cin);
+int conv_dispatch_k3_pw(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
+                        hipStream_t stream);
 int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
+extern unsigned long long* g_fd_debug_timing;
 // tanh / sigmoid applied in place on what a conv stored (elementwise.hip)
 int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream);

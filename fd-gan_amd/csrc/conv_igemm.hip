@@ -4,6 +4,12 @@
 
 #include "conv_igemm.h"
 
+unsigned long long* g_fd_debug_timing = nullptr;
+extern "C" int fdgan_debug_timing(void* device_buf) {
+  g_fd_debug_timing = static_cast<unsigned long long*>(device_buf);
+  return FD_OK;
+}
+
 extern "C" int fdgan_conv_weight_layout(int cout, int cin, int ksize, int stride) {
   // 1x1 stride-1 filters that fit LDS run on the x-stream kernel (conv1x1_xs.hip), which
   // consumes the "x64" fragment order; everything else uses the 32-channel chunk order.
@@ -124,6 +130,7 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
     a.y_sc = 1;
   }
   a.stats = stats ? stats->partial : nullptr;
+  a.dbg = g_fd_debug_timing;
   {  // measurement aid (tools only): FDGAN_DEBUG_NOSTORE=1 drops every output store
     static const bool nostore = getenv("FDGAN_DEBUG_NOSTORE") != nullptr;
     if (nostore) a.Cout = 0;

@@ -200,6 +200,12 @@ int fdgan_plan_time_launches(FdPlan* p, const int64_t* idx, int64_t n);
 int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* launches);
 int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
 
+/* ---- measurement aid (tools/conv_bench.py) ------------------------------------- */
+/* While `device_buf` (>= 64 x int64) is set, the persistent 3x3 kernel's workgroup 0 writes,
+ * per wave w, cycle totals of its pipeline phases to device_buf[w*8 + {0: MFMA block, 1: staging
+ * (vmcnt wait + transform + LDS write), 2: barrier, 3: epilogue, 4: steps}].  NULL disables. */
+int fdgan_debug_timing(void* device_buf);
+
 #ifdef __cplusplus
 }
 #endif

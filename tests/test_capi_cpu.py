@@ -41,11 +41,14 @@ def test_host_only_entry_points():
         t.dtype = L.FD_BF16
         return t
     info = E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1))
-    assert (info.grid_x, info.grid_y, info.stats_rows, info.stats_cpad) == (4096, 1, 4096, 32)
-    assert info.lds_bytes <= 80 * 1024                                              # two workgroups per CU
-    info = E.conv_info(fd(16, 256, 256, 256, 256), fd(16, 128, 128, 128, 160), 128, E.conv_desc(1),
+    # persistent-filter kernel: one 8-wave workgroup per CU, one statistics row per workgroup
+    assert (info.grid_x, info.grid_y, info.stats_rows, info.stats_cpad) == (256, 1, 256, 32)
+    assert info.lds_bytes <= 160 * 1024
+    assert lib.fdgan_conv_weight_layout(128, 256, 1, 1) == L.WLAYOUT_X64
+    info = E.conv_info(fd(16, 256, 256, 256, 256), fd(16, 128, 128, 128, 160), 128,
+                       E.conv_desc(1, w_layout=L.WLAYOUT_X64),
                        E.make_prologue(pool=True))
-    assert (info.grid_x, info.grid_y) == (16 * 16 * 8, 1)
+    assert (info.grid_x, info.grid_y) == (512, 1)                                   # persistent x-stream kernel
     # argument validation crosses the ABI as an error code + message, never an abort
     bad = fd(1, 8, 8, 16, 12)
     rc = lib.fdgan_conv2d_fwd_info(C.byref(bad), C.byref(fd(1, 8, 8, 16, 16)), 16, C.byref(E.conv_desc(3, 1, 1)), None,

@@ -123,6 +123,15 @@ def test_conv3x3_128_to_32_bn_relu_stats(E):
     _run(E, 2, 32, 48, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=256, c0_out=96, running=True)
 
 
+def test_conv3x3_persistent_filter_kernel(E):
+    """conv3x3_pw: ragged tiles, several tiles per workgroup (persistence + register statistics),
+    partial last chunk, NHWC fallback stores."""
+    _run(E, 3, 40, 24, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=96, c0_out=64, seed=40)
+    _run(E, 16, 128, 128, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=64, c0_out=32, seed=41)
+    _run(E, 2, 33, 17, 72, 20, 3, pad=1, p_act=ACT_LEAKY02, bias=True, stats=True, seed=42)
+    _run(E, 1, 64, 64, 16, 3, 3, pad=1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=43)
+
+
 # dense-layer bottleneck: 1x1 over a channel prefix of a wider concat buffer
 def test_conv1x1_prefix_to_128_bn_relu_stats(E):
     _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3)
@@ -141,7 +150,7 @@ def test_conv1x1_xstream_shapes(E):
     """x-stream kernel: ragged pixel counts, every BN width, NCHW fp32 output, many tiles per workgroup."""
     from fdgan_hip import lib as L
     assert L.load().fdgan_conv_weight_layout(128, 224, 1, 1) == L.WLAYOUT_X64
-    assert L.load().fdgan_conv_weight_layout(128, 992, 1, 1) == L.WLAYOUT_CHUNK32
+    assert L.load().fdgan_conv_weight_layout(128, 992, 1, 1) == L.WLAYOUT_X64      # streamed in k-groups
     assert L.load().fdgan_conv_weight_layout(32, 128, 3, 1) == L.WLAYOUT_CHUNK32
     _run(E, 3, 19, 23, 224, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=21, running=True)
     _run(E, 2, 10, 14, 160, 64, 1, bias=True, e_act=ACT_RELU, stats=True, seed=22)
@@ -150,6 +159,11 @@ def test_conv1x1_xstream_shapes(E):
     _run(E, 1, 16, 16, 40, 3, 1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=25)
     _run(E, 8, 128, 128, 64, 128, 1, bn=True, p_act=ACT_RELU, stats=True, seed=26)  # > 1 tile per workgroup
     _run(E, 2, 36, 20, 512, 256, 1, bn=True, p_act=ACT_RELU, pool=True, stats=True, seed=27)
+    # filters larger than LDS: streamed k-groups, 8-wave workgroups, 32-pixel wave tiles
+    _run(E, 2, 24, 24, 992, 128, 1, pitch_in=1024, bn=True, p_act=ACT_RELU, stats=True, seed=28)
+    _run(E, 1, 16, 16, 1024, 512, 1, bn=True, p_act=ACT_RELU, pool=True, seed=29)
+    _run(E, 16, 64, 64, 768, 128, 1, p_act=ACT_RELU, upsample=True, transposed=True, pitch_out=512, seed=30)
+    _run(E, 16, 128, 128, 480, 128, 1, pitch_in=512, bn=True, p_act=ACT_RELU, stats=True, seed=31)
 
 
 def test_transition_pool_prologue(E):
@@ -196,7 +210,7 @@ def test_plan_replay_matches_eager(E):
     with plan.record():
         E.conv2d(E.View(x).fd, pw, None, None, E.View(y1).fd, d)
     torch.cuda.synchronize()
-    assert (y1 == 0).all() and len(plan) == 1 and plan.kernel_names() == ["conv3x3_bn32"]
+    assert (y1 == 0).all() and len(plan) == 1 and plan.kernel_names() == ["conv3x3_pw_bn32"]
     plan.launch()
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)

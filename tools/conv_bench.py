@@ -51,6 +51,14 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
     with plan.record():
         for _ in range(reps):
             E.conv2d(xv.fd, pw, b, pro, yv.fd, desc, ws)
+    dbg = None
+    if os.environ.get("FDGAN_TIMING"):
+        dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+        L.load().fdgan_debug_timing(dbg.data_ptr())
+        E.conv2d(xv.fd, pw, b, pro, yv.fd, desc, ws)
+        torch.cuda.synchronize()
+        L.load().fdgan_debug_timing(None)
+        print("phase cycles per wave [mfma, staging, barrier, epilogue, steps]:", dbg.view(8, 8)[:, :5].tolist())
     for _ in range(2):
         plan.launch()
     torch.cuda.synchronize()
