@@ -1,0 +1,54 @@
+// pool.hip -- 2x2 stride-2 max pooling on NHWC bf16 views (F.max_pool2d(h, 2, 2),
+// /root/reference/myutils/vgg16.py:31,36,42).  HBM-bound: 16 bytes (8 channels) per thread.
+#include "common.h"
+
+namespace {
+struct PoolArgs {
+  const unsigned short* x;
+  unsigned short* y;
+  long long x_sn, x_sh, x_sw, y_sn, y_sh, y_sw;
+  int Ho, Wo, groups;
+  long long total;
+};
+
+__global__ void maxpool2_kernel(PoolArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  const int g = (int)(r % a.groups);
+  r /= a.groups;
+  const int ox = (int)(r % a.Wo);
+  r /= a.Wo;
+  const int oy = (int)(r % a.Ho);
+  const long long n = r / a.Ho;
+  const unsigned short* p = a.x + n * a.x_sn + (long long)(2 * oy) * a.x_sh + (long long)(2 * ox) * a.x_sw + g * 8;
+  const bf16x8 v0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+  const bf16x8 v1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sw));
+  const bf16x8 v2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sh));
+  const bf16x8 v3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw));
+  f32x8 f0 = __builtin_convertvector(v0, f32x8), f1 = __builtin_convertvector(v1, f32x8);
+  f32x8 f2 = __builtin_convertvector(v2, f32x8), f3 = __builtin_convertvector(v3, f32x8);
+  f32x8 m;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = fmaxf(fmaxf(f0[e], f1[e]), fmaxf(f2[e], f3[e]));
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)oy * a.y_sh + (long long)ox * a.y_sw + g * 8) =
+      __builtin_bit_cast(u32x4, __builtin_convertvector(m, bf16x8));
+}
+}  // namespace
+
+extern "C" int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream) {
+  FD_REQUIRE(x && y && x->ptr && y->ptr, "maxpool2_nhwc: NULL pointer");
+  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1,
+             "maxpool2_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(y->n == x->n && y->h == x->h / 2 && y->w == x->w / 2 && y->c == x->c && x->c % 8 == 0,
+             "maxpool2_nhwc: shape mismatch (c must be a multiple of 8)");
+  FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0, "maxpool2_nhwc: 16-byte alignment");
+  for (int i = 0; i < 3; ++i)
+    FD_REQUIRE(x->stride[i] % 8 == 0 && y->stride[i] % 8 == 0, "maxpool2_nhwc: strides must be multiples of 8");
+  PoolArgs a{static_cast<const unsigned short*>(x->ptr), static_cast<unsigned short*>(y->ptr),
+             x->stride[0], x->stride[1], x->stride[2], y->stride[0], y->stride[1], y->stride[2],
+             (int)y->h, (int)y->w, (int)(x->c / 8), y->n * y->h * y->w * (x->c / 8)};
+  FD_REQUIRE(a.total > 0, "maxpool2_nhwc: empty output");
+  return fd_launch(&maxpool2_kernel, "maxpool2_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}

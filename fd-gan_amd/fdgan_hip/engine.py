@@ -147,6 +147,33 @@ def to_nchw(view, out_f32):
             "nhwc_bf16_to_nchw_f32")
 
 
+def maxpool2(src, dst):
+    L.check(L.load().fdgan_maxpool2_nhwc(C.byref(src.fd), C.byref(dst.fd), stream_ptr()), "maxpool2_nhwc")
+
+
+def blur15(x, use_input_norm=True):
+    """x: contiguous NCHW fp32 cuda tensor -> Blur(l=15, sigma=3)(x), same shape."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().fdgan_blur15_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, int(bool(use_input_norm)), stream_ptr()),
+            "blur15_fwd")
+    return y
+
+
+def laplacian3(x):
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().fdgan_laplacian3_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, stream_ptr()), "laplacian3_fwd")
+    return y
+
+
+def fusion_input_nhwc(img, view, use_input_norm=True):
+    """img: NCHW fp32 (n,c,h,w) -> channels [img | LF | HF] of the NHWC bf16 view (D's input)."""
+    n, c, h, w = img.shape
+    L.check(L.load().fdgan_fusion_input_nhwc(img.data_ptr(), n, c, h, w, C.byref(view.fd), int(bool(use_input_norm)),
+                                             stream_ptr()), "fusion_input_nhwc")
+
+
 def copy_nhwc(src, dst):
     L.check(L.load().fdgan_copy_nhwc(C.byref(src.fd), C.byref(dst.fd), stream_ptr()), "copy_nhwc")
 

@@ -1,0 +1,86 @@
+"""MI355X-native `myutils.vgg16.Vgg16`: the perceptual-loss feature extractor
+(/root/reference/myutils/vgg16.py:6-49).  Same constructor, same 26 state_dict tensors
+(conv5_x registered but never called, :23-25), same output: [relu1_2, relu2_2, relu3_3, relu4_3]
+as NCHW fp32 tensors.  The ten 3x3 convs (+bias, +ReLU) run as NHWC bf16 implicit-GEMM MFMA
+kernels, the three 2x2 max-pools as an NHWC kernel, all recorded in one plan per input shape.
+"""
+import torch
+import torch.nn as nn
+
+from fdgan_hip import engine as E
+from fdgan_hip import lib as L
+from fdgan_hip.netplan import NetPlan
+
+_CFG = [("conv1_1", 3, 64), ("conv1_2", 64, 64), "tap", "pool",
+        ("conv2_1", 64, 128), ("conv2_2", 128, 128), "tap", "pool",
+        ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), "tap", "pool",
+        ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), "tap"]
+_UNUSED = [("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512)]
+
+
+class Vgg16(torch.nn.Module):
+    def __init__(self):
+        super(Vgg16, self).__init__()
+        for item in _CFG + _UNUSED:
+            if isinstance(item, tuple):
+                setattr(self, item[0], nn.Conv2d(item[1], item[2], kernel_size=3, stride=1, padding=1))
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_plans", None)
+        return super()._apply(fn, *a, **k)
+
+    def _plan_for(self, X):
+        E.require_gpu(X, "Vgg16.forward")
+        if X.dim() != 4 or X.shape[1] != 3:
+            raise ValueError("Vgg16 expects a Bx3xHxW tensor, got %s" % (tuple(X.shape),))
+        cache = self.__dict__.setdefault("_plans", {})
+        key = (tuple(X.shape), X.device.index)
+        P = cache.get(key)
+        if P is not None and P.param_ptrs() != P._built_ptrs:
+            P = None
+        if P is None:
+            P = self._build(tuple(X.shape), X.device)
+            P._built_ptrs = P.param_ptrs()
+            cache[key] = P
+        return P
+
+    def _build(self, shape, dev):
+        n, _, h, w = shape
+        if h % 8 or w % 8:
+            raise ValueError("Vgg16 on the HIP path needs H and W to be multiples of 8, got %dx%d" % (h, w))
+        P = NetPlan(dev)
+        P.xin = E.new_act(n, h, w, 8, dev, zero=True)
+        cur, cur_c = P.xin, 3
+        P.taps = []
+        for item in _CFG:
+            if item == "tap":
+                P.taps.append(E.View(cur, 0, cur_c))
+            elif item == "pool":
+                nxt = E.new_act(n, cur.shape[1] // 2, cur.shape[2] // 2, cur_c, dev)
+                src, dst = E.View(cur, 0, cur_c), E.View(nxt)
+                P.op(lambda s=src, d=dst: E.maxpool2(s, d))
+                P.keep += [src, dst]
+                cur = nxt
+            else:
+                name, cin, cout = item
+                conv = getattr(self, name)
+                nxt = E.new_act(n, cur.shape[1], cur.shape[2], cout, dev)
+                P.conv(E.View(cur, 0, cin), P.weight(conv.weight, cout, cin, 3), E.View(nxt), 3, pad=1, bias=conv.bias,
+                       e_act=L.ACT_RELU, label=name)
+                cur, cur_c = nxt, cout
+        return P.finish()
+
+    def forward(self, X):
+        P = self._plan_for(X)
+        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("Vgg16 backward through the HIP plan is not built yet; call under torch.no_grad()")
+        with torch.no_grad():
+            E.to_nhwc(X.detach().float().contiguous(), E.View(P.xin))
+            P.launch()
+            outs = []
+            for v in P.taps:
+                nn_, hh, ww, cc = v.shape
+                o = torch.empty((nn_, cc, hh, ww), dtype=torch.float32, device=X.device)
+                E.to_nchw(v, o)
+                outs.append(o)
+        return outs

@@ -200,10 +200,32 @@ int fdgan_plan_time_launches(FdPlan* p, const int64_t* idx, int64_t n);
 int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* launches);
 int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
 
+/* ---- pooling ------------------------------------------------------------------- */
+/* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
+ * y is (n, h/2, w/2, c), c a multiple of 8. */
+int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);
+
+/* ---- frequency split of the Fusion-discriminator input ------------------------- */
+/* Reference: __pycache__/loss.cpython-36.pyc (source loss.py absent).
+ * x, y: NCHW fp32 contiguous, (n, c, h, w).
+ * fdgan_blur15_fwd     = Blur(l=15, isotropic_gaussian_kernel(15, 3.0)).forward  (loss.py:122-162):
+ *                        optional (x - ImageNet mean) / std (c must be 3), ReflectionPad2d(7),
+ *                        the same normalised 15x15 Gaussian on every (b, c) plane.  h, w >= 8.
+ * fdgan_laplacian3_fwd = Laplacian(3).forward (loss.py:245-304): depthwise 3x3, ones with
+ *                        centre -8, zero padding 1, not normalised.
+ * fdgan_fusion_input_nhwc fuses both with the layout change D needs: reads img once and writes
+ *   channels [img | Blur(img) | Laplacian(img)] (3*c) of the NHWC bf16 view y (the concat fed to
+ *   D, facades/network.png); channels of y beyond 3*c are left untouched. */
+int fdgan_blur15_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
+                     FdStream stream);
+int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
+int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w, const FdTensor* y,
+                            int use_input_norm, FdStream stream);
+
 /* ---- measurement aid (tools/conv_bench.py) ------------------------------------- */
-/* While `device_buf` (>= 64 x int64) is set, the persistent 3x3 kernel's workgroup 0 writes,
- * per wave w, cycle totals of its pipeline phases to device_buf[w*8 + {0: MFMA block, 1: staging
- * (vmcnt wait + transform + LDS write), 2: barrier, 3: epilogue, 4: steps}].  NULL disables. */
+/* Registers a device buffer (>= 64 x int64) that instrumented kernel builds fill with per-wave
+ * s_memtime phase totals of workgroup 0 (the round-1 phase analysis of the persistent 3x3 kernel
+ * in DESIGN.md was taken this way).  The shipped kernels carry no instrumentation; NULL disables. */
 int fdgan_debug_timing(void* device_buf);
 
 #ifdef __cplusplus

@@ -162,3 +162,65 @@ def test_fusion_d_matches_golden(nets, golden_dir):
         y2 = d(x2.to(DEV)).cpu()
     assert y2.shape == y_ref.shape == (1, 1, 34, 26)
     assert float((y2 - y_ref).abs().max()) < 2e-2
+
+
+def test_frequency_split_matches_oracle_and_golden(golden_dir):
+    import loss
+    from fdgan_hip import engine as E
+    from oracle import freqsplit_ref
+    from oracle.detweights import det_input
+    gold = np.load(os.path.join(golden_dir, "freqsplit.npz"))
+    x = det_input((2, 3, 40, 48), seed=11)
+    xg = x.to(DEV)
+    b_n = loss.blur(xg).cpu()                               # module-level instance, use_input_norm=True
+    b_r = loss.Blur(15, loss.blur_kernel, use_input_norm=False)(xg).cpu()
+    lp = loss.laplace_filter(xg).cpu()
+    assert (b_n - torch.from_numpy(gold["blur_norm"])).abs().max() < 2e-5
+    assert (b_r - torch.from_numpy(gold["blur_raw"])).abs().max() < 2e-6
+    assert (lp - torch.from_numpy(gold["lap"])).abs().max() < 1e-5
+    # known answers: Blur(const) == const, Laplacian(const) = 0 / -3c / -5c
+    c = torch.full((1, 3, 64, 72), 0.7, device=DEV)
+    assert (loss.Blur(use_input_norm=False)(c) - 0.7).abs().max() < 1e-6
+    lc = loss.laplace_filter(torch.ones(1, 3, 9, 11, device=DEV)).cpu()
+    assert lc[0, 0, 4, 4] == 0 and lc[0, 1, 0, 0] == -5 and lc[0, 2, 0, 5] == -3 and lc[0, 0, 8, 10] == -5
+    with pytest.raises(ValueError):
+        loss.laplace_filter(torch.ones(3, 8, 8, device=DEV))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loss.blur(x)
+    # fused D input: [img | LF | HF] as NHWC bf16, larger ragged image
+    x2 = det_input((2, 3, 70, 90), seed=12).to(DEV)
+    buf = E.new_act(2, 70, 90, 16, torch.device(DEV), zero=True)
+    E.fusion_input_nhwc(x2, E.View(buf, 0, 9), use_input_norm=True)
+    got = E.View(buf, 0, 9).torch_nchw().cpu()
+    ref = torch.cat([x2.cpu(), freqsplit_ref.blur(x2.cpu(), use_input_norm=True), freqsplit_ref.laplacian(x2.cpu())], 1)
+    assert ((got - ref).abs() / (ref.abs() + 1.0)).max() < 8e-3           # bf16 storage
+    assert (E.View(buf, 9, 7).torch_nchw() == 0).all()
+    assert torch.allclose(loss.fusion_input(x2).cpu(), ref, atol=3e-5)
+
+
+def test_vgg16_matches_golden(golden_dir):
+    from myutils.vgg16 import Vgg16
+    from oracle.vgg16_ref import Vgg16 as OVgg
+    from oracle.detweights import det_input, fill_state_dict
+    ov = OVgg()
+    fill_state_dict(ov, seed=0)
+    v = Vgg16()
+    assert list(v.state_dict().keys()) == list(ov.state_dict().keys())
+    v.load_state_dict(ov.state_dict())
+    v = v.to(DEV)
+    gold = np.load(os.path.join(golden_dir, "vgg16_1x32.npz"))
+    with torch.no_grad():
+        feats = v(det_input((1, 3, 32, 32), seed=9).to(DEV))
+    assert [tuple(f.shape) for f in feats] == [(1, 64, 32, 32), (1, 128, 16, 16), (1, 256, 8, 8), (1, 512, 4, 4)]
+    rep = {}
+    for i, f in enumerate(feats):
+        rep["relu%d" % i] = rel_rms(f.cpu(), torch.from_numpy(gold["relu%d" % i]))
+    _report("vgg16", rep)
+    assert max(rep.values()) < 2e-2, rep
+    # a second, non-square shape against the CPU oracle
+    x = det_input((2, 3, 48, 80), seed=10)
+    with torch.no_grad():
+        fr = ov(x)
+        fg = v(x.to(DEV))
+    for a, b in zip(fg, fr):
+        assert a.shape == b.shape and rel_rms(a.cpu(), b) < 2e-2
