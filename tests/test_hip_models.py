@@ -224,3 +224,43 @@ def test_vgg16_matches_golden(golden_dir):
         fg = v(x.to(DEV))
     for a, b in zip(fg, fr):
         assert a.shape == b.shape and rel_rms(a.cpu(), b) < 2e-2
+
+
+def test_demo_end_to_end_png_parity(nets, tmp_path):
+    """demo.py's whole pipeline (dataset -> `module.`-prefixed checkpoint -> train-mode generator on
+    the HIP path -> min-max normalised PNG) against the oracle pushed through the same writer:
+    SURVEY 8c's acceptance is PSNR within 0.02 dB and SSIM within 1e-3 of the reference's score."""
+    net, ref = nets
+    import demo
+    import misc
+    import PSNRSSIM as ps
+    from datasets.pix2pix import write_pair
+    from oracle.detweights import det_input, fill_state_dict
+    from PIL import Image
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    ck = str(tmp_path / "netG_epoch_0.pth")
+    torch.save({"module." + k: v for k, v in og.state_dict().items()}, ck)
+    root, res, oref, gtd = (str(tmp_path / d) for d in ("ds", "res", "oref", "gt"))
+    for d in (res, oref, gtd):
+        os.makedirs(d)
+    hz = det_input((2, 3, 96, 128), seed=77, lo=0.0, hi=1.0)
+    gt = det_input((2, 3, 96, 128), seed=78, lo=0.0, hi=1.0)
+    for i in range(2):
+        write_pair(root, i, hz[i].permute(1, 2, 0).numpy(), gt[i].permute(1, 2, 0).numpy())
+        Image.fromarray(misc.to_uint8_image(gt[i], normalize=False)).save(os.path.join(gtd, "%d.png" % i))
+    opt = demo.build_parser().parse_args(["--valDataroot", root, "--netG", ck, "--outDir", res, "--workers", "0"])
+    written = demo.run(opt)
+    assert [os.path.basename(p) for p in written] == ["0.png", "1.png"]
+    for i in range(2):                          # the reference runs batch 1 in train mode, one sample per call
+        with torch.no_grad():
+            y = og(hz[i:i + 1].clone())
+        misc.save_image(y[0], os.path.join(oref, "%d.png" % i), normalize=True)
+    direct_p, direct_s = ps.score_dirs(oref, res, verbose=False)
+    hp, hs = ps.score_dirs(gtd, res, verbose=False)
+    rp, rs = ps.score_dirs(gtd, oref, verbose=False)
+    rep = {"png_psnr_hip_vs_oracle": direct_p, "png_ssim_hip_vs_oracle": direct_s, "psnr_vs_gt": [hp, rp],
+           "ssim_vs_gt": [hs, rs]}
+    _report("demo_png", rep)
+    assert min(direct_p) > 35.0 and min(direct_s) > 0.98, rep
+    assert abs(np.mean(hp) - np.mean(rp)) < 0.02 and abs(np.mean(hs) - np.mean(rs)) < 1e-3, rep
