@@ -97,17 +97,13 @@ def cpu_baseline(state_dict, size, seconds):
 def main():
     a = parse()
     import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    from fdgan_hip.dp import DpContext
+    dp = DpContext.from_env(backend="nccl")           # RCCL; one process per GPU
+    world, rank, dev = dp.world, dp.rank, dp.device
+    if a.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run "
+                         "--nproc-per-node N ... bench.py --gpus N`" % (a.gpus, world))
 
     from fdgan_hip import lib
     lib.load()
@@ -121,11 +117,7 @@ def main():
     B, S = a.batch, a.size
     x = torch.from_numpy(np.random.default_rng(1234 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    barrier = dp.barrier
 
     with torch.no_grad():
         for _ in range(max(a.warmup, 1)):
@@ -153,15 +145,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(y).all())
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dp.max_over_ranks(dt)
+    images = dp.sum_over_ranks(B * a.steps)
 
     if rank == 0:
         res = {
             "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS",
-            "value": round(world * B * a.steps / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "netG (FDGAN) forward-only, bf16 storage / fp32 accumulate, train-mode "
@@ -207,9 +197,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cpu_sd, S, a.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dp.close()
 
 
 if __name__ == "__main__":

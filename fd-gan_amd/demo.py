@@ -60,9 +60,18 @@ def load_generator_state(path):
 
 
 def run(opt):
-    dev = torch.device('cuda', 0)
+    from fdgan_hip.dp import DpContext
+    dp = DpContext.from_env()            # torchrun: one process per GPU, every world-th image each (demo.py:89's
+    dev = dp.device or torch.device('cuda', 0)   # nn.DataParallel split of the batch, without the gather)
     loader = getLoader(opt.dataset, opt.valDataroot, opt.imageSize, opt.imageSize, opt.valBatchSize, opt.workers,
                        mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), split='Train', shuffle=False, seed=None)
+    names = None
+    if dp.world > 1:
+        if opt.valBatchSize != 1:
+            raise ValueError("multi-GPU demo shards single images: use --valBatchSize 1")
+        names = dp.item_indices(len(loader.dataset))
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(loader.dataset, names), batch_size=1,
+                                             shuffle=False, num_workers=int(opt.workers))
     netG = net.FDGAN()
     sd = load_generator_state(opt.netG)
     missing = [k for k in netG.state_dict() if k not in sd]
@@ -84,10 +93,12 @@ def run(opt):
         print(time.time() - start)
         for _ in range(opt.valBatchSize):
             index += 1
-            print(index)
-            path = os.path.join(opt.outDir, str(index) + '.png')
+            gidx = index if names is None else names[index]
+            print(gidx)
+            path = os.path.join(opt.outDir, str(gidx) + '.png')
             save_image(x_hat[0], path, normalize=True, scale_each=False)   # always element 0 (:141,148)
             written.append(path)
+    dp.close()
     return written
 
 

@@ -77,6 +77,9 @@ def test_module_surface_is_reference_compatible():
     d, od = net.D(9, 36), ref.D(9, 36)
     assert list(d.state_dict().keys()) == list(od.state_dict().keys())
     assert sum(p.numel() for p in d.parameters()) == 790416
+    import models.dehaze22 as net22
+    from oracle import dehaze22_ref as ref22
+    assert list(net22.D(6, 64).state_dict().keys()) == list(ref22.D(6, 64).state_dict().keys())
     b = net.BottleneckBlockdy(64, 32)
     assert set(b.state_dict()) == set(ref.BottleneckBlockdy(64, 32).state_dict())
     assert tuple(net.TransitionBlockdy(96, 16).conv1.weight.shape) == (96, 16, 1, 1)

@@ -1,0 +1,54 @@
+"""N>1 path on CPU: two processes over gloo exercise the sharding and the timing collectives
+bench.py and demo.py use (the forward path itself has no data-path collective)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from fdgan_hip.dp import DpContext
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cpu"))
+    lo, hi = dp.batch_slice(32)
+    items = dp.item_indices(7)
+    dp.barrier()
+    slow = dp.max_over_ranks(1.0 + rank)                 # rank 1 is the slow one
+    total = dp.sum_over_ranks(hi - lo)
+    rate = dp.throughput(16 * 10, 2.0 * (1 + rank))
+    torch.save(dict(lo=lo, hi=hi, items=items, slow=slow, total=total, rate=rate), os.path.join(out_dir, "r%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_sharding_and_timing(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(world)]
+    assert (r[0]["lo"], r[0]["hi"], r[1]["lo"], r[1]["hi"]) == (0, 16, 16, 32)       # SURVEY 8e partitioning
+    assert r[0]["items"] == [0, 2, 4, 6] and r[1]["items"] == [1, 3, 5]
+    assert sorted(r[0]["items"] + r[1]["items"]) == list(range(7))
+    for x in r:
+        assert x["slow"] == 2.0 and x["total"] == 32
+        assert x["rate"] == 2 * 16 * 10 / 4.0                                          # all units / slowest rank
+
+
+def test_single_process_context_is_a_no_op(monkeypatch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    from fdgan_hip.dp import DpContext
+    dp = DpContext.from_env(device=torch.device("cpu"))
+    assert (dp.rank, dp.world) == (0, 1) and dp.batch_slice(16) == (0, 16) and dp.item_indices(3) == [0, 1, 2]
+    assert dp.max_over_ranks(0.5) == 0.5 and dp.throughput(10, 2.0) == 5.0
+    dp.barrier(), dp.close()
+    import pytest
+    monkeypatch.setenv("WORLD_SIZE", "2"), monkeypatch.setenv("RANK", "5")
+    with pytest.raises(ValueError):
+        DpContext.from_env(device=torch.device("cpu"))

@@ -264,3 +264,38 @@ def test_demo_end_to_end_png_parity(nets, tmp_path):
     _report("demo_png", rep)
     assert min(direct_p) > 35.0 and min(direct_s) > 0.98, rep
     assert abs(np.mean(hp) - np.mean(rp)) < 0.02 and abs(np.mean(hs) - np.mean(rs)) < 1e-3, rep
+
+
+def test_dehaze22_d_matches_golden(golden_dir):
+    import models.dehaze22 as net22
+    from oracle import dehaze22_ref as o22
+    from oracle.detweights import det_input, fill_state_dict
+    od = o22.D(9, 36)
+    fill_state_dict(od, seed=2)
+    d = net22.D(9, 36)
+    assert list(d.state_dict().keys()) == list(od.state_dict().keys())
+    d.load_state_dict(od.state_dict())
+    d = d.to(DEV)
+    x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y = d(x.to(DEV)).cpu()
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, "d22_2x64.npz"))["y"])
+    assert y.shape == (2, 1, 6, 6)
+    rep = {"max_abs": float((y - gold).abs().max()), "rel_rms": rel_rms(y, gold)}
+    # 256^2 -> 30x30 patch map (sizePatchGAN, dehaze22.py:150) with D(6,64), eval-mode BN
+    od2, d2 = o22.D(6, 64), net22.D(6, 64)
+    fill_state_dict(od2, seed=3)
+    d2.load_state_dict(od2.state_dict())
+    od2.eval(), d2.eval()
+    d2 = d2.to(DEV)
+    x2 = det_input((1, 6, 256, 256), seed=79, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y_ref = od2(x2.clone())
+        y2 = d2(x2.to(DEV)).cpu()
+    assert y2.shape == y_ref.shape == (1, 1, 30, 30)
+    rep["eval_256_max_abs"] = float((y2 - y_ref).abs().max())
+    _report("dehaze22_d", rep)
+    assert rep["max_abs"] < 2e-2 and rep["rel_rms"] < 2e-2, rep
+    assert rep["eval_256_max_abs"] < 2e-2, rep
+    with pytest.raises(NotImplementedError):
+        net22.G(3, 3, 64)

@@ -141,3 +141,16 @@ def test_freqsplit_known_answers(golden_dir, manifest):
     x = det_input((2, 3, 40, 48), seed=11)
     np.testing.assert_allclose(freqsplit_ref.blur(x, use_input_norm=True).numpy(), gold["blur_norm"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(freqsplit_ref.laplacian(x).numpy(), gold["lap"], rtol=1e-4, atol=1e-5)
+
+
+def test_dehaze22_d_matches_golden(golden_dir, manifest):
+    """dehaze22.D restatement vs the output the REAL reference produced (make_golden.py)."""
+    from oracle import dehaze22_ref as o22
+    d = o22.D(9, 36)
+    sd = fill_state_dict(d, seed=2)
+    assert list(sd.keys()) == manifest["d22_keys"]
+    x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        y = d(x)
+    assert y.shape == (2, 1, 6, 6)
+    np.testing.assert_allclose(y.numpy(), _load(golden_dir, "d22_2x64.npz")["y"], **TOL)
