@@ -57,6 +57,7 @@ struct ConvArgs {
   float* stats;
   int stats_cpad;
   int tiles_x, tiles_y;
+  int seg_rows;  // conv3x3_rs: output rows per work item (tiles_x strips x tiles_y row segments per image)
   int pad;
   // x-stream 1x1 kernel (conv1x1_xs.hip)
   unsigned P;   // output pixels N*Ho*Wo
@@ -66,6 +67,7 @@ struct ConvArgs {
   int x_dense;  // x offset of pixel p is p * x_sw (no pooling, contiguous n/h/w)
   int y_dense;  // y offset of pixel p is p * y_sw (no upsample, contiguous n/h/w, NHWC)
   int y_vec16;  // NHWC bf16 output, 16-byte aligned rows, no upsample: row stores allowed
+  int dbg_skip;             // measurement aid: phases to skip (FDGAN_DEBUG_PHASES), 0 in production
   unsigned long long* dbg;  // measurement aid: per-wave phase cycle totals of workgroup 0 (or NULL)
 };
 
@@ -257,6 +259,33 @@ __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, cons
     const long long off = pixoff(q);
     if (off >= 0)
       *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8) = row;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Same transposition for a caller that already holds the (uniform) address of pixel 0 of the row:
+// pixel q lives at yrow + q * y_sw, pixels [0, npix) are stored.  32-bit per-lane offsets only.
+template <int CT>
+__device__ __forceinline__ void fd_store_row16_ptr(unsigned short* yrow, int y_sw, char* tb, const float (&v)[CT][4],
+                                                  int lane, int npix) {
+  using R = RowStore<CT>;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  const int m = lane & 15, g = lane >> 4;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const u32x2 bits =
+        __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]}, bf16x4_t));
+    *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + g * 8) = bits;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int piece = lane % R::LPP, q0 = lane / R::LPP;
+#pragma unroll
+  for (int i = 0; i < 16 / R::PPI; ++i) {
+    const int q = i * R::PPI + q0;
+    const u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
+    if (q < npix) *reinterpret_cast<u32x4*>(yrow + (unsigned)(q * y_sw + piece * 8)) = row;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -594,6 +623,9 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
 int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
 bool conv3x3_pw_fits(int cout_total, int cin);
+bool conv3x3_rs_fits(const ConvArgs& a, int cout_total);
+int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
+                        hipStream_t stream);
 int conv_dispatch_k3_pw(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream);
 int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,

@@ -136,6 +136,8 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
     if (nostore) a.Cout = 0;
     static const char* co = getenv("FDGAN_DEBUG_COALESCE");
     if (co && d->ksize == 1) a.pad = atoi(co);
+    static const char* ph = getenv("FDGAN_DEBUG_PHASES");   // bit mask of kernel phases to skip (results wrong)
+    a.dbg_skip = ph ? atoi(ph) : 0;
   }
   nimg = x->n;
   return FD_OK;

@@ -132,6 +132,23 @@ def test_conv3x3_persistent_filter_kernel(E):
     _run(E, 1, 64, 64, 16, 3, 3, pad=1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=43)
 
 
+def test_conv3x3_row_streaming_kernel(E):
+    """conv3x3_rs (Cin == 128, Cout <= 32): ragged strips and rows, row segments, more work items than
+    workgroups, input as a channel slice of a wider buffer, narrow outputs, no-BN and LeakyReLU prologues."""
+    from fdgan_hip import engine, lib as L
+    info = engine.conv_info(engine.View(torch.empty((16, 64, 64, 128), dtype=torch.bfloat16, device="cuda:0")).fd,
+                            engine.View(torch.empty((16, 64, 64, 32), dtype=torch.bfloat16, device="cuda:0")).fd, 32,
+                            engine.conv_desc(3, 1, 1))
+    assert (info.grid_x, info.stats_rows, info.stats_cpad) == (256, 256, 32)      # 4 strips x 4 segments x 16 images
+    _run(E, 3, 40, 24, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=96, c0_out=64, seed=50)
+    _run(E, 2, 21, 19 + 5, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_in=192, c0_in=64, seed=51)
+    _run(E, 5, 256, 256, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=64, c0_out=32, seed=52)
+    _run(E, 1, 8, 8, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, seed=53, running=True)
+    _run(E, 2, 36, 40, 128, 20, 3, pad=1, p_act=ACT_LEAKY02, bias=True, stats=True, seed=54)
+    _run(E, 2, 16, 32, 128, 3, 3, pad=1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=55)
+    _run(E, 1, 24, 16, 128, 32, 3, pad=1, stats=True, seed=56)
+
+
 # dense-layer bottleneck: 1x1 over a channel prefix of a wider concat buffer
 def test_conv1x1_prefix_to_128_bn_relu_stats(E):
     _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3)

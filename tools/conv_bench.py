@@ -58,7 +58,7 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
         E.conv2d(xv.fd, pw, b, pro, yv.fd, desc, ws)
         torch.cuda.synchronize()
         L.load().fdgan_debug_timing(None)
-        print("phase cycles per wave [mfma, staging, barrier, epilogue, steps]:", dbg.view(8, 8)[:, :5].tolist())
+        print("phase cycles per wave [mfma, staging, barrier, epilogue, steps]:", dbg.view(8, 8)[:, :6].tolist())
     for _ in range(2):
         plan.launch()
     torch.cuda.synchronize()
