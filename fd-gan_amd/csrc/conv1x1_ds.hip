@@ -1,0 +1,310 @@
+// conv1x1_ds.hip -- the dense-layer bottleneck: 1x1 convolution, Cin (64 .. 1024, a channel prefix of
+// the block's concat buffer) -> 128 channels, BatchNorm + ReLU prologue, batch statistics of the
+// result.  58 of netG's launches and half of its forward time.  "ds" = DMA-streamed.
+//
+// A 1x1 conv is a GEMM  D[cout][pixel] = W[cout][cin] * A[cin][pixel]  that reads every activation
+// exactly once, so all that matters is how the activations stream in.  Its predecessor
+// (conv1x1_xs) loads MFMA B fragments straight from HBM into registers: 16 pixels x 64 B per wave
+// instruction, a few instructions in flight per wave -- 2.7 TB/s marginal at 64x64, 3.7 TB/s at 256x256.
+// Here every workgroup owns 256 consecutive pixels per tile and walks the channel axis in stages of
+// 64 channels; a stage (256 px x 128 B of activations + the 16 KiB filter slice) is fetched by
+// LDS-DMA two stages ahead (tools/ubench/kstream.hip: this pattern streams at 5.8-6.9 TB/s).
+//
+//   * 8 waves, all alike.  Wave w owns pixels [32w, 32w+32) of the tile: it issues the DMA of exactly
+//     those pixels (4 instructions per stage) plus 2 of the 16 filter fragments, and consumes them:
+//     per stage 4 raw B fragments from LDS -> BatchNorm + ReLU in registers (20 VALU per fragment,
+//     every element once) -> 32 MFMAs against the 16 A fragments of the slice.  Only the filter
+//     is shared between waves: one barrier per stage.
+//   * LDS image of a stage: [256 px][8 slots of 16 B], slot = chunk ^ ((px >> 1) & 5), applied on the
+//     DMA source address.  The filter keeps the "x64" fragment order of conv1x1_xs (lane group g owns
+//     channels 64 ks + 16 g + 8 j), so the B read of MFMA j takes chunk 2g + j; with this swizzle the
+//     16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte bank groups.
+//   * the epilogue (statistics in registers across all tiles of the workgroup, 256-byte row stores
+//     staged through the wave's own, just-consumed activation region) overlaps the two stages
+//     already in flight for the next tile.
+// Reference call sites replaced: torchvision _DenseLayer conv1 (densenet.py) as used by
+// /root/reference/models/dehaze1113.py:711-722, and BottleneckBlockdy.conv1 (:262).
+#include "conv_igemm.h"
+
+namespace {
+
+constexpr int DS_NW = 8, DS_NT = 64 * DS_NW;
+constexpr int DS_PX = 256;                    // pixels per tile
+constexpr int DS_ACT_B = DS_PX * 128;         // one stage of activations: 64 channels per pixel
+constexpr int DS_W_B = 16 * 1024;             // one stage of the filter: 2 k32-steps x 8 cout tiles
+constexpr int DS_STAGE_B = DS_ACT_B + DS_W_B;
+constexpr int DS_NBUF = 3;                    // two stages in flight + the one being consumed
+constexpr int DS_CT = 8, DS_PT = 2;           // cout tiles; pixel tiles per wave
+constexpr int DS_IPS = 6;                     // DMA instructions per wave per stage (4 activation + 2 filter)
+constexpr int DS_NSTORE = 8;                  // row-store instructions per wave per epilogue
+
+__host__ __device__ inline unsigned ds_lds_bytes(int nks) {
+  return DS_NBUF * DS_STAGE_B + nks * 64 * 8 + DS_NW * 128 * 2 * 4;
+}
+
+__device__ __forceinline__ void ds_dma16(const unsigned short* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void ds_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// barrier that leaves LDS-DMA in flight (see conv3x3_rs.hip)
+__device__ __forceinline__ void ds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// XMODE: 0 raw, 1 BatchNorm + ReLU, 2 affine + max(v, slope*v)
+template <int XMODE>
+__global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* stage0 = smem;                                                         // [NBUF][act | filter]
+  float* sc_lds = reinterpret_cast<float*>(smem + DS_NBUF * DS_STAGE_B);       // [nks*64]
+  float* sh_lds = sc_lds + a.nks * 64;
+  float* red = sh_lds + a.nks * 64;                                            // [NW][128][2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  fd_fold_bn(a, sc_lds, sh_lds, a.nks * 64, tid, DS_NT);
+  __syncthreads();
+
+  const int my_tiles = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int total = my_tiles * a.nks;
+  const int cmax = a.Cin8 * 8;
+
+  // ---- DMA maps.  Activation instruction i of this wave covers LDS positions [(4 wave + i) KiB, +1 KiB):
+  // local pixel 32 wave + 8 i + lane / 8, slot lane % 8, holding channel chunk slot ^ ((px >> 1) & 5).
+  int dpx[4], dch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dpx[i] = wave * 32 + i * 8 + (lane >> 3);
+    dch[i] = ((lane & 7) ^ ((dpx[i] >> 1) & 5)) * 8;   // element offset of the chunk inside the 64-channel step
+  }
+  unsigned dsrc[4];   // element offset of the lane's pixel in x for the tile being fetched
+  auto retarget = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned px = (unsigned)tile * DS_PX + (unsigned)dpx[i];
+      dsrc[i] = (px < a.P ? px : 0u) * (unsigned)a.x_sw;   // past the end: pixel 0 (masked by the consumer)
+    }
+  };
+  int f_tile = (int)blockIdx.x, f_ks = 0;   // stage to be fetched next
+  auto issue = [&](int buf) __attribute__((always_inline)) {
+    char* dst = stage0 + buf * DS_STAGE_B;
+    if (f_ks == 0) retarget(f_tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = f_ks * 64 + dch[i];
+      ds_dma16(a.x + dsrc[i] + (ch < cmax ? ch : 0), dst + (wave * 4 + i) * 1024);   // past Cin: chunk 0 (masked)
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int fi = wave * 2 + f;   // fragment (j = fi >> 3, cout tile fi & 7) of k-step f_ks
+      ds_dma16(a.w + ((long long)(f_ks * 2 + (fi >> 3)) * DS_CT + (fi & 7)) * 512 + lane * 8, dst + DS_ACT_B + fi * 1024);
+    }
+    if (++f_ks == a.nks) {
+      f_ks = 0;
+      f_tile += (int)gridDim.x;
+    }
+  };
+
+  // ---- consumer maps: B fragment of MFMA j for pixel tile p: local pixel 32 wave + 16 p + m, chunk 2g + j
+  int boff[DS_PT][2];
+#pragma unroll
+  for (int p = 0; p < DS_PT; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int px = wave * 32 + p * 16 + m;
+      boff[p][j] = px * 128 + (((2 * g + j) ^ ((px >> 1) & 5)) * 16);
+    }
+  float st1[DS_CT][4], st2[DS_CT][4];
+#pragma unroll
+  for (int c = 0; c < DS_CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st1[c][r] = st2[c][r] = 0.f;
+  f32x4 acc[DS_PT][DS_CT];
+#pragma unroll
+  for (int p = 0; p < DS_PT; ++p)
+#pragma unroll
+    for (int c = 0; c < DS_CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  int buf = 0, ks = 0, tile = (int)blockIdx.x, pend = 0;
+  for (int s = 0; s < total; ++s) {
+    // this wave's share of stage s has landed; the barrier adds everybody else's filter fragments and
+    // retires the buffer consumed in stage s-1
+    if (s + 1 < total) {
+      if (pend > 0) {
+        ds_wait_vm<DS_IPS + DS_NSTORE>();
+        --pend;
+      } else {
+        ds_wait_vm<DS_IPS>();
+      }
+    } else {
+      ds_wait_vm<0>();
+    }
+    ds_barrier();
+    if (s + 2 < total) issue(buf >= 1 ? buf - 1 : DS_NBUF - 1);   // (buf + 2) % 3
+    const char* act = stage0 + buf * DS_STAGE_B;
+    const char* wfrag = act + DS_ACT_B + lane * 16;
+    const bool full = (unsigned)tile * DS_PX + DS_PX <= a.P;   // uniform
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cb = ks * 64 + g * 16 + j * 8;
+      const bool cok = cb < cmax;
+      bf16x8 xf[DS_PT];
+      u32x4 raw[DS_PT];
+#pragma unroll
+      for (int p = 0; p < DS_PT; ++p) raw[p] = lds_read16(act + boff[p][j]);
+      if (XMODE != 0) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + cb), s1 = *reinterpret_cast<const f32x4*>(sc_lds + cb + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_lds + cb), h1 = *reinterpret_cast<const f32x4*>(sh_lds + cb + 4);
+#pragma unroll
+        for (int p = 0; p < DS_PT; ++p) raw[p] = fd_xform8_r(raw[p], s0, s1, h0, h1, XMODE == 1 ? 0.f : a.p_slope);
+      }
+#pragma unroll
+      for (int p = 0; p < DS_PT; ++p) {
+        // a pixel past the end / a channel group past Cin must contribute exactly zero
+        const bool ok = cok && (full || (unsigned)tile * DS_PX + wave * 32 + p * 16 + m < a.P);
+        xf[p] = __builtin_bit_cast(bf16x8, ok ? raw[p] : zero4);
+      }
+#pragma unroll
+      for (int c0 = 0; c0 < DS_CT; c0 += 4) {
+        bf16x8 wf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + (j * DS_CT + c0 + c) * 1024));
+#pragma unroll
+        for (int p = 0; p < DS_PT; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[p][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[p][c0 + c], 0, 0, 0);
+      }
+    }
+
+    if (ks + 1 == a.nks) {
+      // ---- epilogue of `tile`: statistics (registers) and 256-byte row stores, staged through this
+      // wave's own activation region of the buffer just consumed (nobody else touches it, and the
+      // DMA that refills it is issued by this wave after the next barrier)
+      char* tb = const_cast<char*>(act) + wave * 4096;
+#pragma unroll
+      for (int p = 0; p < DS_PT; ++p) {
+        const unsigned pxt = (unsigned)tile * DS_PX + wave * 32 + p * 16;
+        const bool pok = full || pxt + m < a.P;
+#pragma unroll
+        for (int c = 0; c < DS_CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = pok ? acc[p][c][r] : 0.f;
+            st1[c][r] += v;
+            st2[c][r] = fmaf(v, v, st2[c][r]);
+          }
+        unsigned short* yrow = reinterpret_cast<unsigned short*>(a.y) + (unsigned long long)pxt * (unsigned)a.y_sw;
+        const int npix = full ? 16 : (pxt < a.P ? (int)min(16u, a.P - pxt) : 0);
+#pragma unroll
+        for (int c0 = 0; c0 < DS_CT; c0 += 4) {
+          float v[4][4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[c][r] = acc[p][c0 + c][r];
+          fd_store_row16_ptr<4>(yrow + c0 * 16, a.y_sw, tb, v, lane, npix);
+        }
+#pragma unroll
+        for (int c = 0; c < DS_CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      pend = 2;
+      ks = 0;
+      tile += (int)gridDim.x;
+    } else {
+      ++ks;
+    }
+    buf = buf + 1 == DS_NBUF ? 0 : buf + 1;
+  }
+
+  // ---- one partial row of statistics per workgroup
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int c = 0; c < DS_CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = fd_row_sum16(st1[c][r]), s2 = fd_row_sum16(st2[c][r]);
+        if (m == 0) {
+          float* d = red + ((wave * 128) + c * 16 + g * 4 + r) * 2;
+          d[0] = s1;
+          d[1] = s2;
+        }
+      }
+    __syncthreads();
+    for (int cl = tid; cl < 128; cl += DS_NT) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < DS_NW; ++w_) {
+        t1 += red[(w_ * 128 + cl) * 2];
+        t2 += red[(w_ * 128 + cl) * 2 + 1];
+      }
+      float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + cl) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+int ds_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int XMODE>
+int ds_launch(const ConvArgs& a, dim3 grid, unsigned lds, hipStream_t stream) {
+  auto kfn = &conv1x1_ds_kernel<XMODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_ds): %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  return fd_launch(kfn, "conv1x1_ds_bn128", grid, dim3(DS_NT, 1, 1), lds, a, stream);
+}
+
+}  // namespace
+
+// Cout == 128 exactly, dense NHWC input / output, x64 filter layout, plain epilogue (no bias, no
+// activation, no upsample), scale / shift of every input channel next to the three stage buffers.
+bool conv1x1_ds_fits(const ConvArgs& a, int cout_total, bool pool, int w_layout) {
+  return !pool && cout_total == 128 && a.ntile_total == 8 && w_layout == FD_WLAYOUT_X64 && a.x_dense && a.y_dense &&
+         a.y_vec16 && a.Cout >= 128 && a.bias == nullptr && a.e_slope == 1.f && !a.upsample && !a.out_nchw_f32 &&
+         (a.x_sw % 8) == 0 && a.Cin >= 8 && ds_lds_bytes((a.Cin + 63) / 64) <= 160 * 1024;
+}
+
+int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  a.nks = (a.Cin + 63) / 64;
+  a.ntiles = (int)((a.P + DS_PX - 1) / DS_PX);
+  const int ncu = dry ? 256 : ds_num_cus();
+  dim3 grid((unsigned)(a.ntiles < ncu ? a.ntiles : ncu), 1, 1);
+  a.stats_cpad = 128;
+  const unsigned lds = ds_lds_bytes(a.nks);
+  if (info) {
+    info->stats_rows = grid.x;
+    info->stats_cpad = a.stats_cpad;
+    info->grid_x = grid.x;
+    info->grid_y = 1;
+    info->lds_bytes = lds;
+  }
+  if (dry) return FD_OK;
+  if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)
+    FD_FAIL(FD_EINVAL, "stats workspace too small: need %lld floats, have %lld", (long long)grid.x * a.stats_cpad * 2,
+            stats_cap);
+  if (a.pro_mode == 0) return ds_launch<0>(a, grid, lds, stream);
+  if (a.p_slope == 0.f) return ds_launch<1>(a, grid, lds, stream);
+  return ds_launch<2>(a, grid, lds, stream);
+}

@@ -17,6 +17,8 @@
 //     of the current tile runs, and emit ONE row of batch-statistics partials per
 //     workgroup (<= 512 rows for fdgan_bn_finalize instead of one per tile).
 // No barrier inside the tile loop.
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 
 template <int POOL, int PT, int CT, int NW_>
@@ -373,6 +375,9 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
   a.y_dense = !a.upsample && !a.out_nchw_f32 && a.y_sh == (long long)a.Wo * a.y_sw &&
               a.y_sn == (long long)a.Ho * a.y_sh;
   if (!conv1x1_xs_fits(cout_total, a.Cin)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: filter does not fit LDS");
+  // the bottleneck shape (-> 128 channels, dense tensors, plain epilogue) streams through LDS-DMA
+  if (conv1x1_ds_fits(a, cout_total, pool, FD_WLAYOUT_X64) && getenv("FDGAN_DEBUG_NO_DS") == nullptr)
+    return conv_dispatch_k1_ds(a, info, stats_cap, dry, stream);
   const int nks = a.nks;
   const long long big_tiles = (a.P + 511) / 512;
   const int ncu_ = dry ? 256 : num_cus();

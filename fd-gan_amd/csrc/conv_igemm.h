@@ -620,6 +620,8 @@ int conv_dispatch_k1(ConvArgs& a, long long nimg, int cout_total, int stride, bo
 bool conv1x1_xs_fits(int cout_total, int cin);
 int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, FdConvInfo* info,
                         long long stats_cap, bool dry, hipStream_t stream);
+bool conv1x1_ds_fits(const ConvArgs& a, int cout_total, bool pool, int w_layout);
+int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream);
 int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
 bool conv3x3_pw_fits(int cout_total, int cin);
