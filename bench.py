@@ -176,7 +176,17 @@ def main():
             ach = dom["flops"] / nl / (per_launch_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
-        roof.update({"traffic": None, "kernel": dom_key, "launches_per_step": nl,
+        traffic, traffic_mb = None, None
+        try:   # HBM bytes of this kernel from the committed PMC passes (same shape and batch), else null
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get(dom_key)
+            if pmc and pmc.get("batch") == B and S == 256:
+                traffic_mb = (2.0 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024 / 1e6
+                traffic = round(traffic_mb * 1e6 / (per_launch_ms * 1e-3) / (1e9 if roof["unit"] == "GB/s" else 1e12), 1)
+        except (OSError, ValueError):
+            pass
+        roof.update({"traffic": traffic, "traffic_mb_per_launch": round(traffic_mb, 2) if traffic_mb else None,
+                     "kernel": dom_key, "launches_per_step": nl,
                      "avg_launch_us": round(per_launch_ms * 1e3, 2), "launches_timed": cnt,
                      "algorithmic_mb_per_launch": round(dom["bytes"] / nl / 1e6, 2),
                      "gflop_per_launch": round(dom["flops"] / nl / 1e9, 2),
