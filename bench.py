@@ -130,9 +130,20 @@ def main():
         for c in classes.values():
             c["ms"] = sum(ms[i] for i in c["idx"])
         total_ms = sum(ms)
-        conv_classes = {k: c for k, c in classes.items() if c["bytes"] > 0 and c["flops"] > 0}
-        dom_key = max(conv_classes, key=lambda k: conv_classes[k]["ms"])
-        dom = conv_classes[dom_key]
+        # The roofline object is per KERNEL (all of its launches in a step, whatever their shapes), so that
+        # its average launch duration is the number a rocprofv3 --stats summary shows for that kernel.
+        kernels = {}
+        for k, c in classes.items():
+            if c["bytes"] > 0 and c["flops"] > 0:
+                d = kernels.setdefault(c["kernel"], dict(idx=[], bytes=0.0, flops=0.0, flops_done=0.0, ms=0.0,
+                                                         kernel=c["kernel"], shapes=[]))
+                d["idx"] += c["idx"]
+                d["shapes"].append(k)
+                for f in ("bytes", "flops", "flops_done", "ms"):
+                    d[f] += c[f]
+        dom_key = max(kernels, key=lambda k: kernels[k]["ms"])
+        dom = kernels[dom_key]
+        headline = classes.get("conv3x3_rs_bn32[128->32 @%dx%d]" % (S, S))
         if a.graph:
             plan.main.instantiate_graph()
         else:
@@ -179,8 +190,8 @@ def main():
         traffic, traffic_mb = None, None
         try:   # HBM bytes of this kernel from the committed PMC passes (same shape and batch), else null
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f).get(dom_key)
-            if pmc and pmc.get("batch") == B and S == 256:
+                pmc = json.load(f).get("%s@netG_B%d_%d" % (dom_key, B, S))
+            if pmc:
                 traffic_mb = (2.0 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024 / 1e6
                 traffic = round(traffic_mb * 1e6 / (per_launch_ms * 1e-3) / (1e9 if roof["unit"] == "GB/s" else 1e12), 1)
         except (OSError, ValueError):
@@ -192,6 +203,12 @@ def main():
                      "gflop_per_launch": round(dom["flops"] / nl / 1e9, 2),
                      "tflops": round(dom["flops"] / nl / (per_launch_ms * 1e-3) / 1e12, 1),
                      "share_of_gpu_time": round(dom["ms"] / total_ms, 3)})
+        if headline is not None and headline["ms"] > 0:   # the north-star shape (3x3 128->32 @256^2), from the instrumented replay
+            hl_us = headline["ms"] / len(headline["idx"]) * 1e3
+            roof["headline_3x3"] = {"kernel": "conv3x3_rs_bn32[128->32 @%dx%d]" % (S, S), "avg_launch_us": round(hl_us, 2),
+                                    "achieved_GB/s": round(headline["bytes"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e9, 1),
+                                    "frac_hbm": round(headline["bytes"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "tflops": round(headline["flops"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e12, 1)}
         res["roofline"] = roof
         if a.breakdown:
             rows = []

@@ -24,23 +24,32 @@
 //     already in flight for the next tile.
 // Reference call sites replaced: torchvision _DenseLayer conv1 (densenet.py) as used by
 // /root/reference/models/dehaze1113.py:711-722, and BottleneckBlockdy.conv1 (:262).
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 
 namespace {
 
-constexpr int DS_NW = 8, DS_NT = 64 * DS_NW;
-constexpr int DS_PX = 256;                    // pixels per tile
-constexpr int DS_ACT_B = DS_PX * 128;         // one stage of activations: 64 channels per pixel
-constexpr int DS_W_B = 16 * 1024;             // one stage of the filter: 2 k32-steps x 8 cout tiles
-constexpr int DS_STAGE_B = DS_ACT_B + DS_W_B;
-constexpr int DS_NBUF = 3;                    // two stages in flight + the one being consumed
-constexpr int DS_CT = 8, DS_PT = 2;           // cout tiles; pixel tiles per wave
-constexpr int DS_IPS = 6;                     // DMA instructions per wave per stage (4 activation + 2 filter)
-constexpr int DS_NSTORE = 8;                  // row-store instructions per wave per epilogue
+constexpr int DS_W_B = 16 * 1024;   // one stage of the filter: 2 k32-steps x 8 cout tiles
+constexpr int DS_NBUF = 3;          // two stages in flight + the one being consumed
+constexpr int DS_CT = 8;            // cout tiles
 
-__host__ __device__ inline unsigned ds_lds_bytes(int nks) {
-  return DS_NBUF * DS_STAGE_B + nks * 64 * 8 + DS_NW * 128 * 2 * 4;
-}
+// NW waves, each owning PT pixel tiles of 16 pixels
+template <int NW_, int PT_>
+struct DsCfg {
+  static constexpr int NW = NW_, PT = PT_, NT = 64 * NW_;
+  static constexpr int WPX = PT_ * 16;              // pixels per wave
+  static constexpr int PX = NW_ * WPX;              // pixels per tile
+  static constexpr int ACT_B = PX * 128;            // one stage of activations: 64 channels per pixel
+  static constexpr int STAGE_B = ACT_B + DS_W_B;
+  static constexpr int AI = 2 * PT_;                // activation DMA instructions per wave per stage (1 KiB each)
+  static constexpr int FI = NW_ >= 16 ? 1 : 2;      // filter fragments per wave per stage (16 in all; NW < 16: some twice)
+  static constexpr int IPS = AI + FI;               // DMA instructions per wave per stage
+  static constexpr int SC = PT_ >= 2 ? 4 : 2;       // cout tiles per row-store pass (staging must fit the wave's region)
+  static constexpr int NSTORE = PT_ * (DS_CT / SC) * (16 / RowStore<SC>::PPI);
+  static_assert(RowStore<SC>::BYTES <= WPX * 128, "row-store staging must fit the wave's activation region");
+  __host__ __device__ static unsigned lds_bytes(int nks) { return DS_NBUF * STAGE_B + nks * 64 * 8 + NW * 128 * 2 * 4; }
+};
 
 __device__ __forceinline__ void ds_dma16(const unsigned short* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -53,9 +62,29 @@ __device__ __forceinline__ void ds_wait_vm() {
 // barrier that leaves LDS-DMA in flight (see conv3x3_rs.hip)
 __device__ __forceinline__ void ds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+struct DsTimer {   // measurement aid (tools/conv_bench.py FDGAN_TIMING=1): s_memtime per phase, workgroup 0
+  bool on;
+  unsigned long long t[6], last;
+  __device__ __forceinline__ void start(bool enable) {
+    on = enable;
+    for (int k = 0; k < 6; ++k) t[k] = 0;
+    last = on ? __builtin_amdgcn_s_memtime() : 0;
+  }
+  __device__ __forceinline__ void stamp(int k) {
+    if (on) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      t[k] += now - last;
+      last = now;
+    }
+  }
+};
+
 // XMODE: 0 raw, 1 BatchNorm + ReLU, 2 affine + max(v, slope*v)
-template <int XMODE>
-__global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
+template <int XMODE, int NW, int PT>
+__global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
+  using C = DsCfg<NW, PT>;
+  constexpr int DS_NT = C::NT, DS_PX = C::PX, DS_ACT_B = C::ACT_B, DS_STAGE_B = C::STAGE_B, DS_PT = PT, DS_NW = NW;
+  constexpr int DS_IPS = C::IPS, DS_NSTORE = C::NSTORE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* stage0 = smem;                                                         // [NBUF][act | filter]
   float* sc_lds = reinterpret_cast<float*>(smem + DS_NBUF * DS_STAGE_B);       // [nks*64]
@@ -67,8 +96,11 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
   const int m = lane & 15, g = lane >> 4;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  DsTimer tm;
+  tm.start(a.dbg != nullptr && blockIdx.x == 0);
   fd_fold_bn(a, sc_lds, sh_lds, a.nks * 64, tid, DS_NT);
   __syncthreads();
+  tm.stamp(5);
 
   const int my_tiles = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * a.nks;
@@ -76,16 +108,16 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
 
   // ---- DMA maps.  Activation instruction i of this wave covers LDS positions [(4 wave + i) KiB, +1 KiB):
   // local pixel 32 wave + 8 i + lane / 8, slot lane % 8, holding channel chunk slot ^ ((px >> 1) & 5).
-  int dpx[4], dch[4];
+  int dpx[C::AI], dch[C::AI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    dpx[i] = wave * 32 + i * 8 + (lane >> 3);
+  for (int i = 0; i < C::AI; ++i) {
+    dpx[i] = wave * C::WPX + i * 8 + (lane >> 3);
     dch[i] = ((lane & 7) ^ ((dpx[i] >> 1) & 5)) * 8;   // element offset of the chunk inside the 64-channel step
   }
-  unsigned dsrc[4];   // element offset of the lane's pixel in x for the tile being fetched
+  unsigned dsrc[C::AI];   // element offset of the lane's pixel in x for the tile being fetched
   auto retarget = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < C::AI; ++i) {
       const unsigned px = (unsigned)tile * DS_PX + (unsigned)dpx[i];
       dsrc[i] = (px < a.P ? px : 0u) * (unsigned)a.x_sw;   // past the end: pixel 0 (masked by the consumer)
     }
@@ -95,13 +127,15 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
     char* dst = stage0 + buf * DS_STAGE_B;
     if (f_ks == 0) retarget(f_tile);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < C::AI; ++i) {
       const int ch = f_ks * 64 + dch[i];
-      ds_dma16(a.x + dsrc[i] + (ch < cmax ? ch : 0), dst + (wave * 4 + i) * 1024);   // past Cin: chunk 0 (masked)
+      ds_dma16(a.x + dsrc[i] + (ch < cmax ? ch : 0), dst + (wave * C::AI + i) * 1024);   // past Cin: chunk 0 (masked)
     }
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int fi = wave * 2 + f;   // fragment (j = fi >> 3, cout tile fi & 7) of k-step f_ks
+    for (int f = 0; f < C::FI; ++f) {
+      // fragment (j = fi >> 3, cout tile fi & 7) of k-step f_ks; with fewer than 16 fragment slots left a
+      // wave fetches its first fragment twice (same bytes, same place) so every wave issues IPS instructions
+      const int fi0 = wave + f * DS_NW, fi = fi0 < 16 ? fi0 : wave;
       ds_dma16(a.w + ((long long)(f_ks * 2 + (fi >> 3)) * DS_CT + (fi & 7)) * 512 + lane * 8, dst + DS_ACT_B + fi * 1024);
     }
     if (++f_ks == a.nks) {
@@ -116,7 +150,7 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
   for (int p = 0; p < DS_PT; ++p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int px = wave * 32 + p * 16 + m;
+      const int px = wave * C::WPX + p * 16 + m;
       boff[p][j] = px * 128 + (((2 * g + j) ^ ((px >> 1) & 5)) * 16);
     }
   float st1[DS_CT][4], st2[DS_CT][4];
@@ -146,8 +180,11 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
     } else {
       ds_wait_vm<0>();
     }
+    tm.stamp(0);
     ds_barrier();
+    tm.stamp(1);
     if (s + 2 < total) issue(buf >= 1 ? buf - 1 : DS_NBUF - 1);   // (buf + 2) % 3
+    tm.stamp(2);
     const char* act = stage0 + buf * DS_STAGE_B;
     const char* wfrag = act + DS_ACT_B + lane * 16;
     const bool full = (unsigned)tile * DS_PX + DS_PX <= a.P;   // uniform
@@ -168,7 +205,7 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
 #pragma unroll
       for (int p = 0; p < DS_PT; ++p) {
         // a pixel past the end / a channel group past Cin must contribute exactly zero
-        const bool ok = cok && (full || (unsigned)tile * DS_PX + wave * 32 + p * 16 + m < a.P);
+        const bool ok = cok && (full || (unsigned)tile * DS_PX + wave * C::WPX + p * 16 + m < a.P);
         xf[p] = __builtin_bit_cast(bf16x8, ok ? raw[p] : zero4);
       }
 #pragma unroll
@@ -184,14 +221,15 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
       }
     }
 
+    tm.stamp(3);
     if (ks + 1 == a.nks) {
       // ---- epilogue of `tile`: statistics (registers) and 256-byte row stores, staged through this
       // wave's own activation region of the buffer just consumed (nobody else touches it, and the
       // DMA that refills it is issued by this wave after the next barrier)
-      char* tb = const_cast<char*>(act) + wave * 4096;
+      char* tb = const_cast<char*>(act) + wave * (C::WPX * 128);
 #pragma unroll
       for (int p = 0; p < DS_PT; ++p) {
-        const unsigned pxt = (unsigned)tile * DS_PX + wave * 32 + p * 16;
+        const unsigned pxt = (unsigned)tile * DS_PX + wave * C::WPX + p * 16;
         const bool pok = full || pxt + m < a.P;
 #pragma unroll
         for (int c = 0; c < DS_CT; ++c)
@@ -204,13 +242,13 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
         unsigned short* yrow = reinterpret_cast<unsigned short*>(a.y) + (unsigned long long)pxt * (unsigned)a.y_sw;
         const int npix = full ? 16 : (pxt < a.P ? (int)min(16u, a.P - pxt) : 0);
 #pragma unroll
-        for (int c0 = 0; c0 < DS_CT; c0 += 4) {
-          float v[4][4];
+        for (int c0 = 0; c0 < DS_CT; c0 += C::SC) {
+          float v[C::SC][4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+          for (int c = 0; c < C::SC; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[c][r] = acc[p][c0 + c][r];
-          fd_store_row16_ptr<4>(yrow + c0 * 16, a.y_sw, tb, v, lane, npix);
+          fd_store_row16_ptr<C::SC>(yrow + c0 * 16, a.y_sw, tb, v, lane, npix);
         }
 #pragma unroll
         for (int c = 0; c < DS_CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -218,12 +256,15 @@ __global__ __launch_bounds__(DS_NT) void conv1x1_ds_kernel(ConvArgs a) {
       pend = 2;
       ks = 0;
       tile += (int)gridDim.x;
+      tm.stamp(4);
     } else {
       ++ks;
     }
     buf = buf + 1 == DS_NBUF ? 0 : buf + 1;
   }
 
+  if (tm.on && lane == 0 && wave < 8)
+    for (int k = 0; k < 6; ++k) a.dbg[wave * 8 + k] = tm.t[k];
   // ---- one partial row of statistics per workgroup
   if (a.stats != nullptr) {
 #pragma unroll
@@ -263,9 +304,9 @@ int ds_num_cus() {
   return n;
 }
 
-template <int XMODE>
+template <int XMODE, int NW, int PT>
 int ds_launch(const ConvArgs& a, dim3 grid, unsigned lds, hipStream_t stream) {
-  auto kfn = &conv1x1_ds_kernel<XMODE>;
+  auto kfn = &conv1x1_ds_kernel<XMODE, NW, PT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -273,7 +314,8 @@ int ds_launch(const ConvArgs& a, dim3 grid, unsigned lds, hipStream_t stream) {
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_ds): %s", hipGetErrorString(e));
     attr_done = true;
   }
-  return fd_launch(kfn, "conv1x1_ds_bn128", grid, dim3(DS_NT, 1, 1), lds, a, stream);
+  return fd_launch(kfn, NW == 8 ? "conv1x1_ds_bn128" : (NW == 12 ? "conv1x1_ds_bn128_w12" : "conv1x1_ds_bn128_w16"), grid,
+                   dim3(64 * NW, 1, 1), lds, a, stream);
 }
 
 }  // namespace
@@ -283,16 +325,18 @@ int ds_launch(const ConvArgs& a, dim3 grid, unsigned lds, hipStream_t stream) {
 bool conv1x1_ds_fits(const ConvArgs& a, int cout_total, bool pool, int w_layout) {
   return !pool && cout_total == 128 && a.ntile_total == 8 && w_layout == FD_WLAYOUT_X64 && a.x_dense && a.y_dense &&
          a.y_vec16 && a.Cout >= 128 && a.bias == nullptr && a.e_slope == 1.f && !a.upsample && !a.out_nchw_f32 &&
-         (a.x_sw % 8) == 0 && a.Cin >= 8 && ds_lds_bytes((a.Cin + 63) / 64) <= 160 * 1024;
+         (a.x_sw % 8) == 0 && a.Cin >= 8 && DsCfg<8, 2>::lds_bytes((a.Cin + 63) / 64) <= 160 * 1024;
 }
 
-int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+template <int NW, int PT>
+static int ds_dispatch(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  using C = DsCfg<NW, PT>;
   a.nks = (a.Cin + 63) / 64;
-  a.ntiles = (int)((a.P + DS_PX - 1) / DS_PX);
+  a.ntiles = (int)((a.P + C::PX - 1) / C::PX);
   const int ncu = dry ? 256 : ds_num_cus();
   dim3 grid((unsigned)(a.ntiles < ncu ? a.ntiles : ncu), 1, 1);
   a.stats_cpad = 128;
-  const unsigned lds = ds_lds_bytes(a.nks);
+  const unsigned lds = C::lds_bytes(a.nks);
   if (info) {
     info->stats_rows = grid.x;
     info->stats_cpad = a.stats_cpad;
@@ -304,7 +348,13 @@ int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool
   if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)
     FD_FAIL(FD_EINVAL, "stats workspace too small: need %lld floats, have %lld", (long long)grid.x * a.stats_cpad * 2,
             stats_cap);
-  if (a.pro_mode == 0) return ds_launch<0>(a, grid, lds, stream);
-  if (a.p_slope == 0.f) return ds_launch<1>(a, grid, lds, stream);
-  return ds_launch<2>(a, grid, lds, stream);
+  if (a.pro_mode == 0) return ds_launch<0, NW, PT>(a, grid, lds, stream);
+  if (a.p_slope == 0.f) return ds_launch<1, NW, PT>(a, grid, lds, stream);
+  return ds_launch<2, NW, PT>(a, grid, lds, stream);
+}
+
+int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  // measured: 12 waves x 16 pixels (3 waves per SIMD) is 10-30 % SLOWER than 8 x 32 -- half the A-fragment
+  // reuse, twice the LDS reads per MFMA -- and 16 waves do not fit LDS; one configuration is instantiated
+  return ds_dispatch<8, 2>(a, info, stats_cap, dry, stream);
 }

@@ -99,20 +99,27 @@ struct BnFinArgs {
   float *mean, *var;
 };
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
-  __shared__ double sh[2][8][32];
+// One workgroup per 32 channels, 32 row groups x 32 channels: with <= 512 partial rows every thread has
+// all of its (<= 16) loads in flight at once, so the kernel is two memory latencies long.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinArgs a) {
+  __shared__ double sh[2][32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const long long c = (long long)blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < a.channels) {
     const float2* p = reinterpret_cast<const float2*>(a.partial) + c;
     long long r = rg;
-    for (; r + 24 < a.rows; r += 32) {  // 4 independent loads in flight
-      const float2 v0 = p[r * a.cpad], v1 = p[(r + 8) * a.cpad], v2 = p[(r + 16) * a.cpad], v3 = p[(r + 24) * a.cpad];
-      s1 += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
-      s2 += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+    for (; r + 224 < a.rows; r += 256) {  // 8 independent loads in flight
+      float2 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = p[(r + 32 * i) * a.cpad];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1 += (double)v[i].x;
+        s2 += (double)v[i].y;
+      }
     }
-    for (; r < a.rows; r += 8) {
+    for (; r < a.rows; r += 32) {
       const float2 v = p[r * a.cpad];
       s1 += v.x;
       s2 += v.y;
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
   if (rg == 0 && c < a.channels) {
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 32; ++g) {
       t1 += sh[0][g][cl];
       t2 += sh[1][g][cl];
     }
@@ -141,7 +148,7 @@ extern "C" int fdgan_bn_finalize(const float* partial, int64_t rows, int64_t cpa
   FD_REQUIRE(partial && mean && var, "bn_finalize: NULL pointer");
   FD_REQUIRE(rows > 0 && channels > 0 && cpad >= channels && count > 0, "bn_finalize: bad sizes");
   BnFinArgs a{partial, rows, cpad, channels, 1.0 / (double)count, mean, var};
-  return fd_launch(&bn_finalize_kernel, "bn_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(256), 0, a,
+  return fd_launch(&bn_finalize_kernel, "bn_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
                    static_cast<hipStream_t>(stream));
 }
 

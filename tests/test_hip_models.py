@@ -299,3 +299,39 @@ def test_dehaze22_d_matches_golden(golden_dir):
     assert rep["eval_256_max_abs"] < 2e-2, rep
     with pytest.raises(NotImplementedError):
         net22.G(3, 3, 64)
+
+
+def test_fdgan_full_size_properties(nets):
+    """BASELINE configs[1] size (B=16 @ 256x256), checked through size-independent properties the
+    domain offers: finite tanh-bounded output; bitwise run-to-run determinism; in EVAL mode (running
+    statistics) every image is independent of the rest of the batch, so a batch-2 run must reproduce
+    the first two images of the batch-16 run; train-mode BatchNorm makes the batch matter, so there the
+    same comparison must differ."""
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    x = det_input((16, 3, 256, 256), seed=4321).to(DEV)
+    with torch.no_grad():
+        g.eval()
+        y16 = g(x).clone()
+        y16b = g(x).clone()
+        y2 = g(x[:2].contiguous()).clone()
+        g.train()
+        t16 = g(x).clone()
+        t2 = g(x[:2].contiguous()).clone()
+    torch.cuda.synchronize()
+    assert y16.shape == (16, 3, 256, 256) and bool(torch.isfinite(y16).all()) and float(y16.abs().max()) <= 1.0
+    assert torch.equal(y16, y16b)
+    assert torch.equal(y16[:2], y2), float((y16[:2] - y2).abs().max())
+    assert bool(torch.isfinite(t16).all()) and not torch.equal(t16[:2], t2)
+    # 64 images/... the oracle on two of the sixteen images (eval mode is per-image): end-to-end parity at full size
+    og.eval()
+    with torch.no_grad():
+        y_ref = og(x[:1].cpu())
+    rep = {"psnr_eval_256": psnr(y16[:1].cpu(), y_ref)}
+    _report("fdgan_full_size", rep)
+    assert rep["psnr_eval_256"] > 38.0, rep

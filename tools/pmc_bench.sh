@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM traffic per kernel of the benchmark step, from rocprofv3 hardware counters (separate passes:
+# FETCH_SIZE and WRITE_SIZE cannot share one -- MI355X_MICROARCH.md).  Writes profiles-ready JSON:
+#   tools/pmc_bench.sh  ->  gpurun_out/pmc_bench.json  (copy to profiles/pmc_traffic.json)
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/pmc_bench
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/p$i" -o p -- python "$R/bench.py" --no-cpu-baseline --steps 2 --warmup 1 "$@" > "$OUT/p$i.log" 2>&1
+  i=$((i+1))
+done
+python - "$OUT" "$R/gpurun_out/pmc_bench.json" <<'PY'
+import collections, csv, glob, json, sys
+out, dst = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = {"conv1x1_ds_kernel": "conv1x1_ds_bn128", "conv3x3_rs_kernel": "conv3x3_rs_bn32"}
+res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (netG fwd B=16 @256^2); KiB; "
+                   "FETCH_SIZE is x2-corrected by bench.py per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
+for k, cs in agg.items():
+    for sym, nm in names.items():
+        if sym in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            res["%s@netG_B16_256" % nm] = {"fetch_kib": sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]),
+                                           "write_kib": sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]),
+                                           "launches": len(cs["FETCH_SIZE"]), "symbol": k[:80]}
+json.dump(res, open(dst, "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
