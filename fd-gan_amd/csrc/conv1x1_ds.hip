@@ -98,6 +98,8 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
 
   DsTimer tm;
   tm.start(a.dbg != nullptr && blockIdx.x == 0);
+  // (issuing the first two stages before this fold was measured 3-10 % SLOWER: hipcc then keeps the fold's
+  // global loads behind the in-flight LDS-DMA)
   fd_fold_bn(a, sc_lds, sh_lds, a.nks * 64, tid, DS_NT);
   __syncthreads();
   tm.stamp(5);

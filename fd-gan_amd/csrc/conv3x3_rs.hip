@@ -157,8 +157,8 @@ template <int XMODE>
 __device__ __forceinline__ void rs_loader(const ConvArgs& a, char* ring, const float* sc_lds, const float* sh_lds, int h,
                                           int lane, int bid, int nwg, RsTimer& tm) {
   const int tc = lane & 15, tp = lane >> 4;   // transform: 16-byte chunk, pixel within a group of 4
-  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8), s1 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8 + 4);
-  const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8), h1 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8 + 4);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, h0 = s0, h1 = s0;   // scale / shift of this lane's 8 channels (after barrier F)
+  bool first = true;
   int xf_off[5];   // transform: byte offset of this lane's unit `it` inside a ring row
 #pragma unroll
   for (int it = 0; it < 5; ++it) {
@@ -216,6 +216,14 @@ __device__ __forceinline__ void rs_loader(const ConvArgs& a, char* ring, const f
     for (int gi = 1; gi < RS_PF; ++gi)
       if (gi < n_iter) issue_row(4 * gi + 2 + h, slot_of(4 * gi + 2 + h));
     tm.stamp(0);
+    if (first) {   // barrier F: the other waves have folded BatchNorm into (scale, shift) meanwhile
+      first = false;
+      rs_barrier();
+      s0 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8);
+      s1 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8);
+      h1 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8 + 4);
+    }
     rs_wait_groups(min(RS_PF - 1, n_iter - 1));
     tm.stamp(1);
     xform_row(h, h);
@@ -265,6 +273,7 @@ __device__ __forceinline__ void rs_finisher(const ConvArgs& a, const char* red, 
   const bool plain = a.e_slope == 1.f;   // no epilogue activation (the growth convs)
   char* tb = rowstage + h * RowStore<RS_CT>::BYTES;
   int parity = 0;
+  rs_barrier();   // F (see the kernel body)
 
   for (int item = bid; item < a.ntiles; item += nwg) {
     const RsItem I = rs_item(a, item);
@@ -364,6 +373,7 @@ __device__ __forceinline__ void rs_compute(const ConvArgs& a, const char* ring, 
   for (int dx = 0; dx < 3; ++dx) boff[dx] = (m + dx) * 256 + (((4 * w + g) ^ ((2 * (m + dx)) & 15)) * 16);
   int parity = 0;
   const f32x4 fzero = {0.f, 0.f, 0.f, 0.f};
+  rs_barrier();   // F (see the kernel body)
 
   for (int item = bid; item < a.ntiles; item += nwg) {
     const int n_iter = rs_item(a, item).n_iter;
@@ -430,13 +440,15 @@ __global__ __launch_bounds__(RS_NT) void conv3x3_rs_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   RsTimer tm;
   tm.start(a.dbg != nullptr && blockIdx.x == 0);
-  fd_fold_bn(a, sc_lds, sh_lds, 128, tid, RS_NT);
+  // The BatchNorm fold (four dependent global loads per channel) is done by the compute and finisher waves
+  // while the loaders already issue the first row fetches; barrier F publishes scale / shift.
+  const bool is_loader = wave >= RS_R && wave < 2 * RS_R;
+  if (!is_loader) fd_fold_bn(a, sc_lds, sh_lds, 128, tid < 64 * RS_R ? tid : tid - 64 * RS_R, RS_NT - 64 * RS_R);
 
   // XCD-aware item order: consecutive workgroup ids go round-robin over the 8 XCDs, so give
   // each XCD a contiguous run of items (neighbouring strips share their halo columns in one L2).
   const int nwg = (int)gridDim.x;
   const int bid = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
-  __syncthreads();   // scale / shift visible
 
   if (wave >= RS_R && (a.dbg_skip & 32)) __builtin_amdgcn_s_setprio(2);
   if (wave >= 2 * RS_R) {
