@@ -1,0 +1,489 @@
+// conv_bwd.hip -- backward pieces of the fused convolution (first, correctness-first version):
+//
+//   forward (conv_igemm.h):   a = act_p(bn(x));  y = conv(a, W) (+ bias);  stored tensor = y
+//
+//   * data gradient   da = conv^T(dy, W) is a FORWARD convolution of dy with the flipped, transposed
+//                     filter (fdgan_pack_conv_weight(..., flip = 1), pad' = k - 1 - pad): no kernel here.
+//   * weight gradient dW[co][ci][tap] = sum_px dy[px][co] * a[px + tap][ci]      fdgan_conv2d_bwd_weight
+//                     with `a` recomputed from the raw input and the forward prologue (BatchNorm batch
+//                     statistics + activation), exactly as the forward staged it (bf16, zero padding).
+//   * prologue        dpre = da * act'(bn(x)) and the two BatchNorm reductions (sum dpre, sum dpre*xhat):
+//                     fdgan_bn_act_bwd;  dx = scale * (dpre - dbeta/M - xhat * dgamma/M): fdgan_bn_bwd_apply.
+//   * fdgan_conv2d_bwd_data_direct: any-stride data gradient into an NCHW fp32 tensor, one thread per
+//                     element -- for the gradient w.r.t. a network INPUT (3 / 9 channels), where a GEMM
+//                     formulation would waste the matrix pipe anyway.
+// Reference: autograd of nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU / nn.Sigmoid as composed in
+// /root/reference/models/dehaze1113.py:188-230 (D) and :703-801 (FDGAN).
+#include "conv_igemm.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// weight gradient.  Workgroup = 64 cout x 64 cin of ONE tap; 4 waves, each 32 x 32 (2 x 2 MFMA
+// tiles); k = output pixels, 32 per step.  Both operands are pixel-major in memory with channels
+// contiguous, and both need "8 consecutive pixels of one channel" per lane: the staging pass
+// transposes them into LDS ([channel][32 pixels], row pitch 80 B), after which fragment reads are
+// plain ds_read_b128.
+// ------------------------------------------------------------------------------------------
+constexpr int WG_ROWB = 80;                 // bytes per channel row: 32 pixels * 2 B + pad (16-byte aligned)
+constexpr int WG_TILE_B = 64 * WG_ROWB;     // one operand tile
+
+struct WgradArgs {
+  const unsigned short* x;    // raw forward input (NHWC bf16)
+  long long x_sn;
+  int x_sh, x_sw;
+  int Hs, Ws, Cin, Cin8;
+  const unsigned short* dy;   // gradient of the conv output (NHWC bf16)
+  long long dy_sn;
+  int dy_sh, dy_sw;
+  int Ho, Wo, Cout, Cout8;
+  int ks, stride, pad;
+  long long P;                // N * Ho * Wo
+  // prologue (no side effects in backward)
+  int pro_mode;
+  float p_slope, eps;
+  const float *p_mean, *p_var, *p_gamma, *p_beta;
+  float* dw;                  // [Cout][Cin][ks][ks] fp32
+  float* dbias;               // [Cout] or NULL
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * WG_TILE_B];
+  __shared__ float sc_s[64], sh_s[64];
+  __shared__ float bsum[32][64];
+  char* At = lds;                 // [64 ci][32 px]
+  char* Dt = lds + WG_TILE_B;     // [64 co][32 px]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int ky = tap / a.ks, kx = tap - ky * a.ks;
+  // per-channel scale / shift of this cin tile (BatchNorm fold, as fd_fold_bn but without side effects)
+  if (tid < 64) {
+    const int c = ci0 + tid;
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      sc = 0.f;
+      if (c < a.Cin) {
+        const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
+        sc = g / sqrtf(a.p_var[c] + a.eps);
+        sh = b - a.p_mean[c] * sc;
+      }
+    }
+    sc_s[tid] = sc;
+    sh_s[tid] = sh;
+  }
+  __syncthreads();
+  const int spx = tid >> 3, chunk = tid & 7;   // staging: pixel of the step, 8-channel chunk of the tile
+  const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
+  const bool want_bias = a.dbias != nullptr && tap == 0 && blockIdx.x == 0;
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+  const int m = lane & 15, g = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long HW = (long long)a.Ho * a.Wo;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  for (long long p0 = 0; p0 < a.P; p0 += 32) {
+    const long long p = p0 + spx;
+    u32x4 dv = zero4, xv = zero4;
+    if (p < a.P) {
+      const long long n = p / HW, r = p - n * HW;
+      const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
+      if (dy_ok) dv = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
+      const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+      if (x_ok && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) {
+        xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci0 + chunk * 8);
+        if (a.pro_mode != 0) xv = fd_xform8(xv, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);   // zero padding stays zero
+      }
+    }
+    __syncthreads();   // previous step's fragments consumed
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned short xe = (unsigned short)((xv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      const unsigned short de = (unsigned short)((dv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      *reinterpret_cast<unsigned short*>(At + (chunk * 8 + e) * WG_ROWB + spx * 2) = xe;
+      *reinterpret_cast<unsigned short*>(Dt + (chunk * 8 + e) * WG_ROWB + spx * 2) = de;
+      if (want_bias) bs[e] += __uint_as_float((unsigned)de << 16);
+    }
+    __syncthreads();
+    bf16x8 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + g * 16));   // A: rows = cout
+      bf[i] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + i * 16 + m) * WG_ROWB + g * 16));   // B: cols = cin
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+  // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
+  const int kk = a.ks * a.ks;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wco + i * 16 + g * 4 + r, ci = ci0 + wci + j * 16 + m;
+        if (co < a.Cout && ci < a.Cin) a.dw[((long long)co * a.Cin + ci) * kk + tap] = acc[i][j][r];
+      }
+  if (want_bias) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[spx][chunk * 8 + e] = bs[e];
+    __syncthreads();
+    if (tid < 64 && co0 + tid < a.Cout) {
+      float t = 0.f;
+      for (int q = 0; q < 32; ++q) t += bsum[q][tid];
+      a.dbias[co0 + tid] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// prologue backward, pass 1: dpre = da * act'(scale*x + shift) in place (bf16), and per-workgroup
+// partial sums (sum dpre, sum dpre * xhat) per channel for BatchNorm's dbeta / dgamma.
+// One thread per (pixel, 8-channel group); a workgroup covers 32 pixels x up to 64 channel groups.
+// ------------------------------------------------------------------------------------------
+struct BnActBwdArgs {
+  unsigned short* da;   // in: gradient w.r.t. the activated tensor; out: dpre
+  long long da_sn;
+  int da_sh, da_sw;
+  const unsigned short* x;
+  long long x_sn;
+  int x_sh, x_sw;
+  int H, W, C, C8;
+  long long P;
+  int pro_mode;
+  float slope, eps;
+  const float *mean, *var, *gamma, *beta;
+  float* partial;   // [rows][cpad][2] or NULL (no norm)
+  int cpad;
+};
+
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
+  __shared__ float red[2][32][64];   // [which][pixel slot][channel within this thread column]: reduced below
+  const int tid = threadIdx.x;
+  const int grp = tid & 7, slot = tid >> 3;   // 8 channel groups (64 channels) x 32 pixels per pass
+  const long long HW = (long long)a.H * a.W;
+  for (int c8_0 = 0; c8_0 < a.C8; c8_0 += 8) {
+    const int c8 = c8_0 + grp;
+    const bool cok = c8 < a.C8;
+    float sc[8], sh[8], xm[8], xr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      sc[e] = 1.f, sh[e] = 0.f, xm[e] = 0.f, xr[e] = 1.f;
+      if (a.pro_mode == 2 && cok && c < a.C) {
+        const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+        sc[e] = gmm * rs;
+        sh[e] = b - a.mean[c] * sc[e];
+        xm[e] = a.mean[c];
+        xr[e] = rs;
+      }
+    }
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long p = (long long)blockIdx.x * 32 + slot; p < a.P; p += (long long)gridDim.x * 32) {
+      if (!cok) continue;
+      const long long n = p / HW, r = p - n * HW;
+      const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+      unsigned short* dp = a.da + n * a.da_sn + (long long)y * a.da_sh + (long long)xx * a.da_sw + c8 * 8;
+      const u32x4 dv = *reinterpret_cast<const u32x4*>(dp);
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+      const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dv), f32x8);
+      const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv), f32x8);
+      f32x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pre = fmaf(xf[e], sc[e], sh[e]);
+        const float gsl = pre > 0.f ? 1.f : a.slope;   // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+        o[e] = d[e] * gsl;
+        s1[e] += o[e];
+        s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
+      }
+      *reinterpret_cast<u32x4*>(dp) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+    }
+    if (a.partial != nullptr) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[0][slot][grp * 8 + e] = s1[e];
+        red[1][slot][grp * 8 + e] = s2[e];
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int which = tid >> 6, cl = tid & 63;
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += red[which][q][cl];
+        const int c = c8_0 * 8 + cl;
+        if (c < a.cpad) a.partial[((long long)blockIdx.x * a.cpad + c) * 2 + which] = t;
+      }
+    }
+  }
+}
+
+// sums -> (dgamma, dbeta): the (sum, sum-of-products) rows of bn_act_bwd reduced in fp64
+struct SumFinArgs {
+  const float* partial;
+  long long rows, cpad, channels;
+  float *dbeta, *dgamma;
+  int accumulate;
+};
+__global__ __launch_bounds__(256) void sum_finalize_kernel(SumFinArgs a) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.channels) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (long long r = 0; r < a.rows; ++r) {
+    t1 += a.partial[(r * a.cpad + c) * 2];
+    t2 += a.partial[(r * a.cpad + c) * 2 + 1];
+  }
+  if (a.accumulate) {
+    a.dbeta[c] += (float)t1;
+    a.dgamma[c] += (float)t2;
+  } else {
+    a.dbeta[c] = (float)t1;
+    a.dgamma[c] = (float)t2;
+  }
+}
+
+// prologue backward, pass 2 (BatchNorm only): dx = scale * (dpre - dbeta/M - xhat * dgamma/M), written
+// to (or accumulated into) the gradient buffer of x.
+struct BnApplyArgs {
+  const unsigned short* dpre;
+  long long dp_sn;
+  int dp_sh, dp_sw;
+  const unsigned short* x;
+  long long x_sn;
+  int x_sh, x_sw;
+  unsigned short* dx;
+  long long dx_sn;
+  int dx_sh, dx_sw;
+  int H, W, C, C8;
+  long long P;
+  float eps, inv_m;
+  const float *mean, *var, *gamma, *dbeta, *dgamma;
+  int accumulate;
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= a.P * a.C8) return;
+  const long long p = u / a.C8;
+  const int c8 = (int)(u - p * a.C8);
+  const long long HW = (long long)a.H * a.W, n = p / HW, r = p - n * HW;
+  const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+  const f32x8 d = __builtin_convertvector(
+      __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8)), f32x8);
+  const f32x8 xf = __builtin_convertvector(
+      __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8)), f32x8);
+  unsigned short* op = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+  f32x8 o;
+  if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(op)), f32x8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    float v = 0.f;
+    if (c < a.C) {
+      const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f;
+      const float xhat = (xf[e] - a.mean[c]) * rs;
+      v = gmm * rs * (d[e] - a.dbeta[c] * a.inv_m - xhat * a.dgamma[c] * a.inv_m);
+    }
+    o[e] = a.accumulate ? o[e] + v : v;
+  }
+  *reinterpret_cast<u32x4*>(op) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+}
+
+// ------------------------------------------------------------------------------------------
+// direct data gradient into NCHW fp32 (network inputs): dx[n][ci][iy][ix] = sum over (co, taps) of
+// dy[n][oy][ox][co] * W[co][ci][ky][kx] with oy*stride + ky - pad == iy.  One thread per dx element.
+// ------------------------------------------------------------------------------------------
+struct DgradDirectArgs {
+  const unsigned short* dy;
+  long long dy_sn;
+  int dy_sh, dy_sw;
+  int Ho, Wo, Cout;
+  const float* w;   // [Cout][Cin][ks][ks] fp32
+  float* dx;        // [N][Cin][H][W]
+  int N, Cin, H, W, ks, stride, pad;
+};
+__global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.N * a.Cin * a.H * a.W;
+  if (u >= total) return;
+  const int ix = (int)(u % a.W);
+  long long r = u / a.W;
+  const int iy = (int)(r % a.H);
+  r /= a.H;
+  const int ci = (int)(r % a.Cin), n = (int)(r / a.Cin);
+  float s = 0.f;
+  for (int ky = 0; ky < a.ks; ++ky) {
+    const int ty = iy + a.pad - ky;
+    if (ty < 0 || ty % a.stride) continue;
+    const int oy = ty / a.stride;
+    if (oy >= a.Ho) continue;
+    for (int kx = 0; kx < a.ks; ++kx) {
+      const int tx = ix + a.pad - kx;
+      if (tx < 0 || tx % a.stride) continue;
+      const int ox = tx / a.stride;
+      if (ox >= a.Wo) continue;
+      const unsigned short* dp = a.dy + (long long)n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw;
+      for (int co = 0; co < a.Cout; ++co)
+        s = fmaf(__uint_as_float((unsigned)dp[co] << 16),
+                 (float)(__bf16)a.w[(((long long)co * a.Cin + ci) * a.ks + ky) * a.ks + kx], s);   // the forward's bf16 filter
+    }
+  }
+  a.dx[u] = s;
+}
+
+// sigmoid epilogue backward: g[n][h][w][0] (NHWC bf16, 1 channel stored in an 8-channel-padded view)
+// = dout * s * (1 - s) from NCHW fp32 (C == 1) tensors
+struct SigBwdArgs {
+  const float *dout, *out;
+  unsigned short* g;
+  long long total;
+  int gpitch;
+};
+__global__ void sigmoid_bwd_kernel(SigBwdArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  const float s = a.out[u], v = a.dout[u] * s * (1.f - s);
+  f32x8 o = {v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<u32x4*>(a.g + u * a.gpitch) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+}
+
+int check_view(const FdTensor* t, const char* what) {
+  FD_REQUIRE(t && t->ptr, "%s: NULL tensor", what);
+  FD_REQUIRE(t->dtype == FD_BF16 && t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 &&
+                 ((uintptr_t)t->ptr & 15) == 0,
+             "%s: NHWC bf16 view with 8-element aligned strides expected", what);
+  return FD_OK;
+}
+
+void fill_pro(const FdPrologue* pro, int& mode, float& slope, float& eps, const float*& mean, const float*& var,
+              const float*& gamma, const float*& beta) {
+  mode = 0, slope = 1.f, eps = 1e-5f, mean = var = gamma = beta = nullptr;
+  if (!pro) return;
+  slope = pro->act == FD_ACT_RELU ? 0.f : (pro->act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
+  mode = pro->mean ? 2 : (pro->act != FD_ACT_NONE ? 1 : 0);
+  eps = pro->eps;
+  mean = pro->mean, var = pro->var, gamma = pro->gamma, beta = pro->beta;
+}
+
+}  // namespace
+
+extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
+                                       float* dw, float* dbias, FdStream stream) {
+  if (int rc = check_view(x, "conv2d_bwd_weight(x)")) return rc;
+  if (int rc = check_view(dy, "conv2d_bwd_weight(dy)")) return rc;
+  FD_REQUIRE(d && dw, "conv2d_bwd_weight: NULL descriptor / dw");
+  FD_REQUIRE(!(pro && pro->pool2), "conv2d_bwd_weight: pooled prologue not supported yet");
+  FD_REQUIRE(!d->upsample2, "conv2d_bwd_weight: upsampled output not supported yet");
+  FD_REQUIRE(pro == nullptr || pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU || pro->act == FD_ACT_LEAKY02,
+             "conv2d_bwd_weight: prologue activation %d", pro ? pro->act : 0);
+  const long long ho = (x->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (x->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  FD_REQUIRE(dy->n == x->n && dy->h == ho && dy->w == wo, "conv2d_bwd_weight: dy is %lldx%lld, expected %lldx%lld",
+             (long long)dy->h, (long long)dy->w, ho, wo);
+  const int cout = d->cout ? d->cout : (int)dy->c;
+  WgradArgs a{};
+  a.x = static_cast<const unsigned short*>(x->ptr);
+  a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
+  a.Hs = (int)x->h, a.Ws = (int)x->w, a.Cin = (int)x->c, a.Cin8 = (int)((x->c + 7) / 8);
+  a.dy = static_cast<const unsigned short*>(dy->ptr);
+  a.dy_sn = dy->stride[0], a.dy_sh = (int)dy->stride[1], a.dy_sw = (int)dy->stride[2];
+  a.Ho = (int)ho, a.Wo = (int)wo, a.Cout = cout, a.Cout8 = (cout + 7) / 8;
+  FD_REQUIRE(a.Cout8 * 8 <= dy->stride[2] && a.Cin8 * 8 <= x->stride[2], "conv2d_bwd_weight: channel padding exceeds the pixel pitch");
+  a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  a.P = (long long)x->n * ho * wo;
+  fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
+  a.dw = dw;
+  a.dbias = dbias;
+  dim3 grid((unsigned)((a.Cin + 63) / 64), (unsigned)((cout + 63) / 64), (unsigned)(d->ksize * d->ksize));
+  return fd_launch(&conv_wgrad_kernel, "conv_wgrad", grid, dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
+                                int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
+  if (int rc = check_view(da, "bn_act_bwd(da)")) return rc;
+  if (int rc = check_view(x, "bn_act_bwd(x)")) return rc;
+  FD_REQUIRE(da->n == x->n && da->h == x->h && da->w == x->w && da->c == x->c, "bn_act_bwd: da / x shape mismatch");
+  BnActBwdArgs a{};
+  a.da = static_cast<unsigned short*>(da->ptr);
+  a.da_sn = da->stride[0], a.da_sh = (int)da->stride[1], a.da_sw = (int)da->stride[2];
+  a.x = static_cast<const unsigned short*>(x->ptr);
+  a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
+  a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
+  a.P = (long long)x->n * x->h * x->w;
+  fill_pro(pro, a.pro_mode, a.slope, a.eps, a.mean, a.var, a.gamma, a.beta);
+  a.cpad = a.C8 * 8;
+  long long rows = (a.P + 31) / 32;
+  if (rows > 512) rows = 512;
+  a.partial = (a.pro_mode == 2) ? partial : nullptr;
+  if (a.partial) FD_REQUIRE(rows * a.cpad * 2 <= capacity_floats, "bn_act_bwd: workspace too small (%lld floats needed)", rows * a.cpad * 2);
+  if (rows_out) *rows_out = rows;
+  if (cpad_out) *cpad_out = a.cpad;
+  return fd_launch(&bn_act_bwd_kernel, "bn_act_bwd", dim3((unsigned)rows), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
+                                     float* dbeta, int accumulate, FdStream stream) {
+  FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate};
+  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
+                                  const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream) {
+  if (int rc = check_view(dpre, "bn_bwd_apply(dpre)")) return rc;
+  if (int rc = check_view(x, "bn_bwd_apply(x)")) return rc;
+  if (int rc = check_view(dx, "bn_bwd_apply(dx)")) return rc;
+  FD_REQUIRE(pro && pro->mean && pro->var && dgamma && dbeta, "bn_bwd_apply: needs the forward batch statistics and dgamma/dbeta");
+  FD_REQUIRE(dpre->n == x->n && dpre->h == x->h && dpre->w == x->w && dpre->c == x->c && dx->n == x->n && dx->h == x->h &&
+                 dx->w == x->w && dx->c == x->c,
+             "bn_bwd_apply: shape mismatch");
+  BnApplyArgs a{};
+  a.dpre = static_cast<const unsigned short*>(dpre->ptr);
+  a.dp_sn = dpre->stride[0], a.dp_sh = (int)dpre->stride[1], a.dp_sw = (int)dpre->stride[2];
+  a.x = static_cast<const unsigned short*>(x->ptr);
+  a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
+  a.dx = static_cast<unsigned short*>(dx->ptr);
+  a.dx_sn = dx->stride[0], a.dx_sh = (int)dx->stride[1], a.dx_sw = (int)dx->stride[2];
+  a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
+  a.P = (long long)x->n * x->h * x->w;
+  a.eps = pro->eps;
+  a.inv_m = 1.f / (float)a.P;
+  a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.dbeta = dbeta, a.dgamma = dgamma;
+  a.accumulate = accumulate;
+  const long long units = a.P * a.C8;
+  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)((units + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
+                                            float* dx, int64_t n, int64_t h, int64_t wd, FdStream stream) {
+  if (int rc = check_view(dy, "conv2d_bwd_data_direct(dy)")) return rc;
+  FD_REQUIRE(w && dx && d && cout > 0 && cin > 0, "conv2d_bwd_data_direct: bad arguments");
+  const long long ho = (h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (wd + 2 * d->pad - d->ksize) / d->stride + 1;
+  FD_REQUIRE(dy->n == n && dy->h == ho && dy->w == wo && dy->c >= cout, "conv2d_bwd_data_direct: dy shape mismatch");
+  DgradDirectArgs a{};
+  a.dy = static_cast<const unsigned short*>(dy->ptr);
+  a.dy_sn = dy->stride[0], a.dy_sh = (int)dy->stride[1], a.dy_sw = (int)dy->stride[2];
+  a.Ho = (int)ho, a.Wo = (int)wo, a.Cout = cout;
+  a.w = w, a.dx = dx;
+  a.N = (int)n, a.Cin = cin, a.H = (int)h, a.W = (int)wd, a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  const long long total = n * cin * h * wd;
+  return fd_launch(&dgrad_direct_kernel, "dgrad_direct", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_sigmoid_bwd(const float* dout, const float* out, int64_t count, const FdTensor* g, FdStream stream) {
+  if (int rc = check_view(g, "sigmoid_bwd(g)")) return rc;
+  FD_REQUIRE(dout && out && g->n * g->h * g->w == count && g->stride[1] == g->w * g->stride[2] && g->stride[0] == g->h * g->stride[1],
+             "sigmoid_bwd: g must be a dense NHWC view of `count` pixels");
+  SigBwdArgs a{dout, out, static_cast<unsigned short*>(g->ptr), count, (int)g->stride[2]};
+  return fd_launch(&sigmoid_bwd_kernel, "sigmoid_bwd", dim3((unsigned)((count + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}

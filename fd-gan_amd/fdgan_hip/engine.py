@@ -237,3 +237,43 @@ class Plan:
         ms = (C.c_float * n)()
         L.check(self.lib.fdgan_plan_profile(self.h, stream_ptr(), ms, n), "plan_profile")
         return list(ms)
+
+
+# ---- backward ------------------------------------------------------------------------------------
+def conv_bwd_weight(x_fd, pro, dy_fd, desc, dw, dbias=None):
+    """dw: fp32 tensor shaped like the Conv2d weight (cout, cin, k, k); dbias: fp32 (cout,) or None."""
+    L.check(L.load().fdgan_conv2d_bwd_weight(C.byref(x_fd), C.byref(pro) if pro is not None else None, C.byref(dy_fd),
+                                             C.byref(desc), dw.data_ptr(), dbias.data_ptr() if dbias is not None else None,
+                                             stream_ptr()), "conv2d_bwd_weight")
+
+
+def bn_act_bwd(da_fd, x_fd, pro, ws=None):
+    """In place: da <- da * act'(bn(x)).  With a norm in `pro`, also fills `ws` with the partial sums and
+    returns (rows, cpad) for bn_bwd_finalize."""
+    rows, cpad = C.c_int64(0), C.c_int64(0)
+    L.check(L.load().fdgan_bn_act_bwd(C.byref(da_fd), C.byref(x_fd), C.byref(pro) if pro is not None else None,
+                                      ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                      C.byref(rows), C.byref(cpad), stream_ptr()), "bn_act_bwd")
+    return rows.value, cpad.value
+
+
+def bn_bwd_finalize(ws, rows, cpad, channels, dgamma, dbeta, accumulate=False):
+    L.check(L.load().fdgan_bn_bwd_finalize(ws.data_ptr(), rows, cpad, channels, dgamma.data_ptr(), dbeta.data_ptr(),
+                                           int(bool(accumulate)), stream_ptr()), "bn_bwd_finalize")
+
+
+def bn_bwd_apply(dpre_fd, x_fd, pro, dgamma, dbeta, dx_fd, accumulate=False):
+    L.check(L.load().fdgan_bn_bwd_apply(C.byref(dpre_fd), C.byref(x_fd), C.byref(pro), dgamma.data_ptr(), dbeta.data_ptr(),
+                                        C.byref(dx_fd), int(bool(accumulate)), stream_ptr()), "bn_bwd_apply")
+
+
+def conv_bwd_data_direct(dy_fd, weight, desc, dx):
+    """dx: contiguous NCHW fp32 (n, cin, h, w), overwritten; weight: fp32 (cout, cin, k, k)."""
+    n, cin, h, w = dx.shape
+    L.check(L.load().fdgan_conv2d_bwd_data_direct(C.byref(dy_fd), weight.data_ptr(), weight.shape[0], cin, C.byref(desc),
+                                                  dx.data_ptr(), n, h, w, stream_ptr()), "conv2d_bwd_data_direct")
+
+
+def sigmoid_bwd(dout, out, g_view):
+    L.check(L.load().fdgan_sigmoid_bwd(dout.data_ptr(), out.data_ptr(), out.numel(), C.byref(g_view.fd), stream_ptr()),
+            "sigmoid_bwd")

@@ -85,6 +85,17 @@ SIGNATURES = {
     "fdgan_laplacian3_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_fusion_input_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(FdTensor),
                                           C.c_int, C.c_void_p]),
+    "fdgan_conv2d_bwd_weight": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor),
+                                          C.POINTER(FdConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdgan_bn_act_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
+    "fdgan_bn_bwd_apply": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.c_void_p,
+                                     C.c_void_p, C.POINTER(FdTensor), C.c_int, C.c_void_p]),
+    "fdgan_conv2d_bwd_data_direct": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_int, C.c_int, C.POINTER(FdConvDesc),
+                                               C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(FdTensor), C.c_void_p]),
 }
 
 _lib = None

@@ -201,6 +201,34 @@ int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* launches);
 int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
 
 /* ---- pooling ------------------------------------------------------------------- */
+/* ---- backward (first version: D's training path; the generator's dense blocks follow) -------------
+ * Autograd of the fused forward op  a = act(bn(x)); y = conv(a, W) + b  (nn.Conv2d / nn.BatchNorm2d /
+ * nn.LeakyReLU as composed in dehaze1113.py:188-230).  Gradients of activations are NHWC bf16 views
+ * like the activations themselves; parameter gradients are fp32 in the parameter's own layout.
+ *
+ *  data gradient    da = conv^T(dy, W): call fdgan_conv2d_fwd on dy with the filter packed by
+ *                   fdgan_pack_conv_weight(w, cout' = cin, cin' = cout, k, 0, flip = 1, ...) and pad' = k-1-pad
+ *                   (stride 1); fdgan_conv2d_bwd_data_direct covers any stride for gradients w.r.t.
+ *                   network inputs (NCHW fp32, few channels).
+ *  weight gradient  fdgan_conv2d_bwd_weight: dW[co][ci][ky][kx] = sum_px dy[px][co] * a[px*s + k - pad][ci],
+ *                   `a` recomputed from the raw input x and the forward prologue (batch statistics, no side
+ *                   effects); dbias = sum_px dy (or NULL).
+ *  prologue         fdgan_bn_act_bwd:  dpre = da * act'(bn(x)) in place, plus rows x cpad x {sum dpre,
+ *                   sum dpre*xhat} partials when the prologue has a norm -> fdgan_bn_bwd_finalize -> (dgamma,
+ *                   dbeta); fdgan_bn_bwd_apply: dx = gamma*rstd * (dpre - dbeta/M - xhat*dgamma/M).
+ *  sigmoid          fdgan_sigmoid_bwd: g = dout * s * (1 - s) for the 1-channel NCHW fp32 map D returns. */
+int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
+                            float* dw, float* dbias, FdStream stream);
+int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
+                     int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
+int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
+                          float* dbeta, int accumulate, FdStream stream);
+int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
+                       const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
+int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
+                                 float* dx, int64_t n, int64_t h, int64_t wd, FdStream stream);
+int fdgan_sigmoid_bwd(const float* dout, const float* out, int64_t count, const FdTensor* g, FdStream stream);
+
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);

@@ -1,0 +1,146 @@
+"""GPU parity of the backward primitives (through the C ABI) against torch autograd on CPU in fp64,
+with operands rounded to bf16 where the kernels see bf16."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hiputil import bf16_round, rel_rms, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def E():
+    from fdgan_hip import engine, lib
+    lib.load()
+    return engine
+
+
+def _nhwc(t, pitch=None, dev=DEV):
+    n, c, h, w = t.shape
+    pitch = pitch or (c + 7) // 8 * 8
+    buf = torch.zeros((n, h, w, pitch), dtype=torch.bfloat16, device=dev)
+    buf[..., :c] = t.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    return buf
+
+
+def _from_nhwc(buf, c):
+    return buf[..., :c].permute(0, 3, 1, 2).float().cpu()
+
+
+def _bn_params(c, seed):
+    return dict(mean=seeded((c,), seed, -0.3, 0.3), var=seeded((c,), seed + 1, 0.5, 1.5),
+                gamma=seeded((c,), seed + 2, 0.5, 1.5), beta=seeded((c,), seed + 3, -0.3, 0.3))
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,bn,slope", [
+    (36, 72, 3, 1, 1, False, 0.2), (72, 144, 3, 1, 1, True, 0.2), (144, 40, 4, 1, 1, True, 0.2), (9, 36, 4, 2, 1, False, 1.0),
+    (128, 32, 3, 1, 1, True, 0.0), (96, 128, 1, 1, 0, True, 0.0)])
+def test_weight_gradient(E, cin, cout, k, stride, pad, bn, slope):
+    from fdgan_hip import lib as L
+    n, h, w = 2, 13, 18
+    x = bf16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = bf16_round(seeded((n, cout, ho, wo), 2, -1.0, 1.0))
+    p = _bn_params(cin, 10) if bn else None
+    act = {0.0: L.ACT_RELU, 0.2: L.ACT_LEAKY02, 1.0: L.ACT_NONE}[slope]
+    # reference: a = bf16(act(bn(x))), dW = conv weight gradient in fp64
+    a = x.double()
+    if bn:
+        sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+        sh = (p["beta"] - p["mean"] * sc).float()
+        a = (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()
+    a = torch.where(a > 0, a, a * slope)
+    a = bf16_round(a.float()).double()
+    wref = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(a, wref, None, stride, pad)
+    y.backward(dy.double())
+    xb, dyb = _nhwc(x), _nhwc(dy)
+    pro = None
+    if bn or act != L.ACT_NONE:
+        kw = dict(act=act)
+        if bn:
+            d = {kk: v.to(DEV) for kk, v in p.items()}
+            kw.update(mean=d["mean"], var=d["var"], gamma=d["gamma"], beta=d["beta"], eps=1e-5)
+        pro = E.make_prologue(**kw)
+    dw = torch.full((cout, cin, k, k), 7.0, dtype=torch.float32, device=DEV)
+    db = torch.full((cout,), 7.0, dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(k, stride, pad, cout=cout), dw, db)
+    torch.cuda.synchronize()
+    err = rel_rms(dw.cpu().double(), wref.grad)
+    assert err < 5e-3, err
+    assert rel_rms(db.cpu().double(), dy.double().sum(dim=(0, 2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize("c,slope,bn", [(72, 0.2, True), (36, 0.2, False), (128, 0.0, True)])
+def test_prologue_backward(E, c, slope, bn):
+    from fdgan_hip import lib as L
+    n, h, w = 3, 11, 14
+    x = bf16_round(seeded((n, c, h, w), 3, -1.5, 1.5))
+    da = bf16_round(seeded((n, c, h, w), 4, -1.0, 1.0))
+    act = {0.0: L.ACT_RELU, 0.2: L.ACT_LEAKY02}[slope]
+    xr = x.double().requires_grad_(True)
+    if bn:
+        gamma = seeded((c,), 5, 0.5, 1.5).double().requires_grad_(True)
+        beta = seeded((c,), 6, -0.3, 0.3).double().requires_grad_(True)
+        pre = F.batch_norm(xr, None, None, gamma, beta, True, 0.1, 1e-5)
+        mean = x.double().mean(dim=(0, 2, 3)).float()
+        var = x.double().var(dim=(0, 2, 3), unbiased=False).float()
+    else:
+        pre = xr
+    a = torch.where(pre > 0, pre, pre * slope)
+    a.backward(da.double())
+    xb, dab = _nhwc(x, pitch=(c + 7) // 8 * 8 + 8), _nhwc(da)
+    xv, dav = E.View(xb, 0, c), E.View(dab, 0, c)
+    if bn:
+        keep = [mean.to(DEV), var.to(DEV), gamma.detach().float().to(DEV), beta.detach().float().to(DEV)]   # the struct holds raw pointers
+        pro = E.make_prologue(act=act, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+        ws = torch.zeros(1 << 20, dtype=torch.float32, device=DEV)
+        rows, cpad = E.bn_act_bwd(dav.fd, xv.fd, pro, ws)
+        dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        E.bn_bwd_finalize(ws, rows, cpad, c, dg, db)
+        dxb = torch.zeros_like(dab)
+        E.bn_bwd_apply(dav.fd, xv.fd, pro, dg, db, E.View(dxb, 0, c).fd)
+        torch.cuda.synchronize()
+        assert rel_rms(dg.cpu().double(), gamma.grad) < 6e-3
+        assert rel_rms(db.cpu().double(), beta.grad) < 6e-3
+        assert rel_rms(_from_nhwc(dxb, c).double(), xr.grad) < 1e-2
+    else:
+        pro = E.make_prologue(act=act)
+        E.bn_act_bwd(dav.fd, xv.fd, pro)
+        torch.cuda.synchronize()
+        assert rel_rms(_from_nhwc(dab, c).double(), xr.grad) < 6e-3
+
+
+def test_data_gradient_as_flipped_forward_conv_and_direct(E):
+    from fdgan_hip import lib as L
+    n, cin, cout, h, w = 2, 72, 144, 12, 17
+    for (k, pad) in ((3, 1), (4, 1)):
+        ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+        dy = bf16_round(seeded((n, cout, ho, wo), 7, -1.0, 1.0))
+        wt = seeded((cout, cin, k, k), 8, -1.0, 1.0) * (2.0 / (cin * k * k)) ** 0.5
+        xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, bf16_round(wt).double(), None, 1, pad).backward(dy.double())
+        dyb = _nhwc(dy)
+        wd = wt.to(DEV).contiguous()
+        pw = E.PackedWeight(wd, cin, cout, k, transposed=False, flip=True, stride=1, layout=L.WLAYOUT_CHUNK32)
+        pw.pack()
+        dxb = torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device=DEV)
+        E.conv2d(E.View(dyb, 0, cout).fd, pw, None, None, E.View(dxb, 0, cin).fd,
+                 E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32))
+        torch.cuda.synchronize()
+        assert rel_rms(_from_nhwc(dxb, cin).double(), xr.grad) < 6e-3, (k, pad)
+    # strided 4x4 (D's first conv): direct kernel into NCHW fp32
+    cin, cout, k, s, pad, h, w = 9, 36, 4, 2, 1, 20, 26
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    dy = bf16_round(seeded((n, cout, ho, wo), 9, -1.0, 1.0))
+    wt = seeded((cout, cin, k, k), 10, -0.3, 0.3)
+    xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, bf16_round(wt).double(), None, s, pad).backward(dy.double())
+    dx = torch.full((n, cin, h, w), 5.0, dtype=torch.float32, device=DEV)
+    dyv, wdev = E.View(_nhwc(dy), 0, cout), wt.to(DEV).contiguous()     # keep the buffers alive across the launch
+    E.conv_bwd_data_direct(dyv.fd, wdev, E.conv_desc(k, s, pad, cout=cout), dx)
+    torch.cuda.synchronize()
+    assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5
