@@ -64,3 +64,25 @@ def psnr(a, b, peak=2.0):
 def seeded(shape, seed, lo=-1.0, hi=1.0):
     a = np.random.default_rng(seed).random(shape) * (hi - lo) + lo
     return torch.from_numpy(a.astype(np.float32))
+
+
+def emulate_bf16_operands(module):
+    """Turns an fp32 oracle network into a statement of what the HIP path computes: every conv sees its
+    filter, its (activated) input and its stored output rounded to bf16 -- straight-through for autograd -- and in-place
+    activations are made out-of-place so conv outputs can be inspected.  Accumulation stays fp32/fp64.
+    Needed for GRADIENT parity: ReLU / LeakyReLU derivatives are discontinuous, so an oracle whose
+    pre-activations differ by the bf16 rounding of the operands flips a few masks in a thousand, which
+    alone is a 5-10 % rms difference in every upstream gradient."""
+    import torch.nn as nn
+    st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.weight.copy_(m.weight.to(torch.bfloat16).float())
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            m.register_forward_pre_hook(lambda mod, inp: (st(inp[0]),))
+            m.register_forward_hook(lambda mod, inp, out: st(out))      # the stored (bf16) tensor is what the next op reads
+        if isinstance(m, (nn.ReLU, nn.LeakyReLU)):
+            m.inplace = False
+    return module
