@@ -52,3 +52,32 @@ def test_single_process_context_is_a_no_op(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2"), monkeypatch.setenv("RANK", "5")
     with pytest.raises(ValueError):
         DpContext.from_env(device=torch.device("cpu"))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from fdgan_hip.dp import DpContext, GradBuckets
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    frozen = torch.nn.Linear(4, 4)                       # never receives a gradient: must be skipped, not reduced
+    params = list(net.parameters()) + list(frozen.parameters())
+    x = torch.full((2, 3, 6, 6), float(rank + 1))
+    net(x).square().mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    nb = GradBuckets(params, dp, bucket_mb=0.0002).allreduce_()
+    torch.save(dict(local=local, avg=[p.grad.clone() for p in net.parameters()], nb=nb,
+                    frozen_none=all(p.grad is None for p in frozen.parameters())), os.path.join(out_dir, "g%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "g%d.pt" % i)) for i in range(world)]
+    assert r[0]["nb"] == r[1]["nb"] >= 2 and r[0]["frozen_none"] and r[1]["frozen_none"]
+    for k in range(len(r[0]["local"])):
+        want = (r[0]["local"][k] + r[1]["local"][k]) / 2
+        assert torch.allclose(r[0]["avg"][k], want, rtol=1e-6, atol=1e-8)
+        assert torch.equal(r[0]["avg"][k], r[1]["avg"][k])
