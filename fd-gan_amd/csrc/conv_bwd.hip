@@ -43,8 +43,11 @@ struct WgradArgs {
   int pro_mode;
   float p_slope, eps;
   const float *p_mean, *p_var, *p_gamma, *p_beta;
-  float* dw;                  // [Cout][Cin][ks][ks] fp32
-  float* dbias;               // [Cout] or NULL
+  float* dw;                  // [Cout][Cin][ks][ks] fp32 (nsplit == 1) or [nsplit][Cout][Cin][ks][ks] partials
+  float* dbias;               // [Cout] or NULL ([nsplit][Cout] partials when nsplit > 1)
+  int pool;                   // 2x2 average of the activated input (1x1 convs): x is the full-resolution tensor
+  int nsplit;                 // pixel splits (blockIdx.z = tap * nsplit + split); partials summed by wgrad_reduce
+  long long split_px;         // pixels per split (multiple of 32)
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   char* At = lds;                 // [64 ci][32 px]
   char* Dt = lds + WG_TILE_B;     // [64 co][32 px]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = (int)blockIdx.z / a.nsplit, split = (int)blockIdx.z % a.nsplit;
   const int ky = tap / a.ks, kx = tap - ky * a.ks;
   // per-channel scale / shift of this cin tile (BatchNorm fold, as fd_fold_bn but without side effects)
   if (tid < 64) {
@@ -86,15 +89,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const long long HW = (long long)a.Ho * a.Wo;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  for (long long p0 = 0; p0 < a.P; p0 += 32) {
+  const long long p_begin = (long long)split * a.split_px;
+  const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
+  for (long long p0 = p_begin; p0 < p_end; p0 += 32) {
     const long long p = p0 + spx;
     u32x4 dv = zero4, xv = zero4;
-    if (p < a.P) {
+    if (p < p_end) {
       const long long n = p / HW, r = p - n * HW;
       const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
       if (dy_ok) dv = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
       const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-      if (x_ok && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) {
+      if (a.pool) {   // 1x1 conv on the 2x2 average of the activated input (transition / skip pooling)
+        if (x_ok) {
+          const unsigned short* src = a.x + n * a.x_sn + (long long)(2 * iy) * a.x_sh + (long long)(2 * ix) * a.x_sw + ci0 + chunk * 8;
+          const float* sc = sc_s + chunk * 8;
+          const float* sh = sh_s + chunk * 8;
+          f32x8 f = fd_affine_act(*reinterpret_cast<const u32x4*>(src), sc, sh, a.p_slope);
+          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sw), sc, sh, a.p_slope);
+          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh), sc, sh, a.p_slope);
+          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw), sc, sh, a.p_slope);
+          xv = fd_pack8(f * 0.25f);
+        }
+      } else if (x_ok && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) {
         xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci0 + chunk * 8);
         if (a.pro_mode != 0) xv = fd_xform8(xv, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);   // zero padding stays zero
       }
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
   // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
   const int kk = a.ks * a.ks;
+  float* dwp = a.dw + (long long)split * a.Cout * a.Cin * kk;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco + i * 16 + g * 4 + r, ci = ci0 + wci + j * 16 + m;
-        if (co < a.Cout && ci < a.Cin) a.dw[((long long)co * a.Cin + ci) * kk + tap] = acc[i][j][r];
+        if (co < a.Cout && ci < a.Cin) dwp[((long long)co * a.Cin + ci) * kk + tap] = acc[i][j][r];
       }
   if (want_bias) {
     __syncthreads();
@@ -139,9 +156,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     if (tid < 64 && co0 + tid < a.Cout) {
       float t = 0.f;
       for (int q = 0; q < 32; ++q) t += bsum[q][tid];
-      a.dbias[co0 + tid] = t;
+      a.dbias[(long long)split * a.Cout + co0 + tid] = t;
     }
   }
+}
+
+// partial weight gradients [nsplit][numel] -> out[numel] (+= when accumulate), summed in split order
+struct WredArgs {
+  const float* part;
+  float* out;
+  long long numel;
+  int nsplit, accumulate;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.numel) return;
+  float t = 0.f;
+  for (int s_ = 0; s_ < a.nsplit; ++s_) t += a.part[(long long)s_ * a.numel + i];
+  a.out[i] = a.accumulate ? a.out[i] + t : t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,20 +370,79 @@ __global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
   a.dx[u] = s;
 }
 
-// sigmoid epilogue backward: g[n][h][w][0] (NHWC bf16, 1 channel stored in an 8-channel-padded view)
-// = dout * s * (1 - s) from NCHW fp32 (C == 1) tensors
-struct SigBwdArgs {
+// output-activation backward: g[n][y][x][c] (NHWC bf16) = dout[n][c][y][x] * f'(out) from NCHW fp32 tensors
+// (the sigmoid map D returns, the tanh image FDGAN returns); channels c >= C of the view are zeroed.
+struct OutActBwdArgs {
   const float *dout, *out;
   unsigned short* g;
-  long long total;
-  int gpitch;
+  long long g_sn;
+  int g_sh, g_sw;
+  int N, C, H, W, act, C8;
 };
-__global__ void sigmoid_bwd_kernel(SigBwdArgs a) {
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= a.total) return;
-  const float s = a.out[u], v = a.dout[u] * s * (1.f - s);
-  f32x8 o = {v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  *reinterpret_cast<u32x4*>(a.g + u * a.gpitch) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+__global__ __launch_bounds__(256) void out_act_bwd_kernel(OutActBwdArgs a) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.N * a.H * a.W * a.C8;
+  if (u >= total) return;
+  const int c8 = (int)(u % a.C8);
+  long long r = u / a.C8;
+  const int x = (int)(r % a.W);
+  r /= a.W;
+  const int y = (int)(r % a.H), n = (int)(r / a.H);
+  f32x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    float v = 0.f;
+    if (c < a.C) {
+      const long long i = (((long long)n * a.C + c) * a.H + y) * a.W + x;
+      const float t = a.out[i];
+      v = a.dout[i] * (a.act == FD_ACT_SIGMOID ? t * (1.f - t) : (a.act == FD_ACT_TANH ? 1.f - t * t : 1.f));
+    }
+    o[e] = v;
+  }
+  *reinterpret_cast<u32x4*>(a.g + (long long)n * a.g_sn + (long long)y * a.g_sh + (long long)x * a.g_sw + c8 * 8) =
+      __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+}
+
+// elementwise gradient plumbing on NHWC bf16 views (one thread per pixel x 8-channel group of dst):
+//   mode 0  dst += src                                   (a tensor with several consumers; torch.cat / copies)
+//   mode 1  dst  = 0.25 * src[y/2][x/2]                  (backward of the 2x2 average pool in a prologue)
+//   mode 2  dst  = sum of the 2x2 block of src           (backward of the nearest x2 upsample epilogue)
+//   mode 3  dst  = src where ref > 0, else 0             (ReLU epilogue, ref = the stored post-activation output)
+struct GradEwArgs {
+  const unsigned short *src, *ref;
+  unsigned short* dst;
+  long long s_sn, r_sn, d_sn;
+  int s_sh, s_sw, r_sh, r_sw, d_sh, d_sw;
+  int N, H, W, C8, mode;   // H, W: dst size
+};
+__global__ __launch_bounds__(256) void grad_ew_kernel(GradEwArgs a) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= (long long)a.N * a.H * a.W * a.C8) return;
+  const int c8 = (int)(u % a.C8);
+  long long r = u / a.C8;
+  const int x = (int)(r % a.W);
+  r /= a.W;
+  const int y = (int)(r % a.H), n = (int)(r / a.H);
+  auto ld = [&](const unsigned short* base, long long sn, int sh, int sw, int yy, int xx) {
+    return __builtin_convertvector(
+        __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + n * sn + (long long)yy * sh + (long long)xx * sw + c8 * 8)), f32x8);
+  };
+  unsigned short* dp = a.dst + n * a.d_sn + (long long)y * a.d_sh + (long long)x * a.d_sw + c8 * 8;
+  f32x8 o;
+  if (a.mode == 0) {
+    o = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dp)), f32x8) + ld(a.src, a.s_sn, a.s_sh, a.s_sw, y, x);
+  } else if (a.mode == 1) {
+    o = ld(a.src, a.s_sn, a.s_sh, a.s_sw, y >> 1, x >> 1) * 0.25f;
+  } else if (a.mode == 2) {
+    o = (ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y, 2 * x) + ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y, 2 * x + 1)) +
+        (ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y + 1, 2 * x) + ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y + 1, 2 * x + 1));
+  } else {
+    const f32x8 s_ = ld(a.src, a.s_sn, a.s_sh, a.s_sw, y, x), rf = ld(a.ref, a.r_sn, a.r_sh, a.r_sw, y, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rf[e] > 0.f ? s_[e] : 0.f;
+  }
+  *reinterpret_cast<u32x4*>(dp) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
 }
 
 int check_view(const FdTensor* t, const char* what) {
@@ -375,15 +466,18 @@ void fill_pro(const FdPrologue* pro, int& mode, float& slope, float& eps, const 
 }  // namespace
 
 extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
-                                       float* dw, float* dbias, FdStream stream) {
+                                       float* dw, float* dbias, float* workspace, int64_t workspace_floats,
+                                       int accumulate, FdStream stream) {
   if (int rc = check_view(x, "conv2d_bwd_weight(x)")) return rc;
   if (int rc = check_view(dy, "conv2d_bwd_weight(dy)")) return rc;
   FD_REQUIRE(d && dw, "conv2d_bwd_weight: NULL descriptor / dw");
-  FD_REQUIRE(!(pro && pro->pool2), "conv2d_bwd_weight: pooled prologue not supported yet");
-  FD_REQUIRE(!d->upsample2, "conv2d_bwd_weight: upsampled output not supported yet");
+  FD_REQUIRE(!d->upsample2, "conv2d_bwd_weight: pass the gradient of the PRE-upsample output (fdgan_grad_ew mode 2)");
   FD_REQUIRE(pro == nullptr || pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU || pro->act == FD_ACT_LEAKY02,
              "conv2d_bwd_weight: prologue activation %d", pro ? pro->act : 0);
-  const long long ho = (x->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (x->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  const bool pool = pro && pro->pool2;
+  FD_REQUIRE(!pool || (d->ksize == 1 && d->stride == 1 && d->pad == 0), "conv2d_bwd_weight: pooled prologue needs a 1x1 conv");
+  const long long hin = pool ? x->h / 2 : x->h, win = pool ? x->w / 2 : x->w;
+  const long long ho = (hin + 2 * d->pad - d->ksize) / d->stride + 1, wo = (win + 2 * d->pad - d->ksize) / d->stride + 1;
   FD_REQUIRE(dy->n == x->n && dy->h == ho && dy->w == wo, "conv2d_bwd_weight: dy is %lldx%lld, expected %lldx%lld",
              (long long)dy->h, (long long)dy->w, ho, wo);
   const int cout = d->cout ? d->cout : (int)dy->c;
@@ -397,11 +491,37 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   FD_REQUIRE(a.Cout8 * 8 <= dy->stride[2] && a.Cin8 * 8 <= x->stride[2], "conv2d_bwd_weight: channel padding exceeds the pixel pitch");
   a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
   a.P = (long long)x->n * ho * wo;
+  a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
-  a.dw = dw;
-  a.dbias = dbias;
-  dim3 grid((unsigned)((a.Cin + 63) / 64), (unsigned)((cout + 63) / 64), (unsigned)(d->ksize * d->ksize));
-  return fd_launch(&conv_wgrad_kernel, "conv_wgrad", grid, dim3(256), 0, a, static_cast<hipStream_t>(stream));
+  if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
+  const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
+  const long long base = (long long)((a.Cin + 63) / 64) * ((cout + 63) / 64) * d->ksize * d->ksize;
+  // split the pixel axis until ~768 workgroups exist (one pass over all pixels per workgroup otherwise)
+  long long nsplit = 1;
+  if (workspace != nullptr) {
+    nsplit = 768 / base;
+    const long long max_by_px = (a.P + 2047) / 2048;
+    if (nsplit > max_by_px) nsplit = max_by_px;
+    const long long per = numel + (dbias ? cout : 0);
+    if (nsplit * per > workspace_floats) nsplit = workspace_floats / per;
+    if (nsplit < 1) nsplit = 1;
+  }
+  FD_REQUIRE(workspace != nullptr || !accumulate, "conv2d_bwd_weight: accumulate needs a workspace");
+  const bool direct = workspace == nullptr;
+  FD_REQUIRE(direct || numel + (dbias ? cout : 0) <= workspace_floats, "conv2d_bwd_weight: workspace too small (%lld floats)", numel + cout);
+  a.nsplit = (int)nsplit;
+  a.split_px = ((a.P + nsplit - 1) / nsplit + 31) / 32 * 32;
+  a.dw = direct ? dw : workspace;
+  a.dbias = dbias ? (direct ? dbias : workspace + nsplit * numel) : nullptr;
+  dim3 grid((unsigned)((a.Cin + 63) / 64), (unsigned)((cout + 63) / 64), (unsigned)(d->ksize * d->ksize * nsplit));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = fd_launch(&conv_wgrad_kernel, "conv_wgrad", grid, dim3(256), 0, a, st);
+  if (rc != FD_OK || direct) return rc;
+  WredArgs r{workspace, dw, numel, (int)nsplit, accumulate};
+  rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, r, st);
+  if (rc != FD_OK || !dbias) return rc;
+  WredArgs rb{workspace + nsplit * numel, dbias, cout, (int)nsplit, accumulate};
+  return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, rb, st);
 }
 
 extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
@@ -479,11 +599,39 @@ extern "C" int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, 
                    static_cast<hipStream_t>(stream));
 }
 
-extern "C" int fdgan_sigmoid_bwd(const float* dout, const float* out, int64_t count, const FdTensor* g, FdStream stream) {
-  if (int rc = check_view(g, "sigmoid_bwd(g)")) return rc;
-  FD_REQUIRE(dout && out && g->n * g->h * g->w == count && g->stride[1] == g->w * g->stride[2] && g->stride[0] == g->h * g->stride[1],
-             "sigmoid_bwd: g must be a dense NHWC view of `count` pixels");
-  SigBwdArgs a{dout, out, static_cast<unsigned short*>(g->ptr), count, (int)g->stride[2]};
-  return fd_launch(&sigmoid_bwd_kernel, "sigmoid_bwd", dim3((unsigned)((count + 255) / 256)), dim3(256), 0, a,
+extern "C" int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n, int64_t c, int64_t h, int64_t w, int act,
+                                 const FdTensor* g, FdStream stream) {
+  if (int rc = check_view(g, "out_act_bwd(g)")) return rc;
+  FD_REQUIRE(dout && out && g->n == n && g->h == h && g->w == w && g->c >= c, "out_act_bwd: shape mismatch");
+  FD_REQUIRE(act == FD_ACT_SIGMOID || act == FD_ACT_TANH || act == FD_ACT_NONE, "out_act_bwd: activation %d", act);
+  OutActBwdArgs a{dout, out, static_cast<unsigned short*>(g->ptr), g->stride[0], (int)g->stride[1], (int)g->stride[2],
+                  (int)n, (int)c, (int)h, (int)w, act, (int)((g->c + 7) / 8)};
+  const long long total = n * h * w * a.C8;
+  return fd_launch(&out_act_bwd_kernel, "out_act_bwd", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream) {
+  if (int rc = check_view(src, "grad_ew(src)")) return rc;
+  if (int rc = check_view(dst, "grad_ew(dst)")) return rc;
+  FD_REQUIRE(mode >= 0 && mode <= 3, "grad_ew: mode %d", mode);
+  FD_REQUIRE(src->n == dst->n && src->c == dst->c, "grad_ew: batch / channel mismatch");
+  if (mode == 0 || mode == 3) FD_REQUIRE(src->h == dst->h && src->w == dst->w, "grad_ew: shape mismatch");
+  if (mode == 1) FD_REQUIRE(src->h == dst->h / 2 && src->w == dst->w / 2, "grad_ew(unpool): src must be half of dst");
+  if (mode == 2) FD_REQUIRE(src->h == dst->h * 2 && src->w == dst->w * 2, "grad_ew(sum-pool): src must be twice dst");
+  GradEwArgs a{};
+  a.src = static_cast<const unsigned short*>(src->ptr);
+  a.s_sn = src->stride[0], a.s_sh = (int)src->stride[1], a.s_sw = (int)src->stride[2];
+  if (mode == 3) {
+    if (int rc = check_view(ref, "grad_ew(ref)")) return rc;
+    FD_REQUIRE(ref->n == dst->n && ref->h == dst->h && ref->w == dst->w && ref->c == dst->c, "grad_ew: ref shape mismatch");
+    a.ref = static_cast<const unsigned short*>(ref->ptr);
+    a.r_sn = ref->stride[0], a.r_sh = (int)ref->stride[1], a.r_sw = (int)ref->stride[2];
+  }
+  a.dst = static_cast<unsigned short*>(dst->ptr);
+  a.d_sn = dst->stride[0], a.d_sh = (int)dst->stride[1], a.d_sw = (int)dst->stride[2];
+  a.N = (int)dst->n, a.H = (int)dst->h, a.W = (int)dst->w, a.C8 = (int)((dst->c + 7) / 8), a.mode = mode;
+  const long long total = (long long)a.N * a.H * a.W * a.C8;
+  return fd_launch(&grad_ew_kernel, "grad_ew", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }

@@ -240,11 +240,13 @@ class Plan:
 
 
 # ---- backward ------------------------------------------------------------------------------------
-def conv_bwd_weight(x_fd, pro, dy_fd, desc, dw, dbias=None):
-    """dw: fp32 tensor shaped like the Conv2d weight (cout, cin, k, k); dbias: fp32 (cout,) or None."""
+def conv_bwd_weight(x_fd, pro, dy_fd, desc, dw, dbias=None, ws=None, accumulate=False):
+    """dw: fp32 tensor shaped like the Conv2d weight (cout, cin, k, k); dbias: fp32 (cout,) or None;
+    ws: fp32 workspace for the split-K partials (None: one pass over all pixels per workgroup)."""
     L.check(L.load().fdgan_conv2d_bwd_weight(C.byref(x_fd), C.byref(pro) if pro is not None else None, C.byref(dy_fd),
                                              C.byref(desc), dw.data_ptr(), dbias.data_ptr() if dbias is not None else None,
-                                             stream_ptr()), "conv2d_bwd_weight")
+                                             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                             int(bool(accumulate)), stream_ptr()), "conv2d_bwd_weight")
 
 
 def bn_act_bwd(da_fd, x_fd, pro, ws=None):
@@ -274,6 +276,16 @@ def conv_bwd_data_direct(dy_fd, weight, desc, dx):
                                                   dx.data_ptr(), n, h, w, stream_ptr()), "conv2d_bwd_data_direct")
 
 
-def sigmoid_bwd(dout, out, g_view):
-    L.check(L.load().fdgan_sigmoid_bwd(dout.data_ptr(), out.data_ptr(), out.numel(), C.byref(g_view.fd), stream_ptr()),
-            "sigmoid_bwd")
+def out_act_bwd(dout, out, act, g_view):
+    """g_view (NHWC bf16) <- dout * f'(out) for contiguous NCHW fp32 dout / out."""
+    n, c, h, w = out.shape
+    L.check(L.load().fdgan_out_act_bwd(dout.data_ptr(), out.data_ptr(), n, c, h, w, act, C.byref(g_view.fd), stream_ptr()),
+            "out_act_bwd")
+
+
+GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK = 0, 1, 2, 3
+
+
+def grad_ew(mode, src, dst, ref=None):
+    L.check(L.load().fdgan_grad_ew(mode, C.byref(src.fd), C.byref(ref.fd) if ref is not None else None, C.byref(dst.fd),
+                                   stream_ptr()), "grad_ew")

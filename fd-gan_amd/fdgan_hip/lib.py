@@ -86,7 +86,8 @@ SIGNATURES = {
     "fdgan_fusion_input_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(FdTensor),
                                           C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_weight": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor),
-                                          C.POINTER(FdConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.POINTER(FdConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                          C.c_void_p]),
     "fdgan_bn_act_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.c_void_p, C.c_int64,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
@@ -95,7 +96,9 @@ SIGNATURES = {
                                      C.c_void_p, C.POINTER(FdTensor), C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_data_direct": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_int, C.c_int, C.POINTER(FdConvDesc),
                                                C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
-    "fdgan_sigmoid_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_out_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                    C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_grad_ew": (C.c_int, [C.c_int, C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
 }
 
 _lib = None

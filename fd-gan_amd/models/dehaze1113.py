@@ -426,7 +426,7 @@ class D(_PlannedModule):
             keep.append(pw)
             E.conv2d(dy_view.fd, pw, None, None, dx_view.fd, E.conv_desc(k, 1, k - 1 - pad, cout=cin_f, w_layout=CH))
 
-        E.sigmoid_bwd(dout.detach().float().contiguous(), out, E.View(g5))
+        E.out_act_bwd(dout.detach().float().contiguous(), out, L.ACT_SIGMOID, E.View(g5))
         # layer5: x = a4, LeakyReLU prologue, 4x4 s1 p1 -> 1 channel
         E.conv_bwd_weight(E.View(a4, 0, 8 * nf).fd, lrelu, E.View(g5, 0, 1).fd, E.conv_desc(4, 1, 1, cout=1), grads[id(W5)])
         dgrad(E.View(g5, 0, 1), W5, 1, 8 * nf, 4, 1, E.View(d4))

@@ -216,9 +216,17 @@ int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
  *  prologue         fdgan_bn_act_bwd:  dpre = da * act'(bn(x)) in place, plus rows x cpad x {sum dpre,
  *                   sum dpre*xhat} partials when the prologue has a norm -> fdgan_bn_bwd_finalize -> (dgamma,
  *                   dbeta); fdgan_bn_bwd_apply: dx = gamma*rstd * (dpre - dbeta/M - xhat*dgamma/M).
- *  sigmoid          fdgan_sigmoid_bwd: g = dout * s * (1 - s) for the 1-channel NCHW fp32 map D returns. */
+ *                   With a workspace the pixel axis is split over workgroups and the partials are summed in a
+ *                   fixed order (deterministic); `accumulate` adds into dw / dbias (parameters used twice).
+ *                   A pooled prologue (pool2) is honoured; for an upsampled output pass the 2x2-summed gradient.
+ *  output act       fdgan_out_act_bwd: g (NHWC bf16) = dout * f'(out) for the NCHW fp32 tensors the networks
+ *                   return (sigmoid map of D: s(1-s); tanh image of FDGAN: 1-t^2).
+ *  plumbing         fdgan_grad_ew: 0 dst += src (several consumers of one tensor, torch.cat), 1 dst = src[y/2][x/2]/4
+ *                   (prologue avg-pool), 2 dst = 2x2 sum of src (nearest-upsample epilogue), 3 dst = src * (ref > 0)
+ *                   (ReLU epilogue, ref = the stored output). */
 int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
-                            float* dw, float* dbias, FdStream stream);
+                            float* dw, float* dbias, float* workspace, int64_t workspace_floats, int accumulate,
+                            FdStream stream);
 int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
                      int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
 int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
@@ -227,7 +235,9 @@ int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
                                  float* dx, int64_t n, int64_t h, int64_t wd, FdStream stream);
-int fdgan_sigmoid_bwd(const float* dout, const float* out, int64_t count, const FdTensor* g, FdStream stream);
+int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n, int64_t c, int64_t h, int64_t w, int act,
+                      const FdTensor* g, FdStream stream);
+int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream);
 
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */

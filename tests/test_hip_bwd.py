@@ -144,3 +144,69 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     E.conv_bwd_data_direct(dyv.fd, wdev, E.conv_desc(k, s, pad, cout=cout), dx)
     torch.cuda.synchronize()
     assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5
+
+
+def test_weight_gradient_split_k_pool_and_accumulate(E):
+    """Split-K partials + fixed-order reduction, accumulation into an existing gradient, and the pooled
+    prologue (transition: BN + ReLU + 2x2 average in front of a 1x1 conv)."""
+    from fdgan_hip import lib as L
+    n, cin, cout, h, w = 4, 256, 128, 32, 48
+    x = bf16_round(seeded((n, cin, h, w), 21, -1.5, 1.5))
+    p = _bn_params(cin, 30)
+    keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
+    sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+    sh = (p["beta"] - p["mean"] * sc).float()
+    act = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ws = torch.zeros(1 << 22, dtype=torch.float32, device=DEV)
+    for pool in (False, True):
+        a = bf16_round(F.avg_pool2d(act, 2) if pool else act).double()
+        ho, wo = a.shape[2], a.shape[3]
+        dy = bf16_round(seeded((n, cout, ho, wo), 22, -1.0, 1.0))
+        wref = torch.zeros(cout, cin, 1, 1, dtype=torch.float64, requires_grad=True)
+        F.conv2d(a, wref).backward(dy.double())
+        pro = E.make_prologue(act=L.ACT_RELU, pool=pool, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+        xb, dyb = _nhwc(x), _nhwc(dy)
+        dw = torch.full((cout, cin, 1, 1), 1.0, dtype=torch.float32, device=DEV)
+        E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(1, 1, 0, cout=cout), dw, None, ws, True)
+        torch.cuda.synchronize()
+        assert rel_rms(dw.cpu().double() - 1.0, wref.grad) < 5e-3, pool          # accumulated onto the ones
+        dw2 = torch.empty_like(dw)
+        E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(1, 1, 0, cout=cout), dw2, None, ws, False)
+        dw3 = torch.empty_like(dw)
+        E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(1, 1, 0, cout=cout), dw3, None, ws, False)
+        torch.cuda.synchronize()
+        assert torch.equal(dw2, dw3)                                               # deterministic reduction
+
+
+def test_gradient_plumbing_kernels(E):
+    from fdgan_hip import lib as L
+    n, c, h, w = 2, 40, 6, 10
+    src = bf16_round(seeded((n, c, h, w), 31, -1, 1))
+    dst0 = bf16_round(seeded((n, c, h, w), 32, -1, 1))
+    sb, db = _nhwc(src, pitch=48), _nhwc(dst0, pitch=64)
+    E.grad_ew(E.GRAD_ADD, E.View(sb, 0, c), E.View(db, 0, c))
+    torch.cuda.synchronize()
+    assert rel_rms(_from_nhwc(db, c), bf16_round(src + dst0)) < 1e-6
+    big = E.new_act(n, 2 * h, 2 * w, 40, DEV, zero=True)
+    E.grad_ew(E.GRAD_UNPOOL, E.View(sb, 0, c), E.View(big, 0, c))
+    torch.cuda.synchronize()
+    assert rel_rms(_from_nhwc(big, c), bf16_round(F.interpolate(src, scale_factor=2, mode="nearest") * 0.25)) < 1e-6
+    small = E.new_act(n, h // 2, w // 2, 40, DEV, zero=True)
+    E.grad_ew(E.GRAD_SUMPOOL, E.View(sb, 0, c), E.View(small, 0, c))
+    torch.cuda.synchronize()
+    assert rel_rms(_from_nhwc(small, c), bf16_round(F.avg_pool2d(src, 2) * 4)) < 1e-6
+    refy = bf16_round(torch.relu(seeded((n, c, h, w), 33, -1, 1)))
+    rb, ob = _nhwc(refy), E.new_act(n, h, w, 40, DEV, zero=True)
+    E.grad_ew(E.GRAD_RELU_MASK, E.View(sb, 0, c), E.View(ob, 0, c), ref=E.View(rb, 0, c))
+    torch.cuda.synchronize()
+    assert rel_rms(_from_nhwc(ob, c), src * (refy > 0)) < 1e-6
+    # output activation backward: tanh image (3 channels) and sigmoid map (1 channel)
+    for cc, act, f in ((3, L.ACT_TANH, lambda t: 1 - t * t), (1, L.ACT_SIGMOID, lambda t: t * (1 - t))):
+        out = (seeded((n, cc, h, w), 34, -0.9, 0.9) if act == L.ACT_TANH else seeded((n, cc, h, w), 34, 0.05, 0.95))
+        dout = seeded((n, cc, h, w), 35, -1, 1)
+        g = E.new_act(n, h, w, 8, DEV)
+        od, dd = out.to(DEV).contiguous(), dout.to(DEV).contiguous()
+        E.out_act_bwd(dd, od, act, E.View(g))
+        torch.cuda.synchronize()
+        assert rel_rms(_from_nhwc(g, cc), bf16_round(dout * f(out))) < 1e-6
+        assert float(g[..., cc:].float().abs().max()) == 0.0
