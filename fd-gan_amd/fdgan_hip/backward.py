@@ -1,0 +1,215 @@
+"""Reverse-mode execution of a recorded NetPlan (train-mode BatchNorm), on the HIP backward entry points.
+
+Forward ops are fused convolutions on channel-slice views of shared buffers (torch.cat never exists), so the
+backward is not an autograd graph over tensors but a walk over the plan's op records in reverse:
+
+    y = act_e(conv(pool?(act_p(bn?(x))), W) + b) [nearest x2]
+
+      dy    = G[y]                      (2x2-summed for an upsampled output, masked for a ReLU epilogue)
+      dW,db += wgrad(x, prologue, dy)   (`a` recomputed from the raw x and the forward batch statistics)
+      da    = conv(dy, flip(W))         (the data gradient is a forward convolution, pad' = k-1-pad)
+      G[x] += prologue_backward(da)     (un-pool, activation mask, BatchNorm backward with its two reductions)
+
+G[.] is a gradient buffer mirroring every activation buffer (same NHWC bf16 layout, same views), zeroed
+per backward; a tensor with several consumers -- the prefix of a dense block's concat buffer is read by
+every later layer -- simply accumulates.  Buffers that the forward overwrites (the shared 128-channel
+bottleneck of a dense block, reused by every layer) are recomputed from their producer right before the
+consumer's backward needs them: one extra 1x1 forward per dense layer instead of 58 kept activations.
+
+Reference semantics: torch.autograd over /root/reference/models/dehaze1113.py:703-801 (FDGAN), :256-275,
+:358-370 (dy blocks).
+"""
+import torch
+
+from . import engine as E
+from . import lib as L
+
+
+
+def _r8(v):
+    return (v + 7) // 8 * 8
+
+
+def _op_reference(r, dy_view, meta):
+    """The single fused op under torch autograd on the SAME device tensors (fp32 math, operands rounded to
+    bf16 where the kernels round them): returns (dW reference, dx reference).  Verification aid."""
+    import torch.nn.functional as F
+    x, w, k, pad = r["x"], r["w"], r["k"], r["pad"]
+    st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+    with torch.enable_grad():            # this runs inside an autograd.Function's backward
+        xr = x.torch_nchw().requires_grad_(True)
+        a = xr
+        if meta.get("bn") is not None:
+            a = F.batch_norm(a, None, None, meta["gamma"].detach(), meta["beta"].detach(), True, 0.0, meta["eps"])
+        if meta["act"] == L.ACT_RELU:
+            a = torch.relu(a)
+        elif meta["act"] == L.ACT_LEAKY02:
+            a = F.leaky_relu(a, 0.2)
+        if meta["pool"]:
+            a = F.avg_pool2d(a, 2)
+        a = st(a)
+        p = w.param.detach()
+        wt = (p.permute(1, 0, 2, 3) if w.transposed else p).to(torch.bfloat16).float().requires_grad_(True)
+        y = F.conv2d(a, wt, None, r["stride"], pad)
+        y.backward(dy_view.torch_nchw()[:, :w.cout])
+    return wt.grad, xr.grad
+
+
+def _region(view):
+    return view.buf.data_ptr(), view.c0, view.c0 + view.c
+
+
+def _overlap(a, b):
+    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+
+class PlanBackward:
+    def __init__(self, plan):
+        self.plan = plan
+        self.recs = plan.records
+        self.gbuf = {}          # activation buffer data_ptr -> gradient buffer
+        for r in self.recs:
+            for key in ("x", "y", "src", "dst"):
+                v = r.get(key)
+                if v is not None and v.buf.data_ptr() not in self.gbuf:
+                    self.gbuf[v.buf.data_ptr()] = torch.zeros_like(v.buf)
+        # recomputation: op i's input was produced by op j and overwritten afterwards
+        self.recompute = {}
+        self.multi_version = set()
+        for i, r in enumerate(self.recs):
+            if r["kind"] != "conv":
+                continue
+            rx = _region(r["x"])
+            prod = None
+            for j in range(i - 1, -1, -1):
+                rj = self.recs[j]
+                out = rj.get("y") if rj["kind"] == "conv" else rj.get("dst")
+                if out is not None and _overlap(_region(out), rx):
+                    prod = j
+                    break
+            if prod is None:
+                continue
+            for k in range(i + 1, len(self.recs)):
+                rk = self.recs[k]
+                out = rk.get("y") if rk["kind"] == "conv" else rk.get("dst")
+                if out is not None and _overlap(_region(out), rx):
+                    self.recompute[i] = prod
+                    self.multi_version.add(rx[0])
+                    break
+        dev = plan.device
+        self.ws = torch.empty(1 << 24, dtype=torch.float32, device=dev)      # split-K partials (64 MiB)
+        self.ws_bn = torch.empty(512 * 1024 * 2, dtype=torch.float32, device=dev)
+        self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
+
+    def G(self, view):
+        return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
+
+    def zero_(self):
+        for g in self.gbuf.values():
+            g.zero_()
+
+    # ---- one fused convolution ---------------------------------------------------------------
+    def conv_backward(self, r, dy_view, grads, need_dx=True):
+        """dy_view: gradient of the op's stored output (already sum-pooled / masked by the caller if needed)."""
+        x, w, k, pad, pro = r["x"], r["w"], r["k"], r["pad"], r["pro"]
+        meta = pro._meta if pro is not None else dict(act=L.ACT_NONE, pool=False, bn=None)
+        if r["stride"] != 1 and need_dx:
+            raise NotImplementedError("data gradient of a strided conv inside a plan")
+        desc = E.conv_desc(k, r["stride"], pad, cout=w.cout)
+        # ---- parameters
+        p = w.param
+        if p.requires_grad:
+            if w.transposed:                      # ConvTranspose2d 1x1: weight is (cin, cout, 1, 1)
+                tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
+                E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
+                grads[p] = grads.get(p, 0) + tmp.permute(1, 0, 2, 3)
+            else:
+                if p not in grads:
+                    grads[p] = torch.zeros_like(p)
+                db = None
+                if r["bias"] is not None and r["bias"].requires_grad:
+                    if r["bias"] not in grads:
+                        grads[r["bias"]] = torch.zeros_like(r["bias"])
+                    db = grads[r["bias"]]
+                E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grads[p], db, self.ws, True)
+        check = self.checks is not None
+        if check:
+            dw_ref, dx_ref = _op_reference(r, dy_view, meta)
+            tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
+            E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
+            gx_before = self.G(x).torch_nchw() if need_dx else None
+            rec = dict(label="%dx%d %d->%d @%dx%d%s%s" % (k, k, w.cin, w.cout, dy_view.shape[1], dy_view.shape[2],
+                                                       " pool" if meta["pool"] else "", " bn" if meta.get("bn") is not None else ""),
+                       dw=float((tmp - dw_ref).norm() / (dw_ref.norm() + 1e-30)))
+        if not need_dx:
+            if check:
+                self.checks.append(rec)
+            return
+        # ---- data gradient: forward conv of dy with the flipped filter, at the conv-input resolution
+        n, hy, wy, _ = dy_view.shape
+        hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
+        cin = w.cin
+        T = E.new_act(n, hin, win, _r8(cin), p.device)
+        # the forward filter tensor in OIHW terms: ConvTranspose2d stores (cin, cout): already the transposed one
+        if w.transposed:
+            pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=False, layout=L.WLAYOUT_CHUNK32)
+        else:
+            pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=True, layout=L.WLAYOUT_CHUNK32)
+        pw.pack()
+        E.conv2d(dy_view.fd, pw, None, None, E.View(T).fd, E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32))
+        Tv = E.View(T, 0, cin)
+        if meta["pool"]:
+            T2 = E.new_act(n, 2 * hin, 2 * win, _r8(cin), p.device)
+            E.grad_ew(E.GRAD_UNPOOL, Tv, E.View(T2, 0, cin))
+            T, Tv = T2, E.View(T2, 0, cin)
+        gx = self.G(x)
+        bn = meta.get("bn")
+        if bn is not None:
+            if not meta.get("batch_stats", False):
+                raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
+            act_pro = E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
+                                      beta=meta["beta"], eps=meta["eps"])
+            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
+            dg = torch.empty(cin, dtype=torch.float32, device=p.device)
+            dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
+            E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt)
+            E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
+            if bn.weight is not None and bn.weight.requires_grad:
+                grads[bn.weight] = grads.get(bn.weight, 0) + dg
+                grads[bn.bias] = grads.get(bn.bias, 0) + dbt
+        else:
+            if meta["act"] != L.ACT_NONE:
+                E.bn_act_bwd(Tv.fd, x.fd, E.make_prologue(act=meta["act"]))
+            E.grad_ew(E.GRAD_ADD, Tv, gx)
+        if check:
+            added = self.G(x).torch_nchw() - gx_before
+            rec["dx"] = float((added - dx_ref).norm() / (dx_ref.norm() + 1e-30))
+            rec["dx_scale"] = float(dx_ref.abs().mean() / (gx_before.abs().mean() + 1e-30))
+            self.checks.append(rec)
+
+    # ---- the whole plan ------------------------------------------------------------------------
+    def run(self, grads, skip_dx_of=()):
+        """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's
+        outputs.  `grads`: dict parameter -> fp32 gradient, filled / accumulated."""
+        for i in range(len(self.recs) - 1, -1, -1):
+            r = self.recs[i]
+            if r["kind"] == "copy":
+                E.grad_ew(E.GRAD_ADD, self.G(r["dst"]), self.G(r["src"]))
+                continue
+            if i in self.recompute:
+                self.recs[self.recompute[i]]["rerun"]()
+            y = r["y"]
+            gy = self.G(y)
+            dyv = gy
+            if r["upsample"]:
+                n, h2, w2, _ = y.shape
+                t = E.new_act(n, h2 // 2, w2 // 2, _r8(y.c), y.buf.device)
+                dyv = E.View(t, 0, y.c)
+                E.grad_ew(E.GRAD_SUMPOOL, gy, dyv)
+            if r["e_act"] == L.ACT_RELU:
+                E.grad_ew(E.GRAD_RELU_MASK, dyv, dyv, ref=y)
+            elif r["e_act"] != L.ACT_NONE:
+                raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
+            self.conv_backward(r, dyv, grads, need_dx=(id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of))
+            if y.buf.data_ptr() in self.multi_version:
+                self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer writes a fresh gradient here

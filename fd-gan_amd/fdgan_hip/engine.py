@@ -98,7 +98,20 @@ def make_prologue(act=L.ACT_NONE, pool=False, mean=None, var=None, gamma=None, b
     p.running_var = running_var.data_ptr() if running_var is not None else None
     p.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
     p.count = count
+    # host-side description (also keeps the tensors behind the raw pointers alive): used by the backward pass
+    p._meta = dict(act=act, pool=bool(pool), mean=mean, var=var, gamma=gamma, beta=beta, eps=eps, bn=None, stats=None)
     return p
+
+
+def prologue_without_side_effects(pro):
+    """Same input-side fusion, but no running-statistics update: for recomputation and backward."""
+    if pro is None:
+        return None
+    m = pro._meta
+    q = make_prologue(act=m["act"], pool=m["pool"], mean=m["mean"], var=m["var"], gamma=m["gamma"], beta=m["beta"],
+                      eps=m["eps"])
+    q._meta.update(bn=m["bn"], stats=m["stats"], batch_stats=m.get("batch_stats", False))
+    return q
 
 
 def conv_desc(k, stride=1, pad=0, e_act=L.ACT_NONE, upsample=False, cout=0, w_layout=L.WLAYOUT_CHUNK32):

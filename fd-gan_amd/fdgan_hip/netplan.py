@@ -36,6 +36,7 @@ class NetPlan:
         self.packp = None
         self.keep = []             # anything that must outlive the plan
         self._param_versions = None
+        self.records = []          # per op, in forward order: what the backward pass needs (fdgan_hip/backward.py)
 
     # ---- registration -----------------------------------------------------------
     def weight(self, param, cout, cin, k, transposed=False, stride=1):
@@ -47,13 +48,17 @@ class NetPlan:
         """Prologue of a conv whose input passes through BatchNorm `bn` (+activation)."""
         if bn.training or not bn.track_running_stats:
             assert src_stats is not None
-            return E.make_prologue(act=act, pool=pool, mean=src_stats.mean, var=src_stats.var, gamma=bn.weight,
-                                   beta=bn.bias, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1,
-                                   running_mean=bn.running_mean if bn.track_running_stats else None,
-                                   running_var=bn.running_var if bn.track_running_stats else None,
-                                   nbt=bn.num_batches_tracked if bn.track_running_stats else None, count=count)
-        return E.make_prologue(act=act, pool=pool, mean=bn.running_mean, var=bn.running_var, gamma=bn.weight,
-                               beta=bn.bias, eps=bn.eps)
+            p = E.make_prologue(act=act, pool=pool, mean=src_stats.mean, var=src_stats.var, gamma=bn.weight,
+                                beta=bn.bias, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                running_mean=bn.running_mean if bn.track_running_stats else None,
+                                running_var=bn.running_var if bn.track_running_stats else None,
+                                nbt=bn.num_batches_tracked if bn.track_running_stats else None, count=count)
+            p._meta.update(bn=bn, stats=src_stats, batch_stats=True)
+            return p
+        p = E.make_prologue(act=act, pool=pool, mean=bn.running_mean, var=bn.running_var, gamma=bn.weight,
+                            beta=bn.bias, eps=bn.eps)
+        p._meta.update(bn=bn, stats=None, batch_stats=False)
+        return p
 
     def conv(self, x, w, y, k, pad=0, stride=1, bias=None, pro=None, e_act=L.ACT_NONE, upsample=False,
              stats=None, stats_c0=0, y_fd=None, label=None):
@@ -73,6 +78,15 @@ class NetPlan:
             E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None)
             if stats is not None:
                 E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
+
+        pro_nofx = E.prologue_without_side_effects(pro)
+
+        def rerun():   # the same launch without BatchNorm's running-statistics side effects (recomputation)
+            E.conv2d(x.fd, w, bias, pro_nofx, yfd, desc, self.ws if stats is not None else None)
+            if stats is not None:
+                E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
+        self.records.append(dict(kind="conv", x=x, w=w, y=y if y_fd is None else None, k=k, pad=pad, stride=stride, bias=bias,
+                                 pro=pro_nofx, e_act=e_act, upsample=bool(upsample), rerun=rerun))
         # algorithmic work of this launch: every conv reads its input once and
         # writes its output once; MACs counted on the reference's formulation (conv before pool)
         up = 2 if upsample else 1
@@ -91,6 +105,7 @@ class NetPlan:
         self._ops.append((lambda: E.copy_nhwc(src, dst), 0, dict(label="copy", flops=0.0, flops_done=0.0,
                                                                    bytes=4 * src.fd.n * src.fd.h * src.fd.w * src.c)))
         self.keep += [src, dst]
+        self.records.append(dict(kind="copy", src=src, dst=dst))
 
     def op(self, fn):
         self._ops.append((fn, 0, dict(label="op", flops=0.0, flops_done=0.0, bytes=0)))

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
+from fdgan_hip.backward import PlanBackward
 from fdgan_hip.netplan import ChanStats, NetPlan, bn_flags
 
 from . import tv_densenet121 as _tv
@@ -53,6 +54,37 @@ class _PlannedModule(nn.Module):
 # ---------------------------------------------------------------------------------------
 # decoder blocks
 # ---------------------------------------------------------------------------------------
+class _PlanFunction(torch.autograd.Function):
+    """autograd bridge of a planned module: forward = the recorded HIP plan, backward = the plan walked in
+    reverse (fdgan_hip/backward.py).  Parameters are passed as inputs so autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        out, state = module._autograd_forward(x)
+        ctx.module, ctx.state, ctx.params = module, state, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, grads = ctx.module._autograd_backward(ctx.state, dout.detach().float().contiguous())
+        return (None, dx) + tuple(grads.get(p) for p in ctx.params)
+
+
+def _wants_grad(module, x):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+def _apply_plan_function(module, x):
+    params = tuple(p for p in module.parameters() if p.requires_grad)
+    return _PlanFunction.apply(module, x, *params)
+
+
+def _plan_backward(P):
+    if getattr(P, "_bwd", None) is None:
+        P._bwd = PlanBackward(P)
+    return P._bwd
+
+
 class BottleneckBlockdy(_PlannedModule):
     """dehaze1113.py:256-275.  cat([relu(x), conv2(relu(conv1(relu(x))))], 1); the
     reference's in-place ReLU also overwrites the caller's `x`, reproduced here.
@@ -91,6 +123,10 @@ class BottleneckBlockdy(_PlannedModule):
         return P.finish()
 
     def forward(self, x):
+        if _wants_grad(self, x):
+            if not x.requires_grad:
+                x.relu_()                                           # reference aliasing (:261) for plain data
+            return _apply_plan_function(self, x)
         P = self._plan_for(x)
         with torch.no_grad():
             x.relu_()                                               # reference aliasing (:261)
@@ -100,6 +136,30 @@ class BottleneckBlockdy(_PlannedModule):
                               dtype=torch.float32, device=x.device)
             E.to_nchw(E.View(P.blk), out)
         return out
+
+    # under autograd a tensor that itself requires grad is NOT overwritten (same values and gradients as the
+    # reference's in-place ReLU; only the aliasing side effect is dropped -- PyTorch would refuse it on a leaf)
+    def _autograd_forward(self, x):
+        P = self._plan_for(x)
+        E.to_nhwc(torch.relu(x.detach().float()).contiguous(), E.View(P.blk, 0, self.in_planes))
+        P.launch()
+        out = torch.empty((x.shape[0], self.in_planes + self.out_planes) + tuple(x.shape[2:]), dtype=torch.float32,
+                          device=x.device)
+        E.to_nchw(E.View(P.blk), out)
+        return out, P
+
+    def _autograd_backward(self, P, dout):
+        B = _plan_backward(P)
+        B.zero_()
+        blk = E.View(P.blk)
+        E.to_nhwc(dout, B.G(blk))
+        grads = {}
+        B.run(grads)
+        gx = B.G(E.View(P.blk, 0, self.in_planes))
+        E.grad_ew(E.GRAD_RELU_MASK, gx, gx, ref=E.View(P.blk, 0, self.in_planes))      # d relu(x) / dx
+        dx = torch.empty((dout.shape[0], self.in_planes) + tuple(dout.shape[2:]), dtype=torch.float32, device=dout.device)
+        E.to_nchw(gx, dx)
+        return dx, grads
 
 
 class TransitionBlockdy(_PlannedModule):
@@ -131,6 +191,10 @@ class TransitionBlockdy(_PlannedModule):
         return P.finish()
 
     def forward(self, x):
+        if _wants_grad(self, x):
+            if not x.requires_grad:
+                x.relu_()
+            return _apply_plan_function(self, x)
         P = self._plan_for(x)
         with torch.no_grad():
             x.relu_()
@@ -140,6 +204,28 @@ class TransitionBlockdy(_PlannedModule):
                               device=x.device)
             E.to_nchw(E.View(P.yout, 0, self.out_planes), out)
         return out
+
+    def _autograd_forward(self, x):
+        P = self._plan_for(x)
+        E.to_nhwc(torch.relu(x.detach().float()).contiguous(), E.View(P.xin))
+        P.launch()
+        out = torch.empty((x.shape[0], self.out_planes, 2 * x.shape[2], 2 * x.shape[3]), dtype=torch.float32, device=x.device)
+        E.to_nchw(E.View(P.yout, 0, self.out_planes), out)
+        return out, P
+
+    def _autograd_backward(self, P, dout):
+        B = _plan_backward(P)
+        B.zero_()
+        E.to_nhwc(dout, B.G(E.View(P.yout)))
+        grads = {}
+        B.run(grads)
+        xin = E.View(P.xin, 0, self.in_planes)
+        gx = B.G(xin)
+        E.grad_ew(E.GRAD_RELU_MASK, gx, gx, ref=xin)
+        dx = torch.empty((dout.shape[0], self.in_planes, dout.shape[2] // 2, dout.shape[3] // 2), dtype=torch.float32,
+                         device=dout.device)
+        E.to_nchw(gx, dx)
+        return dx, grads
 
 
 # ---------------------------------------------------------------------------------------
@@ -270,10 +356,32 @@ class FDGAN(_PlannedModule):
         return P.finish()
 
     def forward(self, x):
+        if _wants_grad(self, x):
+            return _apply_plan_function(self, x)
+        return self._forward_plan(self._plan_for(x), x)
+
+    def _autograd_forward(self, x):
         P = self._plan_for(x)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _fdgan_autograd(self, P, x)
-        return self._forward_plan(P, x)
+        out = self._forward_plan(P, x)
+        return out, (P, out)
+
+    def _autograd_backward(self, state, dout):
+        """Gradients of every parameter that receives one (11.8 M of 13.98 M; conv0, dense_block31, dense_norm31
+        and the dy blocks' bn1/bn2 never do).  The gradient w.r.t. the input image is not produced
+        (returns None): the generator's input is data."""
+        if not self.training:
+            raise NotImplementedError("FDGAN backward is built for train-mode BatchNorm (the reference never calls .eval())")
+        P, out = state
+        B = _plan_backward(P)
+        B.zero_()
+        n, _, h, w = out.shape
+        g8 = E.new_act(n, h, w, 8, out.device)
+        E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))                          # dehaze = tanh(conv_refin3(x6)) (:799)
+        grads = {}
+        last = dict(x=E.View(P.x6), w=P.w_last, k=3, pad=1, stride=1, bias=self.conv_refin3.bias, pro=None)
+        B.conv_backward(last, E.View(g8, 0, 3), grads)
+        B.run(grads, skip_dx_of={P.in8.data_ptr()})
+        return None, grads
 
     def _forward_plan(self, P, x):
         with torch.no_grad():
@@ -282,12 +390,6 @@ class FDGAN(_PlannedModule):
             out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             E.conv2d(E.View(P.x6).fd, P.w_last, self.conv_refin3.bias, None, E.nchw_f32_view(out), P.last_desc)
         return out
-
-
-def _fdgan_autograd(model, P, x):
-    raise NotImplementedError(
-        "FDGAN backward through the HIP plan is not built yet (round-1 scope: forward). Call under "
-        "torch.no_grad(), as /root/reference/demo.py does (volatile=True, demo.py:112-113).")
 
 
 # ---------------------------------------------------------------------------------------
