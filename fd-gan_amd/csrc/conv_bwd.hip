@@ -20,12 +20,16 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // weight gradient.  Workgroup = 64 cout x 64 cin of ONE tap; 4 waves, each 32 x 32 (2 x 2 MFMA
-// tiles); k = output pixels, 32 per step.  Both operands are pixel-major in memory with channels
-// contiguous, and both need "8 consecutive pixels of one channel" per lane: the staging pass
-// transposes them into LDS ([channel][32 pixels], row pitch 80 B), after which fragment reads are
-// plain ds_read_b128.
+// tiles); k = output pixels, 128 per step.  Both operands are pixel-major in memory with channels
+// contiguous, and both need "8 consecutive pixels of one channel" per lane.  The staging pass
+// transposes in registers: a thread loads 4 consecutive pixels x 8 channels of each operand (4 x 16 B),
+// regroups them with v_perm_b32 into 8 values of 4 pixels x 1 channel and writes those as ds_write_b64
+// into the [channel][128 pixels] LDS image (row pitch 272 B), after which the MFMA fragments are plain
+// ds_read_b128.  (First version: one pixel per thread and 16 ds_write_b16 per step -- LDS-write bound,
+// 35 ms of a 114 ms generator backward.)
 // ------------------------------------------------------------------------------------------
-constexpr int WG_ROWB = 80;                 // bytes per channel row: 32 pixels * 2 B + pad (16-byte aligned)
+constexpr int WG_KPX = 128;                 // pixels per step
+constexpr int WG_ROWB = WG_KPX * 2 + 16;    // bytes per channel row (16-byte aligned; 17 x 16 B: conflict-free b128 reads)
 constexpr int WG_TILE_B = 64 * WG_ROWB;     // one operand tile
 
 struct WgradArgs {
@@ -50,12 +54,44 @@ struct WgradArgs {
   long long split_px;         // pixels per split (multiple of 32)
 };
 
+__device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s, const float* sh_s, long long p, long long HW,
+                                          int ky, int kx, int ci_off, bool x_ok) {
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const long long n = p / HW, r = p - n * HW;
+  const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
+  const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
+  if (!x_ok) return zero4;
+  if (a.pool) {   // 1x1 conv on the 2x2 average of the activated input (transition / skip pooling)
+    const unsigned short* src = a.x + n * a.x_sn + (long long)(2 * iy) * a.x_sh + (long long)(2 * ix) * a.x_sw + ci_off;
+    f32x8 f = fd_affine_act(*reinterpret_cast<const u32x4*>(src), sc_s, sh_s, a.p_slope);
+    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sw), sc_s, sh_s, a.p_slope);
+    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh), sc_s, sh_s, a.p_slope);
+    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw), sc_s, sh_s, a.p_slope);
+    return fd_pack8(f * 0.25f);
+  }
+  if (iy < 0 || iy >= a.Hs || ix < 0 || ix >= a.Ws) return zero4;   // zero padding of the activated input
+  const u32x4 xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci_off);
+  return a.pro_mode != 0 ? fd_xform8(xv, sc_s, sh_s, a.p_slope) : xv;
+}
+
+// 4 pixels x 8 channels (one u32x4 per pixel) -> 8 x (4 pixels of one channel), written to rows ch0 .. ch0+7
+__device__ __forceinline__ void wg_store_transposed(char* tile, int ch0, int px4, const u32x4 (&v)[4]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    // dword d holds channels 2d (low half) and 2d+1 (high half) of each pixel
+    const unsigned lo01 = __builtin_amdgcn_perm(v[1][d], v[0][d], 0x05040100u), lo23 = __builtin_amdgcn_perm(v[3][d], v[2][d], 0x05040100u);
+    const unsigned hi01 = __builtin_amdgcn_perm(v[1][d], v[0][d], 0x07060302u), hi23 = __builtin_amdgcn_perm(v[3][d], v[2][d], 0x07060302u);
+    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d) * WG_ROWB + px4 * 8) = u32x2{lo01, lo23};
+    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d + 1) * WG_ROWB + px4 * 8) = u32x2{hi01, hi23};
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[2 * WG_TILE_B];
   __shared__ float sc_s[64], sh_s[64];
   __shared__ float bsum[32][64];
-  char* At = lds;                 // [64 ci][32 px]
-  char* Dt = lds + WG_TILE_B;     // [64 co][32 px]
+  char* At = lds;                 // [64 ci][128 px]
+  char* Dt = lds + WG_TILE_B;     // [64 co][128 px]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = (int)blockIdx.z / a.nsplit, split = (int)blockIdx.z % a.nsplit;
   const int ky = tap / a.ks, kx = tap - ky * a.ks;
@@ -75,7 +111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     sh_s[tid] = sh;
   }
   __syncthreads();
-  const int spx = tid >> 3, chunk = tid & 7;   // staging: pixel of the step, 8-channel chunk of the tile
+  // staging map: a 16-lane group shares the channel chunk and covers 16 consecutive 4-pixel groups, so its
+  // ds_write_b64 are 128 contiguous bytes of one row; a wave covers 4 chunks = 64 contiguous bytes per pixel
+  const int chunk = (tid >> 4) & 7, px4 = (tid & 15) | ((tid >> 7) << 4);   // 8 chunks x 32 pixel groups
   const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
   const bool want_bias = a.dbias != nullptr && tap == 0 && blockIdx.x == 0;
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -91,50 +129,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const long long p_begin = (long long)split * a.split_px;
   const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
-  for (long long p0 = p_begin; p0 < p_end; p0 += 32) {
-    const long long p = p0 + spx;
-    u32x4 dv = zero4, xv = zero4;
-    if (p < p_end) {
-      const long long n = p / HW, r = p - n * HW;
-      const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
-      if (dy_ok) dv = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
-      const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-      if (a.pool) {   // 1x1 conv on the 2x2 average of the activated input (transition / skip pooling)
-        if (x_ok) {
-          const unsigned short* src = a.x + n * a.x_sn + (long long)(2 * iy) * a.x_sh + (long long)(2 * ix) * a.x_sw + ci0 + chunk * 8;
-          const float* sc = sc_s + chunk * 8;
-          const float* sh = sh_s + chunk * 8;
-          f32x8 f = fd_affine_act(*reinterpret_cast<const u32x4*>(src), sc, sh, a.p_slope);
-          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sw), sc, sh, a.p_slope);
-          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh), sc, sh, a.p_slope);
-          f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw), sc, sh, a.p_slope);
-          xv = fd_pack8(f * 0.25f);
+  for (long long p0 = p_begin; p0 < p_end; p0 += WG_KPX) {
+    u32x4 dv[4], xv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long p = p0 + px4 * 4 + j;
+      dv[j] = zero4, xv[j] = zero4;
+      if (p < p_end) {
+        if (dy_ok) {
+          const long long n = p / HW, r = p - n * HW;
+          const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
+          dv[j] = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
         }
-      } else if (x_ok && iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) {
-        xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci0 + chunk * 8);
-        if (a.pro_mode != 0) xv = fd_xform8(xv, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);   // zero padding stays zero
+        xv[j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, p, HW, ky, kx, ci0 + chunk * 8, x_ok);
       }
     }
+    if (want_bias)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] += __uint_as_float(((dv[j][e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
     __syncthreads();   // previous step's fragments consumed
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const unsigned short xe = (unsigned short)((xv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-      const unsigned short de = (unsigned short)((dv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-      *reinterpret_cast<unsigned short*>(At + (chunk * 8 + e) * WG_ROWB + spx * 2) = xe;
-      *reinterpret_cast<unsigned short*>(Dt + (chunk * 8 + e) * WG_ROWB + spx * 2) = de;
-      if (want_bias) bs[e] += __uint_as_float((unsigned)de << 16);
-    }
+    wg_store_transposed(At, chunk * 8, px4, xv);
+    wg_store_transposed(Dt, chunk * 8, px4, dv);
     __syncthreads();
-    bf16x8 af[2], bf[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + g * 16));   // A: rows = cout
-      bf[i] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + i * 16 + m) * WG_ROWB + g * 16));   // B: cols = cin
+    for (int sub = 0; sub < WG_KPX / 32; ++sub) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // A: rows = cout
+        bf[i] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // B: cols = cin
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
   }
   // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
   const int kk = a.ks * a.ks;
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (want_bias) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[spx][chunk * 8 + e] = bs[e];
+    for (int e = 0; e < 8; ++e) bsum[px4][chunk * 8 + e] = bs[e];
     __syncthreads();
     if (tid < 64 && co0 + tid < a.Cout) {
       float t = 0.f;
@@ -265,20 +296,33 @@ struct SumFinArgs {
   float *dbeta, *dgamma;
   int accumulate;
 };
-__global__ __launch_bounds__(256) void sum_finalize_kernel(SumFinArgs a) {
-  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.channels) return;
+__global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
+  __shared__ double sh[2][32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const long long c = (long long)blockIdx.x * 32 + cl;
   double t1 = 0.0, t2 = 0.0;
-  for (long long r = 0; r < a.rows; ++r) {
-    t1 += a.partial[(r * a.cpad + c) * 2];
-    t2 += a.partial[(r * a.cpad + c) * 2 + 1];
-  }
-  if (a.accumulate) {
-    a.dbeta[c] += (float)t1;
-    a.dgamma[c] += (float)t2;
-  } else {
-    a.dbeta[c] = (float)t1;
-    a.dgamma[c] = (float)t2;
+  if (c < a.channels)
+    for (long long r = rg; r < a.rows; r += 32) {
+      const float2 v = *reinterpret_cast<const float2*>(a.partial + (r * a.cpad + c) * 2);
+      t1 += v.x;
+      t2 += v.y;
+    }
+  sh[0][rg][cl] = t1;
+  sh[1][rg][cl] = t2;
+  __syncthreads();
+  if (rg == 0 && c < a.channels) {
+    t1 = t2 = 0.0;
+    for (int g = 0; g < 32; ++g) {
+      t1 += sh[0][g][cl];
+      t2 += sh[1][g][cl];
+    }
+    if (a.accumulate) {
+      a.dbeta[c] += (float)t1;
+      a.dgamma[c] += (float)t2;
+    } else {
+      a.dbeta[c] = (float)t1;
+      a.dgamma[c] = (float)t2;
+    }
   }
 }
 
@@ -300,32 +344,44 @@ struct BnApplyArgs {
   const float *mean, *var, *gamma, *dbeta, *dgamma;
   int accumulate;
 };
+// dx = A[c] * dpre + B[c] * x + C[c] with A = gamma*rstd, B = -gamma*rstd^2*dgamma/M, C = -A*dbeta/M - B*mean:
+// a thread keeps one 8-channel group (24 coefficients in registers) and walks pixels with a grid stride.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
-  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (u >= a.P * a.C8) return;
-  const long long p = u / a.C8;
-  const int c8 = (int)(u - p * a.C8);
-  const long long HW = (long long)a.H * a.W, n = p / HW, r = p - n * HW;
-  const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-  const f32x8 d = __builtin_convertvector(
-      __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8)), f32x8);
-  const f32x8 xf = __builtin_convertvector(
-      __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8)), f32x8);
-  unsigned short* op = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
-  f32x8 o;
-  if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(op)), f32x8);
+  const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
+  const long long HW = (long long)a.H * a.W;
+  for (int c8_0 = 0; c8_0 < a.C8; c8_0 += 8) {
+    const int c8 = c8_0 + grp;
+    if (c8 >= a.C8) continue;
+    float A[8], B[8], Cc[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = c8 * 8 + e;
-    float v = 0.f;
-    if (c < a.C) {
-      const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f;
-      const float xhat = (xf[e] - a.mean[c]) * rs;
-      v = gmm * rs * (d[e] - a.dbeta[c] * a.inv_m - xhat * a.dgamma[c] * a.inv_m);
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      A[e] = B[e] = Cc[e] = 0.f;
+      if (c < a.C) {
+        const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f;
+        A[e] = gmm * rs;
+        B[e] = -gmm * rs * rs * a.dgamma[c] * a.inv_m;
+        Cc[e] = -A[e] * a.dbeta[c] * a.inv_m - B[e] * a.mean[c];
+      }
     }
-    o[e] = a.accumulate ? o[e] + v : v;
+    for (long long p = (long long)blockIdx.x * 32 + slot; p < a.P; p += (long long)gridDim.x * 32) {
+      const long long n = p / HW, r = p - n * HW;
+      const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+      const f32x8 d = __builtin_convertvector(
+          __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8)), f32x8);
+      const f32x8 xf = __builtin_convertvector(
+          __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8)), f32x8);
+      unsigned short* op = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+      f32x8 o;
+      if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(op)), f32x8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = fmaf(A[e], d[e], fmaf(B[e], xf[e], Cc[e]));
+        o[e] = a.accumulate ? o[e] + v : v;
+      }
+      *reinterpret_cast<u32x4*>(op) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+    }
   }
-  *reinterpret_cast<u32x4*>(op) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -510,7 +566,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   const bool direct = workspace == nullptr;
   FD_REQUIRE(direct || numel + (dbias ? cout : 0) <= workspace_floats, "conv2d_bwd_weight: workspace too small (%lld floats)", numel + cout);
   a.nsplit = (int)nsplit;
-  a.split_px = ((a.P + nsplit - 1) / nsplit + 31) / 32 * 32;
+  a.split_px = ((a.P + nsplit - 1) / nsplit + WG_KPX - 1) / WG_KPX * WG_KPX;
   a.dw = direct ? dw : workspace;
   a.dbias = dbias ? (direct ? dbias : workspace + nsplit * numel) : nullptr;
   dim3 grid((unsigned)((a.Cin + 63) / 64), (unsigned)((cout + 63) / 64), (unsigned)(d->ksize * d->ksize * nsplit));
@@ -551,7 +607,7 @@ extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t
                                      float* dbeta, int accumulate, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
   SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate};
-  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, a,
+  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
                    static_cast<hipStream_t>(stream));
 }
 
@@ -577,8 +633,9 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   a.inv_m = 1.f / (float)a.P;
   a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.dbeta = dbeta, a.dgamma = dgamma;
   a.accumulate = accumulate;
-  const long long units = a.P * a.C8;
-  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)((units + 255) / 256)), dim3(256), 0, a,
+  long long rows = (a.P + 31) / 32;
+  if (rows > 2048) rows = 2048;
+  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)rows), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
 
