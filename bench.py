@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--breakdown", default="", help="write the per-kernel-class breakdown JSON here")
     ap.add_argument("--graph", action="store_true", help="replay the plan as a hipGraph (no per-kernel events)")
+    ap.add_argument("--train-g", action="store_true",
+                    help="NOT the default workload: time netG forward + backward (mse loss), the part of the training "
+                         "step (BASELINE configs[2]) that exists; no roofline / cpu_baseline objects")
     return ap.parse_args()
 
 
@@ -118,6 +121,33 @@ def main():
     x = torch.from_numpy(np.random.default_rng(1234 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
 
     barrier = dp.barrier
+    if a.train_g:
+        tgt = torch.rand(B, 3, S, S, device=dev) * 2 - 1
+
+        def gstep():
+            g.zero_grad(set_to_none=True)
+            ((g(x) - tgt) ** 2).mean().backward()
+        for _ in range(max(a.warmup, 1)):
+            gstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gstep()
+        barrier()
+        dt = dp.max_over_ranks(time.perf_counter() - t0)
+        images = dp.sum_over_ranks(B * a.steps)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "PARTIAL training step: netG (FDGAN) forward + backward, mse loss, train-mode BatchNorm, "
+                                       "batch %d @ %dx%d per GPU; no D / VGG / optimizer / all-reduce yet" % (B, S, S),
+                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world},
+                "roofline": None, "cpu_baseline": None}), flush=True)
+        dp.close()
+        return
 
     with torch.no_grad():
         for _ in range(max(a.warmup, 1)):
