@@ -292,6 +292,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
       dst[0] = t1;
       dst[1] = t2;
     }
+    if (a.fin_mean != nullptr) fd_finalize_last_block(a, 128, tid, stage0);
   }
 }
 
@@ -345,6 +346,7 @@ static int ds_dispatch(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool 
     info->grid_x = grid.x;
     info->grid_y = 1;
     info->lds_bytes = lds;
+    info->fused_finalize = 1;
   }
   if (dry) return FD_OK;
   if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)

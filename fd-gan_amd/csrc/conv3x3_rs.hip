@@ -481,6 +481,7 @@ __global__ __launch_bounds__(RS_NT) void conv3x3_rs_kernel(ConvArgs a) {
       dst[0] = t1;
       dst[1] = t2;
     }
+    if (a.fin_mean != nullptr) fd_finalize_last_block(a, a.CoutW < RS_CT * 16 ? a.CoutW : RS_CT * 16, tid, ring);
   }
 }
 
@@ -524,6 +525,7 @@ int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
     info->grid_x = grid.x;
     info->grid_y = 1;
     info->lds_bytes = lds;
+    info->fused_finalize = 1;
   }
   if (dry) return FD_OK;
   static bool attr_done = false;

@@ -56,6 +56,10 @@ struct ConvArgs {
   int out_nchw_f32, upsample;
   float* stats;
   int stats_cpad;
+  // in-kernel finalize by the last workgroup (kernels that set FdConvInfo.fused_finalize)
+  float *fin_mean, *fin_var;
+  unsigned* fin_counter;
+  double fin_inv_count;
   int tiles_x, tiles_y;
   int seg_rows;  // conv3x3_rs: output rows per work item (tiles_x strips x tiles_y row segments per image)
   int pad;
@@ -168,6 +172,54 @@ __device__ __forceinline__ void fd_fold_bn(const ConvArgs& a, float* sc_lds, flo
     sh_lds[c] = sh;
   }
   if (a.pro_mode == 2 && a.nbt != nullptr && first && tid == 0) *a.nbt += 1;
+}
+
+// In-kernel finalize of the batch statistics (opt-in: FdStats.mean; measured SLOWER than the separate launch on
+// MI355X -- the device-scope fences below cost an L2 write-back / invalidate per workgroup, 2x on the whole
+// forward -- kept for hardware where that is cheap).  Every workgroup has just written its partial row; the last one
+// to arrive (device-scope counter) reduces all rows in fp64 and writes mean / biased variance, saving the
+// fdgan_bn_finalize launch that would otherwise sit between this conv and its consumer.  Call from ALL threads
+// of the workgroup after the partial row is stored.  Rows are blockIdx.x-indexed with pitch a.stats_cpad.
+// `scratch`: >= 4.5 KiB of LDS that is free at this point (8-byte aligned).
+__device__ __forceinline__ void fd_finalize_last_block(const ConvArgs& a, int channels, int tid, char* scratch) {
+  double(*fd_red)[8][33] = reinterpret_cast<double(*)[8][33]>(scratch);
+  volatile unsigned* fd_is_last = reinterpret_cast<volatile unsigned*>(scratch + 2 * 8 * 33 * 8);
+  __threadfence();   // release this workgroup's partial row at device scope
+  __syncthreads();
+  if (tid == 0) *fd_is_last = atomicAdd(a.fin_counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!*fd_is_last) return;
+  __threadfence();   // acquire the other workgroups' rows
+  const int rows = (int)gridDim.x;
+  for (int c0 = 0; c0 < channels; c0 += 32) {
+    const int cl = tid & 31, rg = tid >> 5;   // 32 channels x 8 row groups (first 256 threads)
+    double s1 = 0.0, s2 = 0.0;
+    if (tid < 256 && c0 + cl < channels)
+      for (int r = rg; r < rows; r += 8) {
+        const volatile float* pr = a.stats + ((long long)r * a.stats_cpad + c0 + cl) * 2;
+        s1 += pr[0];
+        s2 += pr[1];
+      }
+    if (tid < 256) {
+      fd_red[0][rg][cl] = s1;
+      fd_red[1][rg][cl] = s2;
+    }
+    __syncthreads();
+    if (tid < 32 && c0 + tid < channels) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        t1 += fd_red[0][g][tid];
+        t2 += fd_red[1][g][tid];
+      }
+      const double mean = t1 * a.fin_inv_count;
+      double var = t2 * a.fin_inv_count - mean * mean;
+      a.fin_mean[c0 + tid] = (float)mean;
+      a.fin_var[c0 + tid] = (float)(var < 0.0 ? 0.0 : var);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *a.fin_counter = 0u;   // ready for the next launch on this stream
 }
 
 // Sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA result row): 4 VALU adds with

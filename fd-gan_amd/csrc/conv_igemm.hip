@@ -130,6 +130,13 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
     a.y_sc = 1;
   }
   a.stats = stats ? stats->partial : nullptr;
+  if (stats && stats->mean) {
+    FD_REQUIRE(stats->var && stats->counter && stats->count > 0, "conv2d: fused finalize needs var, counter and count");
+    a.fin_mean = stats->mean;
+    a.fin_var = stats->var;
+    a.fin_counter = stats->counter;
+    a.fin_inv_count = 1.0 / (double)stats->count;
+  }
   a.dbg = g_fd_debug_timing;
   {  // measurement aid (tools only): FDGAN_DEBUG_NOSTORE=1 drops every output store
     static const bool nostore = getenv("FDGAN_DEBUG_NOSTORE") != nullptr;

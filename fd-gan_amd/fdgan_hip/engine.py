@@ -128,13 +128,16 @@ def conv_info(x_fd, y_fd, cout, desc, pro=None):
     return info
 
 
-def conv2d(x_fd, w, bias, pro, y_fd, desc, stats_buf=None):
-    """Enqueue (or record) one fused convolution.  Returns FdConvInfo when stats are produced."""
+def conv2d(x_fd, w, bias, pro, y_fd, desc, stats_buf=None, fused=None):
+    """Enqueue (or record) one fused convolution.  Returns FdConvInfo when stats are produced.
+    fused = (mean_ptr, var_ptr, counter_ptr, count): let the kernel's last workgroup finalize the statistics."""
     lib = L.load()
     st, info = None, None
     if stats_buf is not None:
         st = L.FdStats()
         st.partial, st.capacity_floats = stats_buf.data_ptr(), stats_buf.numel()
+        if fused is not None:
+            st.mean, st.var, st.counter, st.count = fused
         info = conv_info(x_fd, y_fd, desc.cout if desc.cout else y_fd.c, desc, pro)
     L.check(lib.fdgan_conv2d_fwd(C.byref(x_fd), w.buf.data_ptr() if isinstance(w, PackedWeight) else w,
                                  bias.data_ptr() if bias is not None else None,

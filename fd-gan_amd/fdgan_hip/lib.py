@@ -40,12 +40,13 @@ class FdConvDesc(C.Structure):
 
 
 class FdStats(C.Structure):
-    _fields_ = [("partial", C.c_void_p), ("capacity_floats", C.c_int64)]
+    _fields_ = [("partial", C.c_void_p), ("capacity_floats", C.c_int64), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("counter", C.c_void_p), ("count", C.c_int64)]
 
 
 class FdConvInfo(C.Structure):
     _fields_ = [("stats_rows", C.c_int64), ("stats_cpad", C.c_int64), ("grid_x", C.c_int64), ("grid_y", C.c_int64),
-                ("lds_bytes", C.c_int64)]
+                ("lds_bytes", C.c_int64), ("fused_finalize", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/fdgan_hip.h declares.

@@ -37,6 +37,12 @@ class NetPlan:
         self.keep = []             # anything that must outlive the plan
         self._param_versions = None
         self.records = []          # per op, in forward order: what the backward pass needs (fdgan_hip/backward.py)
+        import os
+        # Measured (netG fwd B=16 @256^2): letting the producer's last workgroup finalize the statistics removes 86
+        # launches but needs a device-scope release / acquire in EVERY workgroup, and on MI355X that is an L2
+        # write-back + invalidate per XCD: 10.7 ms per step against 5.25 ms with the separate 5 us launches.  Off.
+        self.fuse_finalize = os.environ.get("FDGAN_FUSED_FINALIZE") is not None
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)   # last-workgroup counter of the fused finalize
 
     # ---- registration -----------------------------------------------------------
     def weight(self, param, cout, cin, k, transposed=False, stride=1):
@@ -74,16 +80,20 @@ class NetPlan:
             n, h, ww, _ = (yfd.n, yfd.h, yfd.w, yfd.c)
             count = n * h * ww
 
+        fused = None
+        if stats is not None and info.fused_finalize and self.fuse_finalize:
+            fused = (stats.mean.data_ptr() + 4 * stats_c0, stats.var.data_ptr() + 4 * stats_c0, self.counter.data_ptr(), count)
+
         def run():
-            E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None)
-            if stats is not None:
+            E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None, fused)
+            if stats is not None and fused is None:
                 E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
 
         pro_nofx = E.prologue_without_side_effects(pro)
 
         def rerun():   # the same launch without BatchNorm's running-statistics side effects (recomputation)
-            E.conv2d(x.fd, w, bias, pro_nofx, yfd, desc, self.ws if stats is not None else None)
-            if stats is not None:
+            E.conv2d(x.fd, w, bias, pro_nofx, yfd, desc, self.ws if stats is not None else None, fused)
+            if stats is not None and fused is None:
                 E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
         self.records.append(dict(kind="conv", x=x, w=w, y=y if y_fd is None else None, k=k, pad=pad, stride=stride, bias=bias,
                                  pro=pro_nofx, e_act=e_act, upsample=bool(upsample), rerun=rerun))

@@ -110,6 +110,14 @@ typedef struct FdConvDesc {
 typedef struct FdStats {
   float* partial;
   int64_t capacity_floats;
+  /* Optional in-kernel finalize: when `mean` is set and the kernel supports it (FdConvInfo.fused_finalize), the
+   * LAST workgroup to finish reduces the partial rows itself (fp64) and writes mean / biased variance of the
+   * `cout` stored channels to mean[0..cout) / var[0..cout): no fdgan_bn_finalize launch.  `counter` is one
+   * zero-initialised uint32 per stream of launches (the kernel resets it); `count` = N*H*W of the stored tensor. */
+  float* mean;
+  float* var;
+  uint32_t* counter;
+  int64_t count;
 } FdStats;
 
 typedef struct FdConvInfo {
@@ -117,6 +125,7 @@ typedef struct FdConvInfo {
   int64_t stats_cpad;     /* channels per row (Cout rounded up)           */
   int64_t grid_x, grid_y; /* for the record                               */
   int64_t lds_bytes;
+  int64_t fused_finalize; /* 1: this kernel honours FdStats.mean / var / counter */
 } FdConvInfo;
 
 const char* fdgan_last_error(void);
