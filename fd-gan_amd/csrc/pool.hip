@@ -34,7 +34,77 @@ __global__ void maxpool2_kernel(PoolArgs a) {
   *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)oy * a.y_sh + (long long)ox * a.y_sw + g * 8) =
       __builtin_bit_cast(u32x4, __builtin_convertvector(m, bf16x8));
 }
+// backward: every input position belongs to exactly one 2x2 window; the gradient of the window goes to its
+// FIRST maximum in row-major order (what F.max_pool2d's backward does on ties -- frequent after a ReLU), and is
+// ADDED to dx (the pooled tensor's source is usually also a tapped feature map with its own gradient).
+struct PoolBwdArgs {
+  const unsigned short *x, *dy;
+  unsigned short* dx;
+  long long x_sn, x_sh, x_sw, dy_sn, dy_sh, dy_sw, dx_sn, dx_sh, dx_sw;
+  int Ho, Wo, groups;
+  long long total;
+};
+__global__ void maxpool2_bwd_kernel(PoolBwdArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  const int g = (int)(r % a.groups);
+  r /= a.groups;
+  const int ox = (int)(r % a.Wo);
+  r /= a.Wo;
+  const int oy = (int)(r % a.Ho);
+  const long long n = r / a.Ho;
+  const unsigned short* p = a.x + n * a.x_sn + (long long)(2 * oy) * a.x_sh + (long long)(2 * ox) * a.x_sw + g * 8;
+  const long long xo[4] = {0, a.x_sw, a.x_sh, a.x_sh + a.x_sw};
+  f32x8 f[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f[q] = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + xo[q])), f32x8);
+  const f32x8 d = __builtin_convertvector(
+      __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + g * 8)), f32x8);
+  int arg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int am = 0;
+    float mv = f[0][e];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (f[q][e] > mv) {
+        mv = f[q][e];
+        am = q;
+      }
+    arg[e] = am;
+  }
+  unsigned short* o = a.dx + n * a.dx_sn + (long long)(2 * oy) * a.dx_sh + (long long)(2 * ox) * a.dx_sw + g * 8;
+  const long long dxo[4] = {0, a.dx_sw, a.dx_sh, a.dx_sh + a.dx_sw};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x8 cur = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(o + dxo[q])), f32x8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cur[e] += arg[e] == q ? d[e] : 0.f;
+    *reinterpret_cast<u32x4*>(o + dxo[q]) = __builtin_bit_cast(u32x4, __builtin_convertvector(cur, bf16x8));
+  }
+}
 }  // namespace
+
+extern "C" int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTensor* dx, FdStream stream) {
+  FD_REQUIRE(x && dy && dx && x->ptr && dy->ptr && dx->ptr, "maxpool2_bwd_nhwc: NULL pointer");
+  FD_REQUIRE(x->dtype == FD_BF16 && dy->dtype == FD_BF16 && dx->dtype == FD_BF16 && x->stride[3] == 1 && dy->stride[3] == 1 &&
+                 dx->stride[3] == 1,
+             "maxpool2_bwd_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(dy->n == x->n && dy->h == x->h / 2 && dy->w == x->w / 2 && dy->c == x->c && x->c % 8 == 0 && dx->n == x->n &&
+                 dx->h == x->h && dx->w == x->w && dx->c == x->c,
+             "maxpool2_bwd_nhwc: shape mismatch (c must be a multiple of 8)");
+  FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)dy->ptr | (uintptr_t)dx->ptr) & 15) == 0, "maxpool2_bwd_nhwc: 16-byte alignment");
+  for (int i = 0; i < 3; ++i)
+    FD_REQUIRE(x->stride[i] % 8 == 0 && dy->stride[i] % 8 == 0 && dx->stride[i] % 8 == 0, "maxpool2_bwd_nhwc: strides must be multiples of 8");
+  PoolBwdArgs a{static_cast<const unsigned short*>(x->ptr), static_cast<const unsigned short*>(dy->ptr),
+                static_cast<unsigned short*>(dx->ptr), x->stride[0], x->stride[1], x->stride[2], dy->stride[0], dy->stride[1],
+                dy->stride[2], dx->stride[0], dx->stride[1], dx->stride[2], (int)dy->h, (int)dy->w, (int)(x->c / 8),
+                dy->n * dy->h * dy->w * (x->c / 8)};
+  FD_REQUIRE(a.total > 0, "maxpool2_bwd_nhwc: empty");
+  return fd_launch(&maxpool2_bwd_kernel, "maxpool2_bwd_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
 
 extern "C" int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream) {
   FD_REQUIRE(x && y && x->ptr && y->ptr, "maxpool2_nhwc: NULL pointer");

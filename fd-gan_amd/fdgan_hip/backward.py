@@ -196,6 +196,9 @@ class PlanBackward:
             if r["kind"] == "copy":
                 E.grad_ew(E.GRAD_ADD, self.G(r["dst"]), self.G(r["src"]))
                 continue
+            if r["kind"] == "maxpool":
+                E.maxpool2_bwd(r["src"], self.G(r["dst"]), self.G(r["src"]))
+                continue
             if i in self.recompute:
                 self.recs[self.recompute[i]]["rerun"]()
             y = r["y"]

@@ -167,6 +167,10 @@ def maxpool2(src, dst):
     L.check(L.load().fdgan_maxpool2_nhwc(C.byref(src.fd), C.byref(dst.fd), stream_ptr()), "maxpool2_nhwc")
 
 
+def maxpool2_bwd(x, dy, dx):
+    L.check(L.load().fdgan_maxpool2_bwd_nhwc(C.byref(x.fd), C.byref(dy.fd), C.byref(dx.fd), stream_ptr()), "maxpool2_bwd_nhwc")
+
+
 def blur15(x, use_input_norm=True):
     """x: contiguous NCHW fp32 cuda tensor -> Blur(l=15, sigma=3)(x), same shape."""
     n, c, h, w = x.shape

@@ -117,6 +117,12 @@ class NetPlan:
         self.keep += [src, dst]
         self.records.append(dict(kind="copy", src=src, dst=dst))
 
+    def maxpool(self, src, dst):
+        self._ops.append((lambda: E.maxpool2(src, dst), 0, dict(label="maxpool", flops=0.0, flops_done=0.0,
+                                                                 bytes=2 * src.fd.n * src.fd.h * src.fd.w * src.c * 5 // 4)))
+        self.keep += [src, dst]
+        self.records.append(dict(kind="maxpool", src=src, dst=dst))
+
     def op(self, fn):
         self._ops.append((fn, 0, dict(label="op", flops=0.0, flops_done=0.0, bytes=0)))
 

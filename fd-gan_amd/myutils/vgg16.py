@@ -58,8 +58,7 @@ class Vgg16(torch.nn.Module):
             elif item == "pool":
                 nxt = E.new_act(n, cur.shape[1] // 2, cur.shape[2] // 2, cur_c, dev)
                 src, dst = E.View(cur, 0, cur_c), E.View(nxt)
-                P.op(lambda s=src, d=dst: E.maxpool2(s, d))
-                P.keep += [src, dst]
+                P.maxpool(src, dst)
                 cur = nxt
             else:
                 name, cin, cout = item
@@ -70,10 +69,8 @@ class Vgg16(torch.nn.Module):
                 cur, cur_c = nxt, cout
         return P.finish()
 
-    def forward(self, X):
+    def _run(self, X):
         P = self._plan_for(X)
-        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("Vgg16 backward through the HIP plan is not built yet; call under torch.no_grad()")
         with torch.no_grad():
             E.to_nhwc(X.detach().float().contiguous(), E.View(P.xin))
             P.launch()
@@ -83,4 +80,42 @@ class Vgg16(torch.nn.Module):
                 o = torch.empty((nn_, cc, hh, ww), dtype=torch.float32, device=X.device)
                 E.to_nchw(v, o)
                 outs.append(o)
-        return outs
+        return P, outs
+
+    def forward(self, X):
+        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())):
+            params = tuple(p for p in self.parameters() if p.requires_grad)
+            return list(_VggFunction.apply(self, X, *params))
+        return self._run(X)[1]
+
+    def _backward(self, P, douts, need_dx):
+        """Perceptual-loss path: gradients of the four tapped feature maps back to the input image (and to the
+        filters, if they are not frozen)."""
+        from fdgan_hip.backward import PlanBackward
+        if getattr(P, "_bwd", None) is None:
+            P._bwd = PlanBackward(P)
+        B = P._bwd
+        B.zero_()
+        for v, d in zip(P.taps, douts):
+            if d is not None:
+                E.to_nhwc(d.detach().float().contiguous(), B.G(v))
+        grads = {}
+        B.run(grads, skip_dx_of=() if need_dx else {P.xin.data_ptr()})
+        dx = None
+        if need_dx:
+            dx = torch.empty((P.xin.shape[0], 3, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=P.xin.device)
+            E.to_nchw(B.G(E.View(P.xin, 0, 3)), dx)
+        return dx, grads
+
+
+class _VggFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, X, *params):
+        P, outs = module._run(X)
+        ctx.module, ctx.plan, ctx.params, ctx.need_dx = module, P, params, X.requires_grad
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        dx, grads = ctx.module._backward(ctx.plan, douts, ctx.need_dx)
+        return (None, dx) + tuple(grads.get(p) for p in ctx.params)

@@ -251,6 +251,8 @@ int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTe
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);
+/* its backward: dx += dy routed to the first maximum of each 2x2 window of x (F.max_pool2d's tie rule) */
+int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTensor* dx, FdStream stream);
 
 /* ---- frequency split of the Fusion-discriminator input ------------------------- */
 /* Reference: __pycache__/loss.cpython-36.pyc (source loss.py absent).

