@@ -109,6 +109,43 @@ void gaussian15(float* g, double sigma) {   // 1-D factor of isotropic_gaussian_
   for (int i = 0; i < 15; ++i) g[i] = (float)(v[i] / s);
 }
 
+// Adjoint of Blur along ONE axis (the 2-D adjoint is the x pass followed by the y pass; the Gaussian is
+// symmetric).  Forward, 1-D: out[i] = sum_t g[t] x[refl(i + t - 7)].  Its transpose is the zero-padded
+// correlation z[k] = sum_t g[t] d[k - t + 7] evaluated on the extended range k in [-7, L + 7), with the halo
+// folded back onto the samples the reflection read: dx[j] = z[j] + [1 <= j <= 7] z[-j] + [L-8 <= j <= L-2] z[2(L-1)-j].
+struct BlurAdjArgs {
+  const float* d;
+  float* out;
+  int H, W, C, axis;      // axis 0: along x (W), 1: along y (H)
+  float g[15];
+  float scale[3];         // per-channel factor applied on the way out (1/std of the input normalisation, or 1)
+  long long total;
+};
+__global__ __launch_bounds__(256) void blur_adj_kernel(BlurAdjArgs a) {
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= a.total) return;
+  const int x = (int)(u % a.W);
+  long long r = u / a.W;
+  const int y = (int)(r % a.H);
+  const long long plane = r / a.H;
+  const int L = a.axis ? a.H : a.W, j = a.axis ? y : x;
+  const long long stride = a.axis ? a.W : 1;
+  const float* line = a.d + plane * a.H * a.W + (a.axis ? x : (long long)y * a.W);
+  auto z = [&](int k) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 15; ++t) {
+      const int i = k - t + 7;
+      s = fmaf(a.g[t], (i >= 0 && i < L) ? line[(long long)i * stride] : 0.f, s);
+    }
+    return s;
+  };
+  float v = z(j);
+  if (j >= 1 && j <= 7) v += z(-j);
+  if (j >= L - 8 && j <= L - 2) v += z(2 * (L - 1) - j);
+  a.out[u] = v * a.scale[(int)(plane % a.C) % 3];
+}
+
 int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
   a.tiles_x = (a.W + FS_T - 1) / FS_T;
   a.tiles_y = (a.H + FS_T - 1) / FS_T;
@@ -172,4 +209,26 @@ extern "C" int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, i
   a.norm = use_input_norm ? 1 : 0;
   a.mode = 2;
   return launch(a, n * c, static_cast<hipStream_t>(stream), "fusion_input");
+}
+
+/* Blur's backward (loss.py:142-151 under autograd): dx = (1/std) * reflectpad^T(conv^T(dy)); `tmp` is a caller-owned
+ * scratch of n*c*h*w floats (the two 1-D adjoint passes). */
+extern "C" int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w,
+                                int use_input_norm, FdStream stream) {
+  FD_REQUIRE(dy && tmp && dx, "blur15_bwd: NULL pointer");
+  FD_REQUIRE(h >= 16 && w >= 16, "blur15_bwd: H, W >= 16");
+  FD_REQUIRE(!use_input_norm || c == 3, "blur15_bwd: use_input_norm needs 3 channels");
+  BlurAdjArgs a{};
+  a.H = (int)h, a.W = (int)w, a.C = (int)c;
+  gaussian15(a.g, 3.0);
+  a.total = n * c * h * w;
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  a.d = dy, a.out = tmp, a.axis = 0;
+  for (int i = 0; i < 3; ++i) a.scale[i] = 1.f;
+  int rc = fd_launch(&blur_adj_kernel, "blur15_adj_x", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, st);
+  if (rc != FD_OK) return rc;
+  a.d = tmp, a.out = dx, a.axis = 1;
+  for (int i = 0; i < 3; ++i) a.scale[i] = use_input_norm ? 1.f / sd[i] : 1.f;
+  return fd_launch(&blur_adj_kernel, "blur15_adj_y", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, st);
 }

@@ -180,6 +180,14 @@ def blur15(x, use_input_norm=True):
     return y
 
 
+def blur15_bwd(dy, use_input_norm=True):
+    n, c, h, w = dy.shape
+    tmp, dx = torch.empty_like(dy), torch.empty_like(dy)
+    L.check(L.load().fdgan_blur15_bwd(dy.data_ptr(), tmp.data_ptr(), dx.data_ptr(), n, c, h, w, int(bool(use_input_norm)),
+                                      stream_ptr()), "blur15_bwd")
+    return dx
+
+
 def laplacian3(x):
     n, c, h, w = x.shape
     y = torch.empty_like(x)

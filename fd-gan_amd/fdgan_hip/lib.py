@@ -84,6 +84,8 @@ SIGNATURES = {
     "fdgan_maxpool2_bwd_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_blur15_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                    C.c_void_p]),
+    "fdgan_blur15_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                   C.c_void_p]),
     "fdgan_laplacian3_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_fusion_input_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(FdTensor),
                                           C.c_int, C.c_void_p]),

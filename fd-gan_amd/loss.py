@@ -56,6 +56,8 @@ class Blur(nn.Module):
             self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _BlurFn.apply(x, self.use_input_norm)
         return E.blur15(_gpu_f32(x, "Blur.forward"), self.use_input_norm)
 
 
@@ -71,6 +73,8 @@ class Laplacian(nn.Module):
         self.register_buffer("kernel", get_laplacian_kernel2d(kernel_size))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _LaplacianFn.apply(x)
         return E.laplacian3(_gpu_f32(x, "Laplacian.forward"))
 
 
@@ -79,8 +83,32 @@ blur = Blur(l=15, kernel=blur_kernel)                           # loss.py:162 (u
 laplace_filter = Laplacian(kernel_size=3)                       # loss.py:304
 
 
+class _BlurFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, use_input_norm):
+        ctx.norm = use_input_norm
+        return E.blur15(_gpu_f32(x, "Blur.forward"), use_input_norm)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return E.blur15_bwd(dy.detach().float().contiguous(), ctx.norm), None
+
+
+class _LaplacianFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return E.laplacian3(_gpu_f32(x, "Laplacian.forward"))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return E.laplacian3(dy.detach().float().contiguous())     # self-adjoint: symmetric kernel, zero padding
+
+
 def fusion_input(img, use_input_norm=True):
     """cat([img, LF(img), HF(img)], 1): what the Fusion-discriminator sees for an image
     (/root/reference/facades/network.png).  Returns NCHW fp32 (B, 9, H, W)."""
+    if torch.is_grad_enabled() and img.requires_grad:      # generator's adversarial path: gradients flow through both filters
+        E.require_gpu(img, "fusion_input")
+        return torch.cat([img.float(), _BlurFn.apply(img, use_input_norm), _LaplacianFn.apply(img)], 1)
     x = _gpu_f32(img, "fusion_input")
     return torch.cat([x, E.blur15(x, use_input_norm), E.laplacian3(x)], 1)

@@ -268,6 +268,11 @@ int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTenso
 int fdgan_blur15_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
                      FdStream stream);
 int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
+/* Backward of the two filters (they feed D, whose gradient reaches the generator through them): the Laplacian
+ * is self-adjoint (symmetric kernel, zero padding): call fdgan_laplacian3_fwd on dy.  Blur's adjoint folds the
+ * reflection halo back; `tmp` is n*c*h*w floats of caller-owned scratch. */
+int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w,
+                     int use_input_norm, FdStream stream);
 int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w, const FdTensor* y,
                             int use_input_norm, FdStream stream);
 

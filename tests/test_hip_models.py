@@ -602,3 +602,28 @@ def test_vgg16_backward_perceptual_path(golden_dir):
     P._bwd.checks = None
     sum((f * c.to(DEV)).sum() for f, c in zip(v(xg2), cots)).backward()
     assert rel_rms(xg2.grad.cpu(), xg.grad.cpu()) < 1e-6 and all(p.grad is None or True for p in v.parameters())
+
+
+def test_frequency_split_backward():
+    """Blur (reflection pad 7 + 15x15 Gaussian, optional input normalisation) and Laplacian under autograd vs the
+    fp32 oracle (exact adjoints: linear operators, no rounding boundary anywhere)."""
+    import loss as hl
+    from oracle import freqsplit_ref as fr
+    from oracle.detweights import det_input
+    for shape in ((2, 3, 40, 56), (1, 3, 16, 16)):
+        x = det_input(shape, seed=81, lo=0.0, hi=1.0)
+        cot = det_input((shape[0], 9) + shape[2:], seed=82, lo=-1.0, hi=1.0)
+        xo = x.clone().requires_grad_(True)
+        yo = torch.cat([xo, fr.blur(xo), fr.laplacian(xo)], 1)
+        (yo * cot).sum().backward()
+        xg = x.to(DEV).requires_grad_(True)
+        y = hl.fusion_input(xg)
+        assert y.requires_grad and rel_rms(y.detach().cpu(), yo.detach()) < 1e-5
+        (y * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert rel_rms(xg.grad.cpu(), xo.grad) < 1e-5, shape
+    # module forms
+    xg = det_input((2, 3, 32, 32), seed=83).to(DEV).requires_grad_(True)
+    (hl.Blur(15, use_input_norm=False)(xg).sum() + hl.Laplacian(3)(xg).sum()).backward()
+    # d/dx sum(blur(x)) = A^T 1: away from the border every pixel is read with total weight 1
+    assert abs(float(xg.grad[0, 0, 16, 16]) - 1.0) < 1e-4
