@@ -1,0 +1,64 @@
+"""`models.pytorch_ssim` surface of the reference (/root/reference/models/pytorch_ssim/__init__.py): `ssim(img1, img2)`
+and the `SSIM` module, on the HIP path (csrc/ssim.hip).  Differentiable w.r.t. `img1` (the generated image); the
+reference's defaults -- window 11, sigma 1.5, size_average=True -- are the supported configuration.
+"""
+import ctypes as C
+
+import torch
+
+from fdgan_hip import engine as E
+from fdgan_hip import lib as L
+
+
+def _run_fwd(x, y):
+    n, c, h, w = x.shape
+    tiles = ((h + 31) // 32) * ((w + 31) // 32)
+    partial = torch.empty(n * c * tiles, dtype=torch.float32, device=x.device)
+    d = [torch.empty_like(x) for _ in range(3)]
+    L.check(L.load().fdgan_ssim_fwd(x.data_ptr(), y.data_ptr(), n * c, h, w, partial.data_ptr(), partial.numel(),
+                                    d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), E.stream_ptr()), "ssim_fwd")
+    return partial.double().sum().float() / (n * c * h * w), d
+
+
+class _SsimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        x, y = img1.detach().float().contiguous(), img2.detach().float().contiguous()
+        val, d = _run_fwd(x, y)
+        ctx.save_for_backward(x, y, *d)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, da, db, dc = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.load().fdgan_ssim_bwd(x.data_ptr(), y.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr(), n * c, h, w,
+                                        C.c_float(float(g) / (n * c * h * w)), dx.data_ptr(), E.stream_ptr()), "ssim_bwd")
+        return dx, None
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """pytorch_ssim/__init__.py:65-73."""
+    E.require_gpu(img1, "ssim")
+    E.require_gpu(img2, "ssim")
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("the HIP path implements the reference's defaults: window_size=11, size_average=True")
+    if img1.shape != img2.shape or img1.dim() != 4:
+        raise ValueError("ssim expects two NCHW tensors of the same shape")
+    if img2.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("ssim is differentiable w.r.t. its first argument (the generated image) only")
+    if torch.is_grad_enabled() and img1.requires_grad:
+        return _SsimFn.apply(img1, img2)
+    return _run_fwd(img1.detach().float().contiguous(), img2.detach().float().contiguous())[0]
+
+
+class SSIM(torch.nn.Module):
+    """pytorch_ssim/__init__.py:39-63."""
+
+    def __init__(self, window_size=11, size_average=True):
+        super().__init__()
+        self.window_size, self.size_average = window_size, size_average
+
+    def forward(self, img1, img2):
+        return ssim(img1, img2, self.window_size, self.size_average)

@@ -248,6 +248,15 @@ int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n, int64_t c,
                       const FdTensor* g, FdStream stream);
 int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream);
 
+/* Differentiable SSIM (models/pytorch_ssim/__init__.py:8-73: 11x11 Gaussian window sigma 1.5, depthwise, zero
+ * padding 5, C1 = 0.01^2, C2 = 0.03^2) on fp32 NCHW planes.  fdgan_ssim_fwd writes per-tile partial sums of the
+ * SSIM map (mean = sum / (planes*h*w)) and three planes of partial derivatives; fdgan_ssim_bwd turns them into
+ * d mean / d x, scaled by `weight`. */
+int fdgan_ssim_fwd(const float* x, const float* y, int64_t planes, int64_t h, int64_t w, float* partial,
+                   int64_t partial_floats, float* da, float* db, float* dc, FdStream stream);
+int fdgan_ssim_bwd(const float* x, const float* y, const float* da, const float* db, const float* dc, int64_t planes,
+                   int64_t h, int64_t w, float weight, float* dx, FdStream stream);
+
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);

@@ -627,3 +627,24 @@ def test_frequency_split_backward():
     (hl.Blur(15, use_input_norm=False)(xg).sum() + hl.Laplacian(3)(xg).sum()).backward()
     # d/dx sum(blur(x)) = A^T 1: away from the border every pixel is read with total weight 1
     assert abs(float(xg.grad[0, 0, 16, 16]) - 1.0) < 1e-4
+
+
+def test_ssim_forward_backward(manifest):
+    """models.pytorch_ssim on the HIP path vs the oracle (pinned to the reference's value in MANIFEST.json)."""
+    import models.pytorch_ssim as hs
+    from oracle import ssim_ref
+    from oracle.detweights import det_input
+    for shape in ((2, 3, 64, 64), (1, 3, 40, 72)):
+        a = det_input(shape, seed=91, lo=0.0, hi=1.0)
+        b = (a + 0.2 * det_input(shape, seed=92, lo=-1.0, hi=1.0)).clamp(0, 1)
+        ao = a.clone().requires_grad_(True)
+        vo = ssim_ref.ssim(ao, b)
+        vo.backward()
+        ag = a.to(DEV).requires_grad_(True)
+        v = hs.SSIM()(ag, b.to(DEV))
+        (1 - v).backward()
+        torch.cuda.synchronize()
+        assert abs(float(v) - float(vo)) < 2e-5, (float(v), float(vo))
+        assert rel_rms(-ag.grad.cpu(), ao.grad) < 1e-3, shape
+    same = det_input((1, 3, 32, 32), seed=93).to(DEV)
+    assert abs(float(hs.ssim(same, same)) - 1.0) < 1e-6
