@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--breakdown", default="", help="write the per-kernel-class breakdown JSON here")
     ap.add_argument("--graph", action="store_true", help="replay the plan as a hipGraph (no per-kernel events)")
+    ap.add_argument("--train", action="store_true",
+                    help="NOT the default workload: time the full training step of fd-gan_amd/train.py (G + Fusion-D + VGG16 "
+                         "+ SSIM, Adam; BASELINE configs[2], a reconstructed loss composition); no roofline / cpu_baseline")
     ap.add_argument("--train-g", action="store_true",
                     help="NOT the default workload: time netG forward + backward (mse loss), the part of the training "
                          "step (BASELINE configs[2]) that exists; no roofline / cpu_baseline objects")
@@ -121,6 +124,34 @@ def main():
     x = torch.from_numpy(np.random.default_rng(1234 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
 
     barrier = dp.barrier
+    if a.train:
+        import train as train_mod
+        ts = train_mod.TrainStep(dev, dp=dp)
+        gt = torch.from_numpy(np.random.default_rng(99 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
+        haze = (gt * 0.6 + 0.3).clamp(0, 1)
+        for _ in range(max(a.warmup, 1)):
+            ts.step(haze, gt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            last = ts.step(haze, gt)
+        barrier()
+        dt = dp.max_over_ranks(time.perf_counter() - t0)
+        images = dp.sum_over_ranks(B * a.steps)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "full training step (fd-gan_amd/train.py): G fwd+bwd, Fusion-D 3 fwd + 3 bwd, VGG16 2 fwd + 1 "
+                                       "bwd, SSIM, Adam(G), Adam(D), gradient all-reduce when n_gpus > 1; batch %d @ %dx%d per GPU; "
+                                       "loss composition reconstructed (the reference ships no training loop)" % (B, S, S),
+                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
+                           "last_losses": {k: round(v, 4) for k, v in last.items()}},
+                "roofline": None, "cpu_baseline": None}), flush=True)
+        dp.close()
+        return
     if a.train_g:
         tgt = torch.rand(B, 3, S, S, device=dev) * 2 - 1
 

@@ -62,12 +62,28 @@ class _PlanFunction(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         out, state = module._autograd_forward(x)
         ctx.module, ctx.state, ctx.params = module, state, params
+        ctx.plan = state[0] if isinstance(state, tuple) else state
+        ctx.gen = _bump_generation(ctx.plan)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        _check_generation(ctx.plan, ctx.gen)
         dx, grads = ctx.module._autograd_backward(ctx.state, dout.detach().float().contiguous())
         return (None, dx) + tuple(grads.get(p) for p in ctx.params)
+
+
+def _bump_generation(plan):
+    plan._generation = getattr(plan, "_generation", 0) + 1
+    return plan._generation
+
+
+def _check_generation(plan, gen):
+    """The activations live in the plan's buffers, not in autograd: a later forward of the same module and shape
+    overwrites them.  Backward must run before the next forward (accumulate losses over several backward calls)."""
+    if getattr(plan, "_generation", gen) != gen:
+        raise RuntimeError("this module ran another forward (same input shape) before backward: its plan buffers hold "
+                           "the later activations. Call backward() after each forward; gradients accumulate in .grad")
 
 
 def _wants_grad(module, x):
@@ -494,7 +510,7 @@ class D(_PlannedModule):
         return (m.layer1.conv.weight, l2.conv.weight, l2.bn.weight, l2.bn.bias, l3.conv.weight, l3.bn.weight, l3.bn.bias,
                 m.layer4.conv.weight, m.layer5.conv.weight)
 
-    def _backward(self, P, out, dout):
+    def _backward(self, P, out, dout, need_dx=True):
         """Gradients of the forward just run on plan P (train-mode BatchNorm: batch statistics).
         Returns (dx NCHW fp32, grads in `_grad_params` order).  dehaze1113.py:188-230 under autograd."""
         if not (self.main.layer2.layer2.bn.training and self.main.layer3.layer3.bn.training):
@@ -518,6 +534,9 @@ class D(_PlannedModule):
         d2 = E.new_act(n, h1, w1, r8(2 * nf), dev)
         d1 = E.new_act(n, h1, w1, r8(nf), dev)
         ws = torch.empty(512 * r8(4 * nf) * 2, dtype=torch.float32, device=dev)
+        if getattr(P, "_wgrad_ws", None) is None:
+            P._wgrad_ws = torch.empty(1 << 23, dtype=torch.float32, device=dev)      # split-K partials of the weight gradients
+        wws = P._wgrad_ws
         W1, W2, W3, W4, W5 = (m.layer1.conv.weight, l2.conv.weight, l3.conv.weight, m.layer4.conv.weight, m.layer5.conv.weight)
         grads = {id(p): torch.zeros_like(p) for p in self._grad_params()}
         keep = []
@@ -530,32 +549,39 @@ class D(_PlannedModule):
 
         E.out_act_bwd(dout.detach().float().contiguous(), out, L.ACT_SIGMOID, E.View(g5))
         # layer5: x = a4, LeakyReLU prologue, 4x4 s1 p1 -> 1 channel
-        E.conv_bwd_weight(E.View(a4, 0, 8 * nf).fd, lrelu, E.View(g5, 0, 1).fd, E.conv_desc(4, 1, 1, cout=1), grads[id(W5)])
+        if W5.requires_grad:
+            E.conv_bwd_weight(E.View(a4, 0, 8 * nf).fd, lrelu, E.View(g5, 0, 1).fd, E.conv_desc(4, 1, 1, cout=1), grads[id(W5)], None, wws)
         dgrad(E.View(g5, 0, 1), W5, 1, 8 * nf, 4, 1, E.View(d4))
         E.bn_act_bwd(E.View(d4, 0, 8 * nf).fd, E.View(a4, 0, 8 * nf).fd, lrelu)
         # layer4: x = a3, BatchNorm(layer3.bn) + LeakyReLU prologue, 4x4 s1 p1
-        E.conv_bwd_weight(E.View(a3, 0, 4 * nf).fd, pro3, E.View(d4, 0, 8 * nf).fd, E.conv_desc(4, 1, 1, cout=8 * nf), grads[id(W4)])
+        if W4.requires_grad:
+            E.conv_bwd_weight(E.View(a3, 0, 4 * nf).fd, pro3, E.View(d4, 0, 8 * nf).fd, E.conv_desc(4, 1, 1, cout=8 * nf), grads[id(W4)], None, wws)
         dgrad(E.View(d4, 0, 8 * nf), W4, 8 * nf, 4 * nf, 4, 1, E.View(d3))
         v3, x3 = E.View(d3, 0, 4 * nf), E.View(a3, 0, 4 * nf)
         rows, cpad = E.bn_act_bwd(v3.fd, x3.fd, pro3, ws)
         E.bn_bwd_finalize(ws, rows, cpad, 4 * nf, grads[id(l3.bn.weight)], grads[id(l3.bn.bias)])
         E.bn_bwd_apply(v3.fd, x3.fd, pro3, grads[id(l3.bn.weight)], grads[id(l3.bn.bias)], v3.fd)
         # layer3: x = a2, BatchNorm(layer2.bn) + LeakyReLU prologue, 3x3 s1 p1
-        E.conv_bwd_weight(E.View(a2, 0, 2 * nf).fd, pro2, v3.fd, E.conv_desc(3, 1, 1, cout=4 * nf), grads[id(W3)])
+        if W3.requires_grad:
+            E.conv_bwd_weight(E.View(a2, 0, 2 * nf).fd, pro2, v3.fd, E.conv_desc(3, 1, 1, cout=4 * nf), grads[id(W3)], None, wws)
         dgrad(v3, W3, 4 * nf, 2 * nf, 3, 1, E.View(d2))
         v2, x2 = E.View(d2, 0, 2 * nf), E.View(a2, 0, 2 * nf)
         rows, cpad = E.bn_act_bwd(v2.fd, x2.fd, pro2, ws)
         E.bn_bwd_finalize(ws, rows, cpad, 2 * nf, grads[id(l2.bn.weight)], grads[id(l2.bn.bias)])
         E.bn_bwd_apply(v2.fd, x2.fd, pro2, grads[id(l2.bn.weight)], grads[id(l2.bn.bias)], v2.fd)
         # layer2: x = a1, LeakyReLU prologue, 3x3 s1 p1
-        E.conv_bwd_weight(E.View(a1, 0, nf).fd, lrelu, v2.fd, E.conv_desc(3, 1, 1, cout=2 * nf), grads[id(W2)])
+        if W2.requires_grad:
+            E.conv_bwd_weight(E.View(a1, 0, nf).fd, lrelu, v2.fd, E.conv_desc(3, 1, 1, cout=2 * nf), grads[id(W2)], None, wws)
         dgrad(v2, W2, 2 * nf, nf, 3, 1, E.View(d1))
         v1 = E.View(d1, 0, nf)
         E.bn_act_bwd(v1.fd, E.View(a1, 0, nf).fd, lrelu)
         # layer1: x = the input image, no prologue, 4x4 s2 p1
-        E.conv_bwd_weight(E.View(P.xin, 0, nc).fd, None, v1.fd, E.conv_desc(4, 2, 1, cout=nf), grads[id(W1)])
-        dx = torch.empty((n, nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=dev)
-        E.conv_bwd_data_direct(v1.fd, W1.detach().contiguous(), E.conv_desc(4, 2, 1, cout=nf), dx)
+        if W1.requires_grad:
+            E.conv_bwd_weight(E.View(P.xin, 0, nc).fd, None, v1.fd, E.conv_desc(4, 2, 1, cout=nf), grads[id(W1)], None, wws)
+        dx = None
+        if need_dx:      # only the generator's adversarial path needs the gradient w.r.t. D's input
+            dx = torch.empty((n, nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=dev)
+            E.conv_bwd_data_direct(v1.fd, W1.detach().contiguous(), E.conv_desc(4, 2, 1, cout=nf), dx)
         torch.cuda.current_stream().synchronize()   # the temporaries above must outlive the launches
         self._last_act_grads = (d1, d2, d3, d4)    # dL/d(conv outputs), NHWC bf16 (kept for the parity tests)
         return dx, tuple(grads[id(p)] for p in self._grad_params())
@@ -568,11 +594,13 @@ class _DFunction(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         P, out = module._forward_plan(x)
         ctx.module, ctx.plan = module, P
+        ctx.gen = _bump_generation(P)
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        _check_generation(ctx.plan, ctx.gen)
         (out,) = ctx.saved_tensors
-        dx, grads = ctx.module._backward(ctx.plan, out, dout)
-        return (None, dx) + grads
+        dx, grads = ctx.module._backward(ctx.plan, out, dout, need_dx=ctx.needs_input_grad[1])
+        return (None, dx) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))

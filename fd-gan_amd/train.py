@@ -1,0 +1,122 @@
+"""One FD-GAN training step on the HIP path.
+
+The reference ships no training script: what its tree pins are the Adam hyper-parameters
+(lrD = lrG = 2e-4, beta1 = 0.5, demo.py:43-46), weights_init N(0, 0.02) (misc.py:16-22), ImagePool(50)
+(misc.py:140-161), the linear LR decay helper (misc.py:164-172), the component losses (SSIM, VGG16 features,
+Blur / Laplacian) and the figure showing D on [img, LF(img), HF(img)].  This step is therefore OUR composition of
+those pieces -- the loss weights are not recoverable from the reference:
+
+    D step:  BCE(D(F(gt)), 1) + BCE(D(F(pool(fake.detach()))), 0)                          -> Adam(D)
+    G step:  L1(fake, gt) + (1 - SSIM(fake, gt)) + sum_k MSE(VGG_k(fake), VGG_k(gt)) + w_adv * BCE(D(F(fake)), 1)  -> Adam(G)
+    F(img) = cat[img, Blur15(img), Laplacian3(img)]
+
+Every network forward / backward, the frequency split and SSIM run through libfdgan_hip.so; the scalar loss
+reductions (L1, MSE, BCE on already-computed tensors) and Adam are torch elementwise ops for now.
+Activations live in the modules' plan buffers, so each module's backward runs before its next forward (two
+backward calls for the two halves of the D loss).
+"""
+import argparse
+import time
+
+import torch
+import torch.nn.functional as F
+
+import misc
+import models.dehaze1113 as net
+import models.pytorch_ssim as pytorch_ssim
+from fdgan_hip.dp import DpContext, GradBuckets
+from loss import fusion_input
+from myutils.vgg16 import Vgg16
+
+
+class TrainStep:
+    def __init__(self, device, lrG=2e-4, lrD=2e-4, beta1=0.5, w_adv=0.01, w_perc=1.0, w_ssim=1.0, w_l1=1.0, pool_size=50,
+                 dp=None):
+        self.dev = device
+        self.netG = net.FDGAN().to(device)
+        self.netD = net.D(9, 36).to(device)
+        self.netG.apply(misc.weights_init)
+        self.netD.apply(misc.weights_init)
+        self.vgg = Vgg16().to(device)                       # the reference loads pretrained VGG16 weights; frozen
+        for p in self.vgg.parameters():
+            p.requires_grad_(False)
+        self.g_params = [p for p in self.netG.parameters()]
+        self.optG = torch.optim.Adam(self.g_params, lr=lrG, betas=(beta1, 0.999))
+        self.optD = torch.optim.Adam(self.netD.parameters(), lr=lrD, betas=(beta1, 0.999))
+        self.pool = misc.ImagePool(pool_size)
+        self.w = dict(adv=w_adv, perc=w_perc, ssim=w_ssim, l1=w_l1)
+        self.dp = dp
+        self.bG = GradBuckets(self.g_params, dp) if dp is not None and dp.world > 1 else None
+        self.bD = GradBuckets(list(self.netD.parameters()), dp) if dp is not None and dp.world > 1 else None
+
+    def _set_d_grad(self, flag):
+        for p in self.netD.parameters():
+            p.requires_grad_(flag)
+
+    def step(self, haze, gt):
+        """haze, gt: (B,3,H,W) float in [0,1] on the device.  Returns a dict of python floats."""
+        out = {}
+        fake = self.netG(haze)                                                     # autograd graph of the generator
+        # ---- D step: two backward calls (D's activations live in its plan buffers)
+        self._set_d_grad(True)
+        self.optD.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            real_in = fusion_input(gt)
+            fake_in = fusion_input(self.pool.query(fake.detach()))
+        p_real = self.netD(real_in)
+        l_real = F.binary_cross_entropy(p_real, torch.ones_like(p_real))
+        l_real.backward()
+        p_fake = self.netD(fake_in)
+        l_fake = F.binary_cross_entropy(p_fake, torch.zeros_like(p_fake))
+        l_fake.backward()
+        if self.bD is not None:
+            self.bD.allreduce_()
+        self.optD.step()
+        out["lossD"] = float((l_real + l_fake).detach())
+        # ---- G step
+        self._set_d_grad(False)                                                    # D is a fixed critic here: no dW work
+        self.optG.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            feats_gt = self.vgg(gt)
+        feats = self.vgg(fake)
+        l_perc = sum(F.mse_loss(a, b) for a, b in zip(feats, feats_gt))
+        l_ssim = 1.0 - pytorch_ssim.ssim(fake, gt)
+        l_l1 = (fake - gt).abs().mean()
+        p_adv = self.netD(fusion_input(fake))
+        l_adv = F.binary_cross_entropy(p_adv, torch.ones_like(p_adv))
+        lossG = self.w["l1"] * l_l1 + self.w["ssim"] * l_ssim + self.w["perc"] * l_perc + self.w["adv"] * l_adv
+        lossG.backward()
+        if self.bG is not None:
+            self.bG.allreduce_()
+        self.optG.step()
+        out.update({k: float(v.detach()) for k, v in dict(lossG=lossG, l1=l_l1, ssim=1.0 - l_ssim, perc=l_perc, adv=l_adv).items()})
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser(description="synthetic-data smoke run of the FD-GAN training step")
+    ap.add_argument("--batchSize", type=int, default=16)
+    ap.add_argument("--imageSize", type=int, default=256)
+    ap.add_argument("--niter", type=int, default=5)
+    ap.add_argument("--lrG", type=float, default=0.0002)
+    ap.add_argument("--lrD", type=float, default=0.0002)
+    ap.add_argument("--beta1", type=float, default=0.5)
+    opt = ap.parse_args()
+    dp = DpContext.from_env()
+    dev = dp.device or torch.device("cuda", 0)
+    ts = TrainStep(dev, opt.lrG, opt.lrD, opt.beta1, dp=dp)
+    g = torch.Generator(device="cpu").manual_seed(1234 + dp.rank)
+    for it in range(opt.niter):
+        gt = torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)
+        haze = (gt * 0.6 + 0.3).clamp(0, 1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        r = ts.step(haze, gt)
+        torch.cuda.synchronize()
+        if dp.rank == 0:
+            print("[%d] %.1f ms  %s" % (it, 1e3 * (time.time() - t0), {k: round(v, 4) for k, v in r.items()}), flush=True)
+    dp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -648,3 +648,31 @@ def test_ssim_forward_backward(manifest):
         assert rel_rms(-ag.grad.cpu(), ao.grad) < 1e-3, shape
     same = det_input((1, 3, 32, 32), seed=93).to(DEV)
     assert abs(float(hs.ssim(same, same)) - 1.0) < 1e-6
+
+
+def test_training_step_smoke():
+    """Two full training steps (G + Fusion-D + VGG16 + SSIM, Adam) at a small size: finite losses, both networks'
+    parameters move, BatchNorm statistics advance, and the forward-before-backward guard fires."""
+    import train
+    ts = train.TrainStep(torch.device(DEV))
+    g = torch.Generator().manual_seed(7)
+    gt = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    w0 = ts.netG.conv_refin3.weight.detach().clone()
+    d0 = ts.netD.main.layer4.conv.weight.detach().clone()
+    r1 = ts.step(haze, gt)
+    r2 = ts.step(haze, gt)
+    torch.cuda.synchronize()
+    for r in (r1, r2):
+        assert all(np.isfinite(v) for v in r.values()), r
+    assert not torch.equal(w0, ts.netG.conv_refin3.weight) and not torch.equal(d0, ts.netD.main.layer4.conv.weight)
+    assert int(ts.netG.trans_block3.norm.num_batches_tracked) == 2
+    assert ts.netG.conv0.weight.grad is None                      # never-called modules stay untouched
+    _report("train_step_smoke", {"step1": r1, "step2": r2})
+    # guard: a second forward of the same module before backward invalidates the first graph
+    y1 = ts.netD(fusion := torch.rand(2, 9, 64, 64, device=DEV))
+    ts._set_d_grad(True)
+    y1 = ts.netD(fusion)
+    _ = ts.netD(fusion)
+    with pytest.raises(RuntimeError, match="another forward"):
+        y1.mean().backward()
