@@ -14,6 +14,8 @@
 //                     formulation would waste the matrix pipe anyway.
 // Reference: autograd of nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU / nn.Sigmoid as composed in
 // /root/reference/models/dehaze1113.py:188-230 (D) and :703-801 (FDGAN).
+#include <stdlib.h>
+
 #include "conv_igemm.h"
 
 namespace {
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const long long p_begin = (long long)split * a.split_px;
   const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
-  for (long long p0 = p_begin; p0 < p_end; p0 += WG_KPX) {
-    u32x4 dv[4], xv[4];
+  // software pipeline: the global loads of step s+1 are in flight while the MFMAs of step s run
+  u32x4 dv[4], xv[4];
+  auto load_step = [&](long long p0) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long p = p0 + px4 * 4 + j;
@@ -144,6 +147,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         xv[j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, p, HW, ky, kx, ci0 + chunk * 8, x_ok);
       }
     }
+  };
+  if (p_begin < p_end) load_step(p_begin);
+  for (long long p0 = p_begin; p0 < p_end; p0 += WG_KPX) {
     if (want_bias)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     wg_store_transposed(At, chunk * 8, px4, xv);
     wg_store_transposed(Dt, chunk * 8, px4, dv);
     __syncthreads();
+    if (p0 + WG_KPX < p_end) load_step(p0 + WG_KPX);
 #pragma unroll
     for (int sub = 0; sub < WG_KPX / 32; ++sub) {
       bf16x8 af[2], bf[2];
@@ -190,6 +197,151 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       a.dbias[(long long)split * a.Cout + co0 + tid] = t;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of the dense-layer growth conv (3x3, stride 1, pad 1, Cout <= 32, Cin % 32 == 0), all nine
+// taps in one workgroup.  The per-tap kernel above re-stages x and dy for every tap (9x the VALU, LDS and L2
+// traffic; 1 ms per 256x256 layer).  Here the k dimension walks image rows: a workgroup owns (image, 128-pixel
+// column block, row range, 32-channel slice of Cin); per output row it stages ONE new input row -- transformed
+// once, written as three copies shifted by kx so every tap's B fragment is a 16-byte-aligned ds_read_b128 --
+// and one dy row; the two previous input rows stay in LDS (3 row slots).  Wave w owns (cout tile w & 1,
+// cin tile w >> 1) for all 9 taps: one A read + 9 B reads per 9 MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int W3_PB = 128;                         // pixels per row step
+constexpr int W3_PITCH = W3_PB * 2 + 16;           // 272 B per channel row
+constexpr int W3_XS_B = 3 * 3 * 32 * W3_PITCH;     // [row slot][kx][32 ci][pitch]
+constexpr int W3_DT_B = 32 * W3_PITCH;
+
+struct Wgrad3Args {
+  const unsigned short* x;
+  long long x_sn;
+  int x_sh, x_sw;
+  const unsigned short* dy;
+  long long dy_sn;
+  int dy_sh, dy_sw;
+  int H, W, Cin, Cout, Cout8;
+  int xblocks, seg_rows, segs;   // column blocks per image; rows per work item; row segments per (image, block)
+  int pro_mode;
+  float p_slope, eps;
+  const float *p_mean, *p_var, *p_gamma, *p_beta;
+  float* part;                   // [nsplit][Cout][Cin][9]
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char w3_lds[];
+  char* Xs = w3_lds;
+  char* Dt = w3_lds + W3_XS_B;
+  float* sc_s = reinterpret_cast<float*>(Dt + W3_DT_B);
+  float* sh_s = sc_s + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.x * 32;
+  const int item = blockIdx.y;                       // (image, column block, row segment)
+  const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
+  const int y_begin = seg * a.seg_rows, y_end = min(a.H, y_begin + a.seg_rows);
+  const int xbase = xb * W3_PB;
+  if (tid < 32) {
+    const int c = ci0 + tid;
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
+      sc = g / sqrtf(a.p_var[c] + a.eps);
+      sh = b - a.p_mean[c] * sc;
+    }
+    sc_s[tid] = sc;
+    sh_s[tid] = sh;
+  }
+  __syncthreads();
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bool is_x = tid < 128;                       // threads 0-127 stage x, 128-255 stage dy
+  const int q = (tid & 127) >> 2, chunk = tid & 3;   // 4-pixel group (0..31), 8-channel chunk (0..3)
+  const bool dy_ok = chunk < a.Cout8;
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0 + chunk * 8;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + chunk * 8;
+
+  // one input row -> the three kx-shifted transposed copies of slot (row mod 3)
+  auto stage_x_row = [&](int row) __attribute__((always_inline)) {
+    char* slot = Xs + ((row + 3) % 3) * (3 * 32 * W3_PITCH);
+    u32x4 sv[6];
+    const bool rok = row >= 0 && row < a.H;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int px = xbase + q * 4 - 1 + j;
+      sv[j] = zero4;
+      if (rok && px >= 0 && px < a.W) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + (long long)row * a.x_sh + (long long)px * a.x_sw);
+        sv[j] = a.pro_mode != 0 ? fd_xform8(v, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope) : v;   // padding stays zero
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const u32x4 grp[4] = {sv[kx], sv[kx + 1], sv[kx + 2], sv[kx + 3]};
+      char* tile = slot + kx * (32 * W3_PITCH);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned lo01 = __builtin_amdgcn_perm(grp[1][d], grp[0][d], 0x05040100u), lo23 = __builtin_amdgcn_perm(grp[3][d], grp[2][d], 0x05040100u);
+        const unsigned hi01 = __builtin_amdgcn_perm(grp[1][d], grp[0][d], 0x07060302u), hi23 = __builtin_amdgcn_perm(grp[3][d], grp[2][d], 0x07060302u);
+        *reinterpret_cast<u32x2*>(tile + (chunk * 8 + 2 * d) * W3_PITCH + q * 8) = u32x2{lo01, lo23};
+        *reinterpret_cast<u32x2*>(tile + (chunk * 8 + 2 * d + 1) * W3_PITCH + q * 8) = u32x2{hi01, hi23};
+      }
+    }
+  };
+  auto stage_dy_row = [&](int row) __attribute__((always_inline)) {
+    u32x4 dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = xbase + q * 4 + j;
+      dv[j] = (dy_ok && px < a.W) ? *reinterpret_cast<const u32x4*>(dimg + (long long)row * a.dy_sh + (long long)px * a.dy_sw) : zero4;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned lo01 = __builtin_amdgcn_perm(dv[1][d], dv[0][d], 0x05040100u), lo23 = __builtin_amdgcn_perm(dv[3][d], dv[2][d], 0x05040100u);
+      const unsigned hi01 = __builtin_amdgcn_perm(dv[1][d], dv[0][d], 0x07060302u), hi23 = __builtin_amdgcn_perm(dv[3][d], dv[2][d], 0x07060302u);
+      *reinterpret_cast<u32x2*>(Dt + (chunk * 8 + 2 * d) * W3_PITCH + q * 8) = u32x2{lo01, lo23};
+      *reinterpret_cast<u32x2*>(Dt + (chunk * 8 + 2 * d + 1) * W3_PITCH + q * 8) = u32x2{hi01, hi23};
+    }
+  };
+
+  const int wco = (wave & 1) * 16, wci = (wave >> 1) * 16;
+  const int m = lane & 15, g = lane >> 4;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsub = (min(W3_PB, a.W - xbase) + 31) / 32;
+
+  if (is_x) {
+    stage_x_row(y_begin - 1);
+    stage_x_row(y_begin);
+  }
+  for (int y = y_begin; y < y_end; ++y) {
+    if (is_x)
+      stage_x_row(y + 1);        // slot (y+1) % 3: last read two steps ago
+    else
+      stage_dy_row(y);
+    __syncthreads();
+    for (int sub = 0; sub < nsub; ++sub) {
+      const bf16x8 af = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + m) * W3_PITCH + sub * 64 + g * 16));
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const char* slot = Xs + ((y + ky - 1 + 3) % 3) * (3 * 32 * W3_PITCH);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(slot + kx * (32 * W3_PITCH) + (wci + m) * W3_PITCH + sub * 64 + g * 16));
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[ky * 3 + kx], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();             // fragments consumed: the next step overwrites Dt and the oldest x slot
+  }
+  // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
+  float* dwp = a.part + (long long)item * a.Cout * a.Cin * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = wco + g * 4 + r, ci = ci0 + wci + m;
+      if (co < a.Cout) dwp[((long long)co * a.Cin + ci) * 9 + t] = acc[t][r];
+    }
 }
 
 // partial weight gradients [nsplit][numel] -> out[numel] (+= when accumulate), summed in split order
@@ -550,6 +702,41 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
+  // the dense-layer growth conv: all nine taps in one workgroup
+  if (workspace != nullptr && dbias == nullptr && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !pool && cout <= 32 &&
+      a.Cin % 32 == 0 && a.Ws % 4 == 0 && getenv("FDGAN_DEBUG_NO_WGRAD3") == nullptr) {
+    Wgrad3Args w{};
+    w.x = a.x, w.x_sn = a.x_sn, w.x_sh = a.x_sh, w.x_sw = a.x_sw;
+    w.dy = a.dy, w.dy_sn = a.dy_sn, w.dy_sh = a.dy_sh, w.dy_sw = a.dy_sw;
+    w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin, w.Cout = cout, w.Cout8 = a.Cout8;
+    w.xblocks = (a.Ws + W3_PB - 1) / W3_PB;
+    w.pro_mode = a.pro_mode, w.p_slope = a.p_slope, w.eps = a.eps;
+    w.p_mean = a.p_mean, w.p_var = a.p_var, w.p_gamma = a.p_gamma, w.p_beta = a.p_beta;
+    const long long numel3 = (long long)cout * a.Cin * 9;
+    const long long strips = (long long)x->n * w.xblocks, ci_tiles = a.Cin / 32;
+    long long segs = 1024 / (strips * ci_tiles);                 // ~1024 workgroups in all
+    if (segs < 1) segs = 1;
+    if (segs > (a.Hs + 7) / 8) segs = (a.Hs + 7) / 8;            // at least 8 rows per item (2 rows of halo re-staged per item)
+    while (segs > 1 && strips * segs * numel3 > workspace_floats) --segs;
+    if (strips * segs * numel3 <= workspace_floats && strips * segs < 65536) {
+      w.segs = (int)segs;
+      w.seg_rows = (int)((a.Hs + segs - 1) / segs);
+      w.part = workspace;
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_wgrad3x3): %s", hipGetErrorString(e));
+        attr_done = true;
+      }
+      hipStream_t st3 = static_cast<hipStream_t>(stream);
+      int rc3 = fd_launch(&conv_wgrad3x3_kernel, "conv_wgrad3x3", dim3((unsigned)ci_tiles, (unsigned)(strips * segs)), dim3(256),
+                          W3_XS_B + W3_DT_B + 256, w, st3);
+      if (rc3 != FD_OK) return rc3;
+      WredArgs r3{workspace, dw, numel3, (int)(strips * segs), accumulate};
+      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 255) / 256)), dim3(256), 0, r3, st3);
+    }
+  }
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
   const long long base = (long long)((a.Cin + 63) / 64) * ((cout + 63) / 64) * d->ksize * d->ksize;
   // split the pixel axis until ~768 workgroups exist (one pass over all pixels per workgroup otherwise)

@@ -210,3 +210,31 @@ def test_gradient_plumbing_kernels(E):
         torch.cuda.synchronize()
         assert rel_rms(_from_nhwc(g, cc), bf16_round(dout * f(out))) < 1e-6
         assert float(g[..., cc:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 32, 21, 40), (2, 256, 24, 9, 132), (1, 64, 32, 64, 64), (2, 128, 32, 5, 8)])
+def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
+    """conv_wgrad3x3 (growth-conv shape: 3x3 s1 p1, Cout <= 32, Cin % 32 == 0): ragged column blocks, several
+    row segments, rows above / below the image, against torch on identical bf16 operands; also equal (up to
+    summation order) to the per-tap kernel."""
+    import os
+    from fdgan_hip import lib as L
+    x = bf16_round(seeded((n, cin, h, w), 41, -1.5, 1.5))
+    dy = bf16_round(seeded((n, cout, h, w), 42, -1.0, 1.0))
+    p = _bn_params(cin, 50)
+    keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
+    sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+    sh = (p["beta"] - p["mean"] * sc).float()
+    a = bf16_round(torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).double()
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a, wref, None, 1, 1).backward(dy.double())
+    pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+    xb, dyb = _nhwc(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 16)
+    ws = torch.zeros(1 << 23, dtype=torch.float32, device=DEV)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw, None, ws, False)
+    dw_direct = torch.empty_like(dw)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw_direct, None, None, False)
+    torch.cuda.synchronize()
+    assert rel_rms(dw.cpu().double(), wref.grad) < 5e-3
+    assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
