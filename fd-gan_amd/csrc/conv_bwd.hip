@@ -88,17 +88,24 @@ __device__ __forceinline__ void wg_store_transposed(char* tile, int ch0, int px4
   }
 }
 
+// T = 64: workgroup tile 64 cout x 64 cin (wave 32 x 32); T = 128: 128 x 128 (wave 64 x 64, 4x the MFMA work for
+// 2x the staging: the 1x1 bottleneck / transition shapes, whose dy would otherwise be re-staged by 16 cin tiles).
+template <int T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * WG_TILE_B];
-  __shared__ float sc_s[64], sh_s[64];
-  __shared__ float bsum[32][64];
-  char* At = lds;                 // [64 ci][128 px]
-  char* Dt = lds + WG_TILE_B;     // [64 co][128 px]
+  constexpr int NT = T / 32;              // MFMA tiles per wave in each direction (2 or 4)
+  constexpr int UPT = T / 64;             // staging units (4 pixels x 8 channels) per thread and operand
+  constexpr int TILE_B = T * WG_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* At = lds;                         // [T ci][128 px]
+  char* Dt = lds + TILE_B;                // [T co][128 px]
+  float* sc_s = reinterpret_cast<float*>(lds + 2 * TILE_B);   // [T]
+  float* sh_s = sc_s + T;
+  float* bsum = sh_s + T;                 // [32][T] (dbias only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = (int)blockIdx.z / a.nsplit, split = (int)blockIdx.z % a.nsplit;
+  const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T, tap = (int)blockIdx.z / a.nsplit, split = (int)blockIdx.z % a.nsplit;
   const int ky = tap / a.ks, kx = tap - ky * a.ks;
   // per-channel scale / shift of this cin tile (BatchNorm fold, as fd_fold_bn but without side effects)
-  if (tid < 64) {
+  if (tid < T) {
     const int c = ci0 + tid;
     float sc = 1.f, sh = 0.f;
     if (a.pro_mode == 2) {
@@ -115,36 +122,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __syncthreads();
   // staging map: a 16-lane group shares the channel chunk and covers 16 consecutive 4-pixel groups, so its
   // ds_write_b64 are 128 contiguous bytes of one row; a wave covers 4 chunks = 64 contiguous bytes per pixel
-  const int chunk = (tid >> 4) & 7, px4 = (tid & 15) | ((tid >> 7) << 4);   // 8 chunks x 32 pixel groups
-  const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
+  const int chunk0 = (tid >> 4) & 7, px4 = (tid & 15) | ((tid >> 7) << 4);   // 8 chunks x 32 pixel groups; unit u adds 8 chunks
   const bool want_bias = a.dbias != nullptr && tap == 0 && blockIdx.x == 0;
-  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+  float bs[UPT][8];
+#pragma unroll
+  for (int u = 0; u < UPT; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[u][e] = 0.f;
+  const int wco = (wave & 1) * (T / 2), wci = (wave >> 1) * (T / 2);
   const int m = lane & 15, g = lane >> 4;
-  f32x4 acc[2][2];
+  f32x4 acc[NT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long long HW = (long long)a.Ho * a.Wo;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   const long long p_begin = (long long)split * a.split_px;
   const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
   // software pipeline: the global loads of step s+1 are in flight while the MFMAs of step s run
-  u32x4 dv[4], xv[4];
+  u32x4 dv[UPT][4], xv[UPT][4];
   auto load_step = [&](long long p0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long long p = p0 + px4 * 4 + j;
-      dv[j] = zero4, xv[j] = zero4;
-      if (p < p_end) {
-        if (dy_ok) {
-          const long long n = p / HW, r = p - n * HW;
-          const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
-          dv[j] = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
+    for (int u = 0; u < UPT; ++u) {
+      const int chunk = chunk0 + 8 * u;
+      const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long p = p0 + px4 * 4 + j;
+        dv[u][j] = zero4, xv[u][j] = zero4;
+        if (p < p_end) {
+          if (dy_ok) {
+            const long long n = p / HW, r = p - n * HW;
+            const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
+            dv[u][j] = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
+          }
+          xv[u][j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, p, HW, ky, kx, ci0 + chunk * 8, x_ok);
         }
-        xv[j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, p, HW, ky, kx, ci0 + chunk * 8, x_ok);
       }
     }
   };
@@ -152,35 +167,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (long long p0 = p_begin; p0 < p_end; p0 += WG_KPX) {
     if (want_bias)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int u = 0; u < UPT; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bs[e] += __uint_as_float(((dv[j][e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bs[u][e] += __uint_as_float(((dv[u][j][e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
     __syncthreads();   // previous step's fragments consumed
-    wg_store_transposed(At, chunk * 8, px4, xv);
-    wg_store_transposed(Dt, chunk * 8, px4, dv);
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      wg_store_transposed(At, (chunk0 + 8 * u) * 8, px4, xv[u]);
+      wg_store_transposed(Dt, (chunk0 + 8 * u) * 8, px4, dv[u]);
+    }
     __syncthreads();
     if (p0 + WG_KPX < p_end) load_step(p0 + WG_KPX);
 #pragma unroll
     for (int sub = 0; sub < WG_KPX / 32; ++sub) {
-      bf16x8 af[2], bf[2];
+      bf16x8 af[NT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NT; ++i) {
         af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // A: rows = cout
         bf[i] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // B: cols = cin
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   }
   // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
   const int kk = a.ks * a.ks;
   float* dwp = a.dw + (long long)split * a.Cout * a.Cin * kk;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco + i * 16 + g * 4 + r, ci = ci0 + wci + j * 16 + m;
@@ -189,11 +209,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (want_bias) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[px4][chunk * 8 + e] = bs[e];
+    for (int u = 0; u < UPT; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[px4 * T + (chunk0 + 8 * u) * 8 + e] = bs[u][e];
     __syncthreads();
-    if (tid < 64 && co0 + tid < a.Cout) {
+    if (tid < T && co0 + tid < a.Cout) {
       float t = 0.f;
-      for (int q = 0; q < 32; ++q) t += bsum[q][tid];
+      for (int q = 0; q < 32; ++q) t += bsum[q * T + tid];
       a.dbias[(long long)split * a.Cout + co0 + tid] = t;
     }
   }
@@ -738,7 +760,11 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
     }
   }
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
-  const long long base = (long long)((a.Cin + 63) / 64) * ((cout + 63) / 64) * d->ksize * d->ksize;
+  // workgroup tile edge.  The 128 x 128 instantiation (4x the MFMA work per 2x staging) measured SLOWER on the
+  // training step (91.3 vs 87.2 ms): half the workgroups per CU and twice the serial staging per step; tuning aid only
+  static const bool big = getenv("FDGAN_DEBUG_WGRAD_T128") != nullptr;
+  const int T = (big && cout >= 128 && a.Cin >= 128) ? 128 : 64;
+  const long long base = (long long)((a.Cin + T - 1) / T) * ((cout + T - 1) / T) * d->ksize * d->ksize;
   // split the pixel axis until ~768 workgroups exist (one pass over all pixels per workgroup otherwise)
   long long nsplit = 1;
   if (workspace != nullptr) {
@@ -756,9 +782,18 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   a.split_px = ((a.P + nsplit - 1) / nsplit + WG_KPX - 1) / WG_KPX * WG_KPX;
   a.dw = direct ? dw : workspace;
   a.dbias = dbias ? (direct ? dbias : workspace + nsplit * numel) : nullptr;
-  dim3 grid((unsigned)((a.Cin + 63) / 64), (unsigned)((cout + 63) / 64), (unsigned)(d->ksize * d->ksize * nsplit));
+  dim3 grid((unsigned)((a.Cin + T - 1) / T), (unsigned)((cout + T - 1) / T), (unsigned)(d->ksize * d->ksize * nsplit));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = fd_launch(&conv_wgrad_kernel, "conv_wgrad", grid, dim3(256), 0, a, st);
+  const unsigned lds = 2u * T * WG_ROWB + 2u * T * 4 + (dbias ? 32u * T * 4 : 0u);
+  static bool attr128 = false;
+  if (T == 128 && !attr128) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_wgrad<128>): %s", hipGetErrorString(e));
+    attr128 = true;
+  }
+  int rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128>, "conv_wgrad_t128", grid, dim3(256), lds, a, st)
+                    : fd_launch(&conv_wgrad_kernel<64>, "conv_wgrad", grid, dim3(256), lds, a, st);
   if (rc != FD_OK || direct) return rc;
   WredArgs r{workspace, dw, numel, (int)nsplit, accumulate};
   rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, r, st);
