@@ -333,3 +333,47 @@ int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream) {
   return fd_launch(&act_inplace_kernel, act == FD_ACT_TANH ? "tanh_inplace" : "sigmoid_inplace",
                    dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, stream);
 }
+
+// ---------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, no weight decay / amsgrad: what demo.py's lrG / lrD / beta1 flags
+// configure): p -= lr * (m / (1 - b1^t)) / (sqrt(v / (1 - b2^t)) + eps) on one flat fp32 tensor.
+// ---------------------------------------------------------------------------------
+struct AdamArgs {
+  float *p, *m, *v;
+  const float* g;
+  long long n;
+  float lr, b1, b2, eps, bc1, bc2;   // bc = 1 - beta^t
+};
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= a.n) return;
+  if (i + 4 <= a.n) {
+    f32x4 p = *reinterpret_cast<f32x4*>(a.p + i), m = *reinterpret_cast<f32x4*>(a.m + i), v = *reinterpret_cast<f32x4*>(a.v + i);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m[e] = a.b1 * m[e] + (1.f - a.b1) * g[e];
+      v[e] = a.b2 * v[e] + (1.f - a.b2) * g[e] * g[e];
+      p[e] -= a.lr * (m[e] / a.bc1) / (sqrtf(v[e] / a.bc2) + a.eps);
+    }
+    *reinterpret_cast<f32x4*>(a.p + i) = p;
+    *reinterpret_cast<f32x4*>(a.m + i) = m;
+    *reinterpret_cast<f32x4*>(a.v + i) = v;
+  } else {
+    for (long long j = i; j < a.n; ++j) {
+      const float g = a.g[j];
+      a.m[j] = a.b1 * a.m[j] + (1.f - a.b1) * g;
+      a.v[j] = a.b2 * a.v[j] + (1.f - a.b2) * g * g;
+      a.p[j] -= a.lr * (a.m[j] / a.bc1) / (sqrtf(a.v[j] / a.bc2) + a.eps);
+    }
+  }
+}
+
+extern "C" int fdgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, int64_t step, FdStream stream) {
+  FD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  FD_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte aligned flat tensors");
+  AdamArgs a{p, m, v, g, n, lr, beta1, beta2, eps, (float)(1.0 - pow((double)beta1, (double)step)),
+             (float)(1.0 - pow((double)beta2, (double)step))};
+  return fd_launch(&adam_kernel, "adam_step", dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}

@@ -80,6 +80,8 @@ SIGNATURES = {
     "fdgan_plan_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "fdgan_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int64]),
     "fdgan_debug_timing": (C.c_int, [C.c_void_p]),
+    "fdgan_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_int64, C.c_void_p]),
     "fdgan_ssim_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_ssim_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

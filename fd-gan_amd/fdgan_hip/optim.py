@@ -1,0 +1,61 @@
+"""Adam on the HIP path: the parameters that receive gradients live in ONE flat fp32 buffer (their `.data` are views
+of it), so are their gradients; a step is one kernel launch over the flat tensor and the data-parallel all-reduce is
+one (or a few, bucketed) collective on the flat gradient -- no per-parameter kernels, no torch.cat per step."""
+import torch
+
+from . import engine as E
+from . import lib as L
+
+
+class FlatAdam:
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no parameter requires grad")
+        dev = self.params[0].device
+        E.require_gpu(self.params[0], "FlatAdam")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]                 # 16-byte aligned segments
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            seg = self.flat[o:o + p.numel()].view_as(p)
+            seg.copy_(p.data)
+            p.data = seg                                                          # the parameter now aliases the flat buffer
+            p.grad = self.grad[o:o + p.numel()].view_as(p)                        # and so does its gradient
+        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.param_groups = [{"lr": lr, "params": self.params}]                  # misc.adjust_learning_rate compatibility
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):                              # re-attach if someone dropped .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def step(self):
+        self.t += 1
+        lr = self.param_groups[0]["lr"]
+        L.check(L.load().fdgan_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         self.flat.numel(), lr, self.betas[0], self.betas[1], self.eps, self.t, E.stream_ptr()),
+                "adam_step")
+
+    def allreduce_grads(self, ctx, bucket_mb=8.0):
+        """Data-parallel gradient averaging on the flat buffer: RCCL all-reduce of contiguous slices, last slice
+        first (the parameters whose gradients are produced first by the backward walk live at the end)."""
+        if ctx is None or ctx.world == 1:
+            return 0
+        import torch.distributed as dist
+        n, step = self.grad.numel(), max(1, int(bucket_mb * (1 << 20) / 4))
+        works = []
+        for hi in range(n, 0, -step):
+            lo = max(0, hi - step)
+            works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        self.grad.div_(ctx.world)
+        return len(works)

@@ -11,7 +11,8 @@ those pieces -- the loss weights are not recoverable from the reference:
     F(img) = cat[img, Blur15(img), Laplacian3(img)]
 
 Every network forward / backward, the frequency split and SSIM run through libfdgan_hip.so; the scalar loss
-reductions (L1, MSE, BCE on already-computed tensors) and Adam are torch elementwise ops for now.
+reductions (L1, MSE, BCE on already-computed tensors) are torch elementwise ops for now; Adam is one HIP kernel over
+a flat fp32 parameter buffer (fdgan_hip/optim.py), whose flat gradient is also what RCCL all-reduces.
 Activations live in the modules' plan buffers, so each module's backward runs before its next forward (two
 backward calls for the two halves of the D loss).
 """
@@ -24,7 +25,8 @@ import torch.nn.functional as F
 import misc
 import models.dehaze1113 as net
 import models.pytorch_ssim as pytorch_ssim
-from fdgan_hip.dp import DpContext, GradBuckets
+from fdgan_hip.dp import DpContext
+from fdgan_hip.optim import FlatAdam
 from loss import fusion_input
 from myutils.vgg16 import Vgg16
 
@@ -40,14 +42,28 @@ class TrainStep:
         self.vgg = Vgg16().to(device)                       # the reference loads pretrained VGG16 weights; frozen
         for p in self.vgg.parameters():
             p.requires_grad_(False)
-        self.g_params = [p for p in self.netG.parameters()]
-        self.optG = torch.optim.Adam(self.g_params, lr=lrG, betas=(beta1, 0.999))
-        self.optD = torch.optim.Adam(self.netD.parameters(), lr=lrD, betas=(beta1, 0.999))
+        # Only parameters that can receive a gradient go into the optimizer: FDGAN registers 2.2 M that never do
+        # (conv0, dense_block31, dense_norm31, the dy blocks' bn1 / bn2 -- SURVEY 8e).  One dry forward + backward
+        # at a tiny size finds them.
+        self.g_params = self._params_with_grad(self.netG, device)
+        self.optG = FlatAdam(self.g_params, lr=lrG, betas=(beta1, 0.999))
+        self.optD = FlatAdam(list(self.netD.parameters()), lr=lrD, betas=(beta1, 0.999))
         self.pool = misc.ImagePool(pool_size)
         self.w = dict(adv=w_adv, perc=w_perc, ssim=w_ssim, l1=w_l1)
         self.dp = dp
-        self.bG = GradBuckets(self.g_params, dp) if dp is not None and dp.world > 1 else None
-        self.bD = GradBuckets(list(self.netD.parameters()), dp) if dp is not None and dp.world > 1 else None
+
+    @staticmethod
+    def _params_with_grad(module, device):
+        was = {n: (m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+               for n, m in module.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)}
+        module(torch.rand(1, 3, 32, 32, device=device)).mean().backward()
+        got = [p for p in module.parameters() if p.grad is not None]
+        for p in module.parameters():
+            p.grad = None
+        for n, m in module.named_modules():                          # the probe must not count as a training step
+            if n in was:
+                m.running_mean.copy_(was[n][0]), m.running_var.copy_(was[n][1]), m.num_batches_tracked.copy_(was[n][2])
+        return got
 
     def _set_d_grad(self, flag):
         for p in self.netD.parameters():
@@ -59,7 +75,7 @@ class TrainStep:
         fake = self.netG(haze)                                                     # autograd graph of the generator
         # ---- D step: two backward calls (D's activations live in its plan buffers)
         self._set_d_grad(True)
-        self.optD.zero_grad(set_to_none=True)
+        self.optD.zero_grad()
         with torch.no_grad():
             real_in = fusion_input(gt)
             fake_in = fusion_input(self.pool.query(fake.detach()))
@@ -69,13 +85,12 @@ class TrainStep:
         p_fake = self.netD(fake_in)
         l_fake = F.binary_cross_entropy(p_fake, torch.zeros_like(p_fake))
         l_fake.backward()
-        if self.bD is not None:
-            self.bD.allreduce_()
+        self.optD.allreduce_grads(self.dp)
         self.optD.step()
         out["lossD"] = float((l_real + l_fake).detach())
         # ---- G step
         self._set_d_grad(False)                                                    # D is a fixed critic here: no dW work
-        self.optG.zero_grad(set_to_none=True)
+        self.optG.zero_grad()
         with torch.no_grad():
             feats_gt = self.vgg(gt)
         feats = self.vgg(fake)
@@ -86,8 +101,7 @@ class TrainStep:
         l_adv = F.binary_cross_entropy(p_adv, torch.ones_like(p_adv))
         lossG = self.w["l1"] * l_l1 + self.w["ssim"] * l_ssim + self.w["perc"] * l_perc + self.w["adv"] * l_adv
         lossG.backward()
-        if self.bG is not None:
-            self.bG.allreduce_()
+        self.optG.allreduce_grads(self.dp)
         self.optG.step()
         out.update({k: float(v.detach()) for k, v in dict(lossG=lossG, l1=l_l1, ssim=1.0 - l_ssim, perc=l_perc, adv=l_adv).items()})
         return out

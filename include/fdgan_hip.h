@@ -248,6 +248,11 @@ int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n, int64_t c,
                       const FdTensor* g, FdStream stream);
 int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream);
 
+/* torch.optim.Adam's update (no weight decay, no amsgrad -- what the reference's lrG / lrD / beta1 flags configure,
+ * demo.py:43-46) on one flat fp32 tensor: exp_avg m, exp_avg_sq v, 1-based `step` for the bias corrections. */
+int fdgan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int64_t step, FdStream stream);
+
 /* Differentiable SSIM (models/pytorch_ssim/__init__.py:8-73: 11x11 Gaussian window sigma 1.5, depthwise, zero
  * padding 5, C1 = 0.01^2, C2 = 0.03^2) on fp32 NCHW planes.  fdgan_ssim_fwd writes per-tile partial sums of the
  * SSIM map (mean = sum / (planes*h*w)) and three planes of partial derivatives; fdgan_ssim_bwd turns them into

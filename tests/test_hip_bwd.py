@@ -238,3 +238,27 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     torch.cuda.synchronize()
     assert rel_rms(dw.cpu().double(), wref.grad) < 5e-3
     assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
+
+
+def test_flat_adam_matches_torch_adam():
+    from fdgan_hip.optim import FlatAdam
+    torch.manual_seed(3)
+    shapes = [(36, 9, 4, 4), (72,), (5, 3, 3, 3), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    o_hip = FlatAdam(mine, lr=2e-4, betas=(0.5, 0.999))
+    for step in range(4):
+        o_ref.zero_grad(), o_hip.zero_grad()
+        gs = [torch.randn(s) * (0.1 + step) for s in shapes]
+        for p, q, g in zip(ref, mine, gs):
+            (p * g).sum().backward()
+            (q * g.to(DEV)).sum().backward()             # autograd accumulates into the flat gradient view
+        o_ref.step(), o_hip.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ref, mine):
+        assert q.data_ptr() >= o_hip.flat.data_ptr() and torch.allclose(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7)
+    o_hip.param_groups[0]["lr"] = 0.0
+    before = o_hip.flat.clone()
+    o_hip.step()
+    assert torch.equal(before, o_hip.flat)
