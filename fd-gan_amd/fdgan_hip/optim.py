@@ -13,7 +13,6 @@ class FlatAdam:
         if not self.params:
             raise ValueError("FlatAdam: no parameter requires grad")
         dev = self.params[0].device
-        E.require_gpu(self.params[0], "FlatAdam")
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]                 # 16-byte aligned segments
         self.offsets = [0]
         for s in sizes:
@@ -38,6 +37,7 @@ class FlatAdam:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
     def step(self):
+        E.require_gpu(self.flat, "FlatAdam.step")          # the update is a HIP kernel; no CPU fallback
         self.t += 1
         lr = self.param_groups[0]["lr"]
         L.check(L.load().fdgan_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

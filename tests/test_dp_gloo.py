@@ -81,3 +81,35 @@ def test_two_rank_gradient_allreduce(tmp_path):
         want = (r[0]["local"][k] + r[1]["local"][k]) / 2
         assert torch.allclose(r[0]["avg"][k], want, rtol=1e-6, atol=1e-8)
         assert torch.equal(r[0]["avg"][k], r[1]["avg"][k])
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from fdgan_hip.dp import DpContext
+    from fdgan_hip.optim import FlatAdam
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2, 3, 3))]
+    opt = FlatAdam(params, lr=1e-3)
+    opt.zero_grad()
+    sum((p * float(rank + 1)).sum() for p in params).backward()          # d/dp = rank + 1 everywhere
+    nb = opt.allreduce_grads(dp, bucket_mb=0.0001)
+    ok_alias = all(p.grad.data_ptr() == opt.grad.data_ptr() + 4 * o for p, o in zip(params, opt.offsets))
+    try:
+        opt.step()
+        stepped = True
+    except RuntimeError as e:
+        stepped = "no CPU fallback" not in str(e)
+    torch.save(dict(g=[p.grad.clone() for p in params], nb=nb, ok_alias=ok_alias, stepped=stepped), os.path.join(out_dir, "f%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_flat_gradient_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_flat_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "f%d.pt" % i)) for i in range(world)]
+    for x in r:
+        assert x["nb"] >= 2 and x["ok_alias"] and x["stepped"] is False      # the Adam update itself needs the GPU
+        for g in x["g"]:
+            assert torch.allclose(g, torch.full_like(g, 1.5))                  # mean of 1 and 2
