@@ -568,7 +568,10 @@ struct DgradDirectArgs {
   int dy_sh, dy_sw;
   int Ho, Wo, Cout;
   const float* w;   // [Cout][Cin][ks][ks] fp32
-  float* dx;        // [N][Cin][H][W]
+  float* dx;        // [N][Cin][H][W] fp32, or NULL when dx_nhwc is used
+  unsigned short* dx_nhwc;   // NHWC bf16 view (strided convs inside a plan)
+  long long dxn_sn;
+  int dxn_sh, dxn_sw;
   int N, Cin, H, W, ks, stride, pad;
 };
 __global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
@@ -597,7 +600,11 @@ __global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
                  (float)(__bf16)a.w[(((long long)co * a.Cin + ci) * a.ks + ky) * a.ks + kx], s);   // the forward's bf16 filter
     }
   }
-  a.dx[u] = s;
+  if (a.dx != nullptr)
+    a.dx[u] = s;
+  else
+    a.dx_nhwc[(long long)n * a.dxn_sn + (long long)iy * a.dxn_sh + (long long)ix * a.dxn_sw + ci] =
+        (unsigned short)(__builtin_bit_cast(unsigned short, (__bf16)s));
 }
 
 // output-activation backward: g[n][y][x][c] (NHWC bf16) = dout[n][c][y][x] * f'(out) from NCHW fp32 tensors
@@ -912,5 +919,26 @@ extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref,
   a.N = (int)dst->n, a.H = (int)dst->h, a.W = (int)dst->w, a.C8 = (int)((dst->c + 7) / 8), a.mode = mode;
   const long long total = (long long)a.N * a.H * a.W * a.C8;
   return fd_launch(&grad_ew_kernel, "grad_ew", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+/* the same any-stride data gradient into an NHWC bf16 view (strided convolutions inside a plan: dehaze22.D's 4x4 s2) */
+extern "C" int fdgan_conv2d_bwd_data_direct_nhwc(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
+                                                 const FdTensor* dx, FdStream stream) {
+  if (int rc = check_view(dy, "conv2d_bwd_data_direct_nhwc(dy)")) return rc;
+  if (int rc = check_view(dx, "conv2d_bwd_data_direct_nhwc(dx)")) return rc;
+  FD_REQUIRE(w && d && cout > 0 && cin > 0 && dx->c >= cin, "conv2d_bwd_data_direct_nhwc: bad arguments");
+  const long long ho = (dx->h + 2 * d->pad - d->ksize) / d->stride + 1, wo = (dx->w + 2 * d->pad - d->ksize) / d->stride + 1;
+  FD_REQUIRE(dy->n == dx->n && dy->h == ho && dy->w == wo && dy->c >= cout, "conv2d_bwd_data_direct_nhwc: dy shape mismatch");
+  DgradDirectArgs a{};
+  a.dy = static_cast<const unsigned short*>(dy->ptr);
+  a.dy_sn = dy->stride[0], a.dy_sh = (int)dy->stride[1], a.dy_sw = (int)dy->stride[2];
+  a.Ho = (int)ho, a.Wo = (int)wo, a.Cout = cout;
+  a.w = w, a.dx = nullptr;
+  a.dx_nhwc = static_cast<unsigned short*>(dx->ptr);
+  a.dxn_sn = dx->stride[0], a.dxn_sh = (int)dx->stride[1], a.dxn_sw = (int)dx->stride[2];
+  a.N = (int)dx->n, a.Cin = cin, a.H = (int)dx->h, a.W = (int)dx->w, a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
+  const long long total = (long long)a.N * cin * a.H * a.W;
+  return fd_launch(&dgrad_direct_kernel, "dgrad_direct_nhwc", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }

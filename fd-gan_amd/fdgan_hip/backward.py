@@ -113,8 +113,8 @@ class PlanBackward:
         """dy_view: gradient of the op's stored output (already sum-pooled / masked by the caller if needed)."""
         x, w, k, pad, pro = r["x"], r["w"], r["k"], r["pad"], r["pro"]
         meta = pro._meta if pro is not None else dict(act=L.ACT_NONE, pool=False, bn=None)
-        if r["stride"] != 1 and need_dx:
-            raise NotImplementedError("data gradient of a strided conv inside a plan")
+        if r["stride"] != 1 and need_dx and (w.transposed or (pro is not None and pro._meta["pool"])):
+            raise NotImplementedError("data gradient of a strided transposed / pooled conv")
         desc = E.conv_desc(k, r["stride"], pad, cout=w.cout)
         # ---- parameters
         p = w.param
@@ -147,8 +147,13 @@ class PlanBackward:
             return
         # ---- data gradient: forward conv of dy with the flipped filter, at the conv-input resolution
         n, hy, wy, _ = dy_view.shape
-        hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
         cin = w.cin
+        if r["stride"] != 1:     # any-stride direct kernel (one thread per input element): the discriminators' 4x4 s2 convs
+            hin, win = x.shape[1], x.shape[2]
+            T = E.new_act(n, hin, win, _r8(cin), p.device, zero=True)
+            E.conv_bwd_data_direct_nhwc(dy_view.fd, p.detach().contiguous(), desc, E.View(T, 0, cin), cin)
+            return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
+        hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
         T = E.new_act(n, hin, win, _r8(cin), p.device)
         # the forward filter tensor in OIHW terms: ConvTranspose2d stores (cin, cout): already the transposed one
         if w.transposed:
@@ -157,6 +162,16 @@ class PlanBackward:
             pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=True, layout=L.WLAYOUT_CHUNK32)
         pw.pack()
         E.conv2d(dy_view.fd, pw, None, None, E.View(T).fd, E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32))
+        return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
+
+    def _prologue_backward(self, r, T, meta, grads, check_state=None):
+        """G[x] += backward of (pool?, activation, BatchNorm) applied to da = T."""
+        x, w = r["x"], r["w"]
+        p, cin = w.param, w.cin
+        n, hin, win = T.shape[0], T.shape[1], T.shape[2]
+        check = check_state is not None
+        if check:
+            rec, gx_before, dx_ref = check_state
         Tv = E.View(T, 0, cin)
         if meta["pool"]:
             T2 = E.new_act(n, 2 * hin, 2 * win, _r8(cin), p.device)

@@ -304,6 +304,12 @@ def conv_bwd_data_direct(dy_fd, weight, desc, dx):
                                                   dx.data_ptr(), n, h, w, stream_ptr()), "conv2d_bwd_data_direct")
 
 
+def conv_bwd_data_direct_nhwc(dy_fd, weight, desc, dx_view, cin):
+    """dx_view: NHWC bf16 view written for channels [0, cin); weight: fp32 (cout, cin, k, k)."""
+    L.check(L.load().fdgan_conv2d_bwd_data_direct_nhwc(C.byref(dy_fd), weight.data_ptr(), weight.shape[0], cin, C.byref(desc),
+                                                       C.byref(dx_view.fd), stream_ptr()), "conv2d_bwd_data_direct_nhwc")
+
+
 def out_act_bwd(dout, out, act, g_view):
     """g_view (NHWC bf16) <- dout * f'(out) for contiguous NCHW fp32 dout / out."""
     n, c, h, w = out.shape

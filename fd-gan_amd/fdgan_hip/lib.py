@@ -106,6 +106,8 @@ SIGNATURES = {
                                      C.c_void_p, C.POINTER(FdTensor), C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_data_direct": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_int, C.c_int, C.POINTER(FdConvDesc),
                                                C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_conv2d_bwd_data_direct_nhwc": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_int, C.c_int, C.POINTER(FdConvDesc),
+                                                    C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_out_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                     C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_grad_ew": (C.c_int, [C.c_int, C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),

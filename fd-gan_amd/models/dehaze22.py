@@ -12,7 +12,7 @@ import torch.nn as nn
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
 from fdgan_hip.netplan import ChanStats, NetPlan
-from models.dehaze1113 import _Named, _PlannedModule
+from models.dehaze1113 import _Named, _PlannedModule, _apply_plan_function, _plan_backward, _wants_grad
 
 
 def blockUNet(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
@@ -73,23 +73,53 @@ class D(_PlannedModule):
                pro=P.bn_prologue(l2.bn, s2, n * hs[2] * ws[2], act=L.ACT_LEAKY02), stats=s3 if l3.bn.training else None)
         P.conv(E.View(a3, 0, 4 * nf), P.weight(l4.conv.weight, 8 * nf, 4 * nf, 4), E.View(a4), 4, pad=1,
                pro=P.bn_prologue(l3.bn, s3, n * hs[3] * ws[3], act=L.ACT_LEAKY02), stats=s4 if l4.bn.training else None)
-        P.a4 = a4
+        P.a4, P.a1 = a4, a1
         P.w_last = P.weight(m.layer5.conv.weight, 1, 8 * nf, 4)
         P.last_desc = E.conv_desc(4, 1, 1, L.ACT_SIGMOID, False, cout=1)
         P.last_pro = P.bn_prologue(l4.bn, s4, n * hs[4] * ws[4], act=L.ACT_LEAKY02)
         P.keep += [s2, s3, s4, a1, a2, a3]
         return P.finish()
 
-    def forward(self, x):
+    def _run(self, x):
         P = self._plan_for(x)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("D backward through the HIP plan is not built yet; call under torch.no_grad()")
         with torch.no_grad():
             E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
             P.launch()
             out = torch.empty(P.out_shape, dtype=torch.float32, device=x.device)
             E.conv2d(E.View(P.a4, 0, 8 * self.nf).fd, P.w_last, None, P.last_pro, E.nchw_f32_view(out), P.last_desc)
-        return out
+        return P, out
+
+    def forward(self, x):
+        if _wants_grad(self, x):
+            return _apply_plan_function(self, x)
+        return self._run(x)[1]
+
+    def _autograd_forward(self, x):
+        P, out = self._run(x)
+        return out, (P, out, bool(x.requires_grad))
+
+    def _autograd_backward(self, state, dout):
+        """dehaze22.py:114-156 under autograd (train-mode BatchNorm).  The 4x4 stride-2 data gradients use the
+        any-stride direct kernel."""
+        P, out, need_dx = state
+        if not self.main.layer4.bn.training:
+            raise NotImplementedError("dehaze22.D backward is built for train-mode BatchNorm")
+        B = _plan_backward(P)
+        B.zero_()
+        n, _, h5, w5 = out.shape
+        g8 = E.new_act(n, h5, w5, 8, out.device)
+        E.out_act_bwd(dout, out, L.ACT_SIGMOID, E.View(g8))
+        grads = {}
+        last = dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,
+                    pro=E.prologue_without_side_effects(P.last_pro))
+        B.conv_backward(last, E.View(g8, 0, 1), grads)
+        B.run(grads, skip_dx_of={P.xin.data_ptr()})
+        dx = None
+        if need_dx:
+            dx = torch.empty((n, self.nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=out.device)
+            E.conv_bwd_data_direct(B.G(E.View(P.a1, 0, self.nf)).fd, self.main.layer1.conv.weight.detach().contiguous(),
+                                   E.conv_desc(4, 2, 1, cout=self.nf), dx)
+        return dx, grads
 
 
 def _legacy(name):

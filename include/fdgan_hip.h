@@ -244,6 +244,8 @@ int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
                                  float* dx, int64_t n, int64_t h, int64_t wd, FdStream stream);
+int fdgan_conv2d_bwd_data_direct_nhwc(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
+                                      const FdTensor* dx, FdStream stream);
 int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n, int64_t c, int64_t h, int64_t w, int act,
                       const FdTensor* g, FdStream stream);
 int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream);

@@ -676,3 +676,30 @@ def test_training_step_smoke():
     _ = ts.netD(fusion)
     with pytest.raises(RuntimeError, match="another forward"):
         y1.mean().backward()
+
+
+def test_dehaze22_d_backward():
+    """PatchGAN D (4x4 stride-2 convs: any-stride direct data gradient) under autograd vs the bf16-emulating oracle."""
+    from hiputil import emulate_bf16_operands
+    import models.dehaze22 as net22
+    from oracle import dehaze22_ref as o22
+    from oracle.detweights import det_input, fill_state_dict
+    od = o22.D(9, 36)
+    fill_state_dict(od, seed=2)
+    d = net22.D(9, 36)
+    d.load_state_dict(od.state_dict())
+    d = d.to(DEV)
+    emulate_bf16_operands(od)
+    x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0)
+    cot = det_input((2, 1, 6, 6), seed=5, lo=-1.0, hi=1.0)
+    xo = x.clone().requires_grad_(True)
+    (od(xo) * cot).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y = d(xg)
+    assert y.shape == (2, 1, 6, 6) and y.requires_grad
+    (y * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    rep = _grad_report(d, od)
+    rep["dx"] = rel_rms(xg.grad.cpu(), xo.grad)
+    _report("dehaze22_d_backward", rep)
+    assert max(rep.values()) < 0.12, rep
