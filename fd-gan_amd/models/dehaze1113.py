@@ -491,116 +491,43 @@ class D(_PlannedModule):
     def _forward_plan(self, x):
         """Runs the recorded forward; returns (plan, sigmoid map).  No autograd."""
         P = self._plan_for(x)
-        E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
-        P.launch()
-        out = torch.empty(P.out_shape, dtype=torch.float32, device=x.device)
-        E.conv2d(E.View(P.a4, 0, 8 * self.nf).fd, P.w_last, None, E.make_prologue(act=L.ACT_LEAKY02),
-                 E.nchw_f32_view(out), P.last_desc)
+        with torch.no_grad():
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
+            P.launch()
+            out = torch.empty(P.out_shape, dtype=torch.float32, device=x.device)
+            E.conv2d(E.View(P.a4, 0, 8 * self.nf).fd, P.w_last, None, E.make_prologue(act=L.ACT_LEAKY02),
+                     E.nchw_f32_view(out), P.last_desc)
         return P, out
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _DFunction.apply(self, x, *self._grad_params())
-        with torch.no_grad():
-            return self._forward_plan(x)[1]
+        if _wants_grad(self, x):
+            return _apply_plan_function(self, x)
+        return self._forward_plan(x)[1]
 
-    def _grad_params(self):
-        m = self.main
-        l2, l3 = m.layer2.layer2, m.layer3.layer3
-        return (m.layer1.conv.weight, l2.conv.weight, l2.bn.weight, l2.bn.bias, l3.conv.weight, l3.bn.weight, l3.bn.bias,
-                m.layer4.conv.weight, m.layer5.conv.weight)
+    def _autograd_forward(self, x):
+        P, out = self._forward_plan(x)
+        return out, (P, out, bool(x.requires_grad))
 
-    def _backward(self, P, out, dout, need_dx=True):
-        """Gradients of the forward just run on plan P (train-mode BatchNorm: batch statistics).
-        Returns (dx NCHW fp32, grads in `_grad_params` order).  dehaze1113.py:188-230 under autograd."""
+    def _autograd_backward(self, state, dout):
+        """dehaze1113.py:188-230 under autograd (train-mode BatchNorm): the recorded plan walked in reverse
+        (fdgan_hip/backward.py); the gradient w.r.t. the 9-channel input -- what the generator's adversarial loss
+        needs -- comes from the any-stride direct kernel (layer1 is 4x4 stride 2)."""
+        P, out, need_dx = state
         if not (self.main.layer2.layer2.bn.training and self.main.layer3.layer3.bn.training):
             raise NotImplementedError("D backward is built for train-mode BatchNorm (the reference never calls .eval())")
-        dev, nf, nc = out.device, self.nf, self.nc
-        r8 = lambda v: (v + 7) // 8 * 8
-        m = self.main
-        l2, l3 = m.layer2.layer2, m.layer3.layer3
+        B = _plan_backward(P)
+        B.zero_()
         n, _, h5, w5 = out.shape
-        a1, a2, a3, a4 = P.acts
-        _, h1, w1, _ = a1.shape
-        _, h4, w4, _ = a4.shape
-        CH = L.WLAYOUT_CHUNK32
-        lrelu = E.make_prologue(act=L.ACT_LEAKY02)
-        # backward prologues: the forward's batch statistics, no running-stat side effects
-        pro2 = E.make_prologue(act=L.ACT_LEAKY02, mean=P.s2.mean, var=P.s2.var, gamma=l2.bn.weight, beta=l2.bn.bias, eps=l2.bn.eps)
-        pro3 = E.make_prologue(act=L.ACT_LEAKY02, mean=P.s3.mean, var=P.s3.var, gamma=l3.bn.weight, beta=l3.bn.bias, eps=l3.bn.eps)
-        g5 = E.new_act(n, h5, w5, 8, dev)
-        d4 = E.new_act(n, h4, w4, r8(8 * nf), dev)
-        d3 = E.new_act(n, h1, w1, r8(4 * nf), dev)
-        d2 = E.new_act(n, h1, w1, r8(2 * nf), dev)
-        d1 = E.new_act(n, h1, w1, r8(nf), dev)
-        ws = torch.empty(512 * r8(4 * nf) * 2, dtype=torch.float32, device=dev)
-        if getattr(P, "_wgrad_ws", None) is None:
-            P._wgrad_ws = torch.empty(1 << 23, dtype=torch.float32, device=dev)      # split-K partials of the weight gradients
-        wws = P._wgrad_ws
-        W1, W2, W3, W4, W5 = (m.layer1.conv.weight, l2.conv.weight, l3.conv.weight, m.layer4.conv.weight, m.layer5.conv.weight)
-        grads = {id(p): torch.zeros_like(p) for p in self._grad_params()}
-        keep = []
-
-        def dgrad(dy_view, W, cout_f, cin_f, k, pad, dx_view):
-            pw = E.PackedWeight(W.detach().contiguous(), cin_f, cout_f, k, flip=True, layout=CH)   # cout' = cin, cin' = cout
-            pw.pack()
-            keep.append(pw)
-            E.conv2d(dy_view.fd, pw, None, None, dx_view.fd, E.conv_desc(k, 1, k - 1 - pad, cout=cin_f, w_layout=CH))
-
-        E.out_act_bwd(dout.detach().float().contiguous(), out, L.ACT_SIGMOID, E.View(g5))
-        # layer5: x = a4, LeakyReLU prologue, 4x4 s1 p1 -> 1 channel
-        if W5.requires_grad:
-            E.conv_bwd_weight(E.View(a4, 0, 8 * nf).fd, lrelu, E.View(g5, 0, 1).fd, E.conv_desc(4, 1, 1, cout=1), grads[id(W5)], None, wws)
-        dgrad(E.View(g5, 0, 1), W5, 1, 8 * nf, 4, 1, E.View(d4))
-        E.bn_act_bwd(E.View(d4, 0, 8 * nf).fd, E.View(a4, 0, 8 * nf).fd, lrelu)
-        # layer4: x = a3, BatchNorm(layer3.bn) + LeakyReLU prologue, 4x4 s1 p1
-        if W4.requires_grad:
-            E.conv_bwd_weight(E.View(a3, 0, 4 * nf).fd, pro3, E.View(d4, 0, 8 * nf).fd, E.conv_desc(4, 1, 1, cout=8 * nf), grads[id(W4)], None, wws)
-        dgrad(E.View(d4, 0, 8 * nf), W4, 8 * nf, 4 * nf, 4, 1, E.View(d3))
-        v3, x3 = E.View(d3, 0, 4 * nf), E.View(a3, 0, 4 * nf)
-        rows, cpad = E.bn_act_bwd(v3.fd, x3.fd, pro3, ws)
-        E.bn_bwd_finalize(ws, rows, cpad, 4 * nf, grads[id(l3.bn.weight)], grads[id(l3.bn.bias)])
-        E.bn_bwd_apply(v3.fd, x3.fd, pro3, grads[id(l3.bn.weight)], grads[id(l3.bn.bias)], v3.fd)
-        # layer3: x = a2, BatchNorm(layer2.bn) + LeakyReLU prologue, 3x3 s1 p1
-        if W3.requires_grad:
-            E.conv_bwd_weight(E.View(a2, 0, 2 * nf).fd, pro2, v3.fd, E.conv_desc(3, 1, 1, cout=4 * nf), grads[id(W3)], None, wws)
-        dgrad(v3, W3, 4 * nf, 2 * nf, 3, 1, E.View(d2))
-        v2, x2 = E.View(d2, 0, 2 * nf), E.View(a2, 0, 2 * nf)
-        rows, cpad = E.bn_act_bwd(v2.fd, x2.fd, pro2, ws)
-        E.bn_bwd_finalize(ws, rows, cpad, 2 * nf, grads[id(l2.bn.weight)], grads[id(l2.bn.bias)])
-        E.bn_bwd_apply(v2.fd, x2.fd, pro2, grads[id(l2.bn.weight)], grads[id(l2.bn.bias)], v2.fd)
-        # layer2: x = a1, LeakyReLU prologue, 3x3 s1 p1
-        if W2.requires_grad:
-            E.conv_bwd_weight(E.View(a1, 0, nf).fd, lrelu, v2.fd, E.conv_desc(3, 1, 1, cout=2 * nf), grads[id(W2)], None, wws)
-        dgrad(v2, W2, 2 * nf, nf, 3, 1, E.View(d1))
-        v1 = E.View(d1, 0, nf)
-        E.bn_act_bwd(v1.fd, E.View(a1, 0, nf).fd, lrelu)
-        # layer1: x = the input image, no prologue, 4x4 s2 p1
-        if W1.requires_grad:
-            E.conv_bwd_weight(E.View(P.xin, 0, nc).fd, None, v1.fd, E.conv_desc(4, 2, 1, cout=nf), grads[id(W1)], None, wws)
+        g8 = E.new_act(n, h5, w5, 8, out.device)
+        E.out_act_bwd(dout, out, L.ACT_SIGMOID, E.View(g8))
+        grads = {}
+        last = dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,
+                    pro=E.make_prologue(act=L.ACT_LEAKY02))
+        B.conv_backward(last, E.View(g8, 0, 1), grads)
+        B.run(grads, skip_dx_of={P.xin.data_ptr()})
         dx = None
-        if need_dx:      # only the generator's adversarial path needs the gradient w.r.t. D's input
-            dx = torch.empty((n, nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=dev)
-            E.conv_bwd_data_direct(v1.fd, W1.detach().contiguous(), E.conv_desc(4, 2, 1, cout=nf), dx)
-        torch.cuda.current_stream().synchronize()   # the temporaries above must outlive the launches
-        self._last_act_grads = (d1, d2, d3, d4)    # dL/d(conv outputs), NHWC bf16 (kept for the parity tests)
-        return dx, tuple(grads[id(p)] for p in self._grad_params())
-
-
-class _DFunction(torch.autograd.Function):
-    """autograd bridge of D: forward = the recorded HIP plan, backward = D._backward."""
-
-    @staticmethod
-    def forward(ctx, module, x, *params):
-        P, out = module._forward_plan(x)
-        ctx.module, ctx.plan = module, P
-        ctx.gen = _bump_generation(P)
-        ctx.save_for_backward(out)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        _check_generation(ctx.plan, ctx.gen)
-        (out,) = ctx.saved_tensors
-        dx, grads = ctx.module._backward(ctx.plan, out, dout, need_dx=ctx.needs_input_grad[1])
-        return (None, dx) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))
+        if need_dx:
+            dx = torch.empty((n, self.nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=out.device)
+            E.conv_bwd_data_direct(B.G(E.View(P.acts[0], 0, self.nf)).fd, self.main.layer1.conv.weight.detach().contiguous(),
+                                   E.conv_desc(4, 2, 1, cout=self.nf), dx)
+        return dx, grads
