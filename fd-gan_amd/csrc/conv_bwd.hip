@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
   const int tid = threadIdx.x;
   const int grp = tid & 7, slot = tid >> 3;   // 8 channel groups (64 channels) x 32 pixels per pass
   const long long HW = (long long)a.H * a.W;
-  for (int c8_0 = 0; c8_0 < a.C8; c8_0 += 8) {
+  {   // one 64-channel chunk per blockIdx.y: the per-channel setup is paid once per workgroup
+    const int c8_0 = blockIdx.y * 8;
     const int c8 = c8_0 + grp;
     const bool cok = c8 < a.C8;
     float sc[8], sh[8], xm[8], xr[8];
@@ -424,25 +425,38 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
       }
     }
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long p = (long long)blockIdx.x * 32 + slot; p < a.P; p += (long long)gridDim.x * 32) {
-      if (!cok) continue;
-      const long long n = p / HW, r = p - n * HW;
-      const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-      unsigned short* dp = a.da + n * a.da_sn + (long long)y * a.da_sh + (long long)xx * a.da_sw + c8 * 8;
-      const u32x4 dv = *reinterpret_cast<const u32x4*>(dp);
-      const u32x4 xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
-      const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dv), f32x8);
-      const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv), f32x8);
-      f32x8 o;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long p0 = (long long)blockIdx.x * 32 + slot; cok && p0 < a.P; p0 += 4 * stride) {   // 4 pixels in flight
+      u32x4 dvv[4], xvv[4];
+      unsigned short* dp[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pre = fmaf(xf[e], sc[e], sh[e]);
-        const float gsl = pre > 0.f ? 1.f : a.slope;   // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
-        o[e] = d[e] * gsl;
-        s1[e] += o[e];
-        s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
+      for (int k = 0; k < 4; ++k) {
+        const long long p = p0 + k * stride;
+        dp[k] = nullptr;
+        if (p < a.P) {
+          const long long n = p / HW, r = p - n * HW;
+          const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+          dp[k] = a.da + n * a.da_sn + (long long)y * a.da_sh + (long long)xx * a.da_sw + c8 * 8;
+          dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
+          xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+        }
       }
-      *reinterpret_cast<u32x4*>(dp) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (dp[k] == nullptr) continue;
+        const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dvv[k]), f32x8);
+        const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xvv[k]), f32x8);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pre = fmaf(xf[e], sc[e], sh[e]);
+          const float gsl = pre > 0.f ? 1.f : a.slope;   // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
+          o[e] = d[e] * gsl;
+          s1[e] += o[e];
+          s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
+        }
+        *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+      }
     }
     if (a.partial != nullptr) {
       __syncthreads();
@@ -523,9 +537,9 @@ struct BnApplyArgs {
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
   const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
   const long long HW = (long long)a.H * a.W;
-  for (int c8_0 = 0; c8_0 < a.C8; c8_0 += 8) {
-    const int c8 = c8_0 + grp;
-    if (c8 >= a.C8) continue;
+  {   // one 64-channel chunk per blockIdx.y
+    const int c8 = blockIdx.y * 8 + grp;
+    if (c8 >= a.C8) return;
     float A[8], B[8], Cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -538,22 +552,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
         Cc[e] = -A[e] * a.dbeta[c] * a.inv_m - B[e] * a.mean[c];
       }
     }
-    for (long long p = (long long)blockIdx.x * 32 + slot; p < a.P; p += (long long)gridDim.x * 32) {
-      const long long n = p / HW, r = p - n * HW;
-      const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-      const f32x8 d = __builtin_convertvector(
-          __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8)), f32x8);
-      const f32x8 xf = __builtin_convertvector(
-          __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8)), f32x8);
-      unsigned short* op = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
-      f32x8 o;
-      if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(op)), f32x8);
+    // four pixels per iteration: 8-12 independent 16-byte loads in flight per thread (the single-pixel loop ran
+    // at 2.7 TB/s of its 4-tensor traffic)
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long p0 = (long long)blockIdx.x * 32 + slot; p0 < a.P; p0 += 4 * stride) {
+      u32x4 dv[4], xv[4], gv[4];
+      unsigned short* op[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = fmaf(A[e], d[e], fmaf(B[e], xf[e], Cc[e]));
-        o[e] = a.accumulate ? o[e] + v : v;
+      for (int k = 0; k < 4; ++k) {
+        const long long p = p0 + k * stride;
+        op[k] = nullptr;
+        if (p < a.P) {
+          const long long n = p / HW, r = p - n * HW;
+          const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+          dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8);
+          xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+          op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+          if (a.accumulate) gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
+        }
       }
-      *reinterpret_cast<u32x4*>(op) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (op[k] == nullptr) continue;
+        const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dv[k]), f32x8);
+        const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[k]), f32x8);
+        f32x8 o;
+        if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaf(A[e], d[e], fmaf(B[e], xf[e], Cc[e]));
+          o[e] = a.accumulate ? o[e] + v : v;
+        }
+        *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+      }
     }
   }
 }
@@ -824,12 +855,16 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
   fill_pro(pro, a.pro_mode, a.slope, a.eps, a.mean, a.var, a.gamma, a.beta);
   a.cpad = a.C8 * 8;
   long long rows = (a.P + 31) / 32;
-  if (rows > 512) rows = 512;
+  static const char* cap_env = getenv("FDGAN_DEBUG_BN_ROWS");   // experiment aid
+  const long long chunks = (a.C8 + 7) / 8;                      // 64-channel chunks -> gridDim.y
+  long long cap = (cap_env ? atoll(cap_env) : 512) / chunks;    // ~2 workgroups per CU in total measured best
+  if (cap < 16) cap = 16;
+  if (rows > cap) rows = cap;
   a.partial = (a.pro_mode == 2) ? partial : nullptr;
   if (a.partial) FD_REQUIRE(rows * a.cpad * 2 <= capacity_floats, "bn_act_bwd: workspace too small (%lld floats needed)", rows * a.cpad * 2);
   if (rows_out) *rows_out = rows;
   if (cpad_out) *cpad_out = a.cpad;
-  return fd_launch(&bn_act_bwd_kernel, "bn_act_bwd", dim3((unsigned)rows), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+  return fd_launch(&bn_act_bwd_kernel, "bn_act_bwd", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
@@ -863,8 +898,12 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.dbeta = dbeta, a.dgamma = dgamma;
   a.accumulate = accumulate;
   long long rows = (a.P + 31) / 32;
-  if (rows > 2048) rows = 2048;
-  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)rows), dim3(256), 0, a,
+  static const char* cap_env = getenv("FDGAN_DEBUG_BN_ROWS");   // experiment aid
+  const long long chunks = (a.C8 + 7) / 8;
+  long long cap = (cap_env ? atoll(cap_env) : 512) / chunks;
+  if (cap < 16) cap = 16;
+  if (rows > cap) rows = cap;
+  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
 
