@@ -52,15 +52,16 @@ struct WgradArgs {
   float* dw;                  // [Cout][Cin][ks][ks] fp32 (nsplit == 1) or [nsplit][Cout][Cin][ks][ks] partials
   float* dbias;               // [Cout] or NULL ([nsplit][Cout] partials when nsplit > 1)
   int pool;                   // 2x2 average of the activated input (1x1 convs): x is the full-resolution tensor
-  int nsplit;                 // pixel splits (blockIdx.z = tap * nsplit + split); partials summed by wgrad_reduce
+  int nsplit;                 // pixel splits; partials summed by wgrad_reduce
   long long split_px;         // pixels per split (multiple of 32)
+  int tiles_ci, tiles_co;     // 1-D grid: work item -> (split, tap, cout tile, cin tile), cin tile fastest
+  int dbg_skip;               // FDGAN_DEBUG_PHASES (results wrong): 1 no global loads, 2 no LDS stores, 4 no fragment reads / MFMAs
 };
 
-__device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s, const float* sh_s, long long p, long long HW,
-                                          int ky, int kx, int ci_off, bool x_ok) {
+__device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s, const float* sh_s, long long n, int oy, int ox,
+                                          int ky, int kx, int ci_off, bool x_ok, bool& raw) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const long long n = p / HW, r = p - n * HW;
-  const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
+  raw = false;
   const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
   if (!x_ok) return zero4;
   if (a.pool) {   // 1x1 conv on the 2x2 average of the activated input (transition / skip pooling)
@@ -72,28 +73,32 @@ __device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s
     return fd_pack8(f * 0.25f);
   }
   if (iy < 0 || iy >= a.Hs || ix < 0 || ix >= a.Ws) return zero4;   // zero padding of the activated input
-  const u32x4 xv = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci_off);
-  return a.pro_mode != 0 ? fd_xform8(xv, sc_s, sh_s, a.p_slope) : xv;
+  raw = a.pro_mode != 0;   // transformed by the caller just before the LDS store (keeps the load in flight over the MFMAs)
+  return *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci_off);
 }
 
-// 4 pixels x 8 channels (one u32x4 per pixel) -> 8 x (4 pixels of one channel), written to rows ch0 .. ch0+7
+// 4 k-entries x 8 channels (one u32x4 per entry) -> 8 x (4 entries of one channel), written to rows ch0 .. ch0+7.
+// The 16-byte column of a row is XORed with the row's chunk index ((row >> 3) & 7): adjacent lanes hold adjacent
+// chunks (rows 8 apart = 32 banks apart at this pitch), and the swizzle spreads them over the banks.
 __device__ __forceinline__ void wg_store_transposed(char* tile, int ch0, int px4, const u32x4 (&v)[4]) {
+  const int col = (((px4 >> 1) ^ ((ch0 >> 3) & 7)) << 4) | ((px4 & 1) << 3);
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    // dword d holds channels 2d (low half) and 2d+1 (high half) of each pixel
+    // dword d holds channels 2d (low half) and 2d+1 (high half) of each entry
     const unsigned lo01 = __builtin_amdgcn_perm(v[1][d], v[0][d], 0x05040100u), lo23 = __builtin_amdgcn_perm(v[3][d], v[2][d], 0x05040100u);
     const unsigned hi01 = __builtin_amdgcn_perm(v[1][d], v[0][d], 0x07060302u), hi23 = __builtin_amdgcn_perm(v[3][d], v[2][d], 0x07060302u);
-    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d) * WG_ROWB + px4 * 8) = u32x2{lo01, lo23};
-    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d + 1) * WG_ROWB + px4 * 8) = u32x2{hi01, hi23};
+    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d) * WG_ROWB + col) = u32x2{lo01, lo23};
+    *reinterpret_cast<u32x2*>(tile + (ch0 + 2 * d + 1) * WG_ROWB + col) = u32x2{hi01, hi23};
   }
 }
 
 // T = 64: workgroup tile 64 cout x 64 cin (wave 32 x 32); T = 128: 128 x 128 (wave 64 x 64, 4x the MFMA work for
 // 2x the staging: the 1x1 bottleneck / transition shapes, whose dy would otherwise be re-staged by 16 cin tiles).
-template <int T>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int NT = T / 32;              // MFMA tiles per wave in each direction (2 or 4)
-  constexpr int UPT = T / 64;             // staging units (4 pixels x 8 channels) per thread and operand
+template <int T, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NTM = T / 32;             // MFMA tiles per wave along cout (2 waves along cout)
+  constexpr int NTN = T / (NW / 2) / 16;  // ... along cin (NW / 2 waves along cin)
+  constexpr int UPT = T / (16 * NW);      // staging units (4 pixels x 8 channels) per thread and operand
   constexpr int TILE_B = T * WG_ROWB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* At = lds;                         // [T ci][128 px]
@@ -102,7 +107,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   float* sh_s = sc_s + T;
   float* bsum = sh_s + T;                 // [32][T] (dbias only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ci0 = blockIdx.x * T, co0 = blockIdx.y * T, tap = (int)blockIdx.z / a.nsplit, split = (int)blockIdx.z % a.nsplit;
+  // workgroups are dealt to the 8 XCDs round-robin: renumber so that the tiles of one pixel split -- which read the
+  // same dy / x pixels -- run on ONE XCD back to back and share its L2 (otherwise every tile pulls its operands
+  // through a different L2: (Cin / T) x the dy traffic, (Cout / T) x the x traffic on the fabric)
+  int item = blockIdx.x;
+  {
+    const int per_xcd = gridDim.x >> 3;
+    if (item < per_xcd * 8 && !(a.dbg_skip & 8)) item = (item & 7) * per_xcd + (item >> 3);
+  }
+  const int tci = item % a.tiles_ci;
+  int rest = item / a.tiles_ci;
+  const int tco = rest % a.tiles_co;
+  rest /= a.tiles_co;
+  const int kk_ = a.ks * a.ks, tap = rest % kk_, split = rest / kk_;
+  const int ci0 = tci * T, co0 = tco * T;
   const int ky = tap / a.ks, kx = tap - ky * a.ks;
   // per-channel scale / shift of this cin tile (BatchNorm fold, as fd_fold_bn but without side effects)
   if (tid < T) {
@@ -120,22 +138,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     sh_s[tid] = sh;
   }
   __syncthreads();
-  // staging map: a 16-lane group shares the channel chunk and covers 16 consecutive 4-pixel groups, so its
-  // ds_write_b64 are 128 contiguous bytes of one row; a wave covers 4 chunks = 64 contiguous bytes per pixel
-  const int chunk0 = (tid >> 4) & 7, px4 = (tid & 15) | ((tid >> 7) << 4);   // 8 chunks x 32 pixel groups; unit u adds 8 chunks
-  const bool want_bias = a.dbias != nullptr && tap == 0 && blockIdx.x == 0;
+  // staging map: adjacent lanes take adjacent 8-channel chunks of one pixel (T / 8 lanes = one whole 128- or 256-byte
+  // run per pixel; the first version gave a wave 64-byte pieces of 16 pixels 2 KB apart and spent 350 of its 410 us
+  // waiting for them).  The k order inside a step is free as long as both operands agree: entry 4 q + j of a step is
+  // pixel 32 j + q, so load j of a wave covers consecutive pixels.
+  constexpr int CH = T / 8;
+  static_assert(64 * NW == 4 * T, "one staging unit per thread and operand");
+  const int chunk0 = tid % CH, px4 = tid / CH;
+  constexpr int CHUNK_STEP = 0;
+  const bool want_bias = a.dbias != nullptr && tap == 0 && tci == 0;
   float bs[UPT][8];
 #pragma unroll
   for (int u = 0; u < UPT; ++u)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[u][e] = 0.f;
-  const int wco = (wave & 1) * (T / 2), wci = (wave >> 1) * (T / 2);
+  const int wco = (wave & 1) * (T / 2), wci = (wave >> 1) * (NTN * 16);
   const int m = lane & 15, g = lane >> 4;
-  f32x4 acc[NT][NT];
+  f32x4 acc[NTM][NTN];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NTM; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long long HW = (long long)a.Ho * a.Wo;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
@@ -143,23 +166,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
   // software pipeline: the global loads of step s+1 are in flight while the MFMAs of step s run
   u32x4 dv[UPT][4], xv[UPT][4];
+  // (image, row, column) of this thread's first pixel, advanced by 128 per step: the 64-bit divisions of the
+  // first version (two per pixel and operand) cost more VALU time than the transposition itself
+  int q_n, q_oy, q_ox;
+  {
+    const long long p = p_begin + px4;
+    const long long n = p / HW, r = p - n * HW;
+    q_n = (int)n, q_oy = (int)(r / a.Wo), q_ox = (int)(r - (long long)q_oy * a.Wo);
+  }
+  unsigned xraw = 0;   // bit (4 u + j): xv[u][j] still needs the prologue transform
   auto load_step = [&](long long p0) __attribute__((always_inline)) {
+    xraw = 0;
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) {
-      const int chunk = chunk0 + 8 * u;
-      const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
+    for (int j = 0; j < 4; ++j) {
+      const long long p = p0 + 32 * j + px4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const long long p = p0 + px4 * 4 + j;
+      for (int u = 0; u < UPT; ++u) {
+        const int chunk = chunk0 + CHUNK_STEP * u;
+        const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
         dv[u][j] = zero4, xv[u][j] = zero4;
-        if (p < p_end) {
-          if (dy_ok) {
-            const long long n = p / HW, r = p - n * HW;
-            const int oy = (int)(r / a.Wo), ox = (int)(r - (long long)oy * a.Wo);
-            dv[u][j] = *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + co0 + chunk * 8);
-          }
-          xv[u][j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, p, HW, ky, kx, ci0 + chunk * 8, x_ok);
+        if (p < p_end && !(a.dbg_skip & 1)) {
+          if (dy_ok) dv[u][j] = *reinterpret_cast<const u32x4*>(a.dy + (long long)q_n * a.dy_sn + (long long)q_oy * a.dy_sh + (long long)q_ox * a.dy_sw + co0 + chunk * 8);
+          bool raw;
+          xv[u][j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, q_n, q_oy, q_ox, ky, kx, ci0 + chunk * 8, x_ok, raw);
+          if (raw) xraw |= 1u << (u * 4 + j);
         }
+      }
+      q_ox += 32;   // the position of pixel p + 32 (after j = 3: this thread's first pixel of the next step)
+      while (q_ox >= a.Wo) {
+        q_ox -= a.Wo;
+        if (++q_oy == a.Ho) q_oy = 0, ++q_n;
       }
     }
   };
@@ -173,34 +209,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) bs[u][e] += __uint_as_float(((dv[u][j][e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
     __syncthreads();   // previous step's fragments consumed
+    if (!(a.dbg_skip & 2))
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
-      wg_store_transposed(At, (chunk0 + 8 * u) * 8, px4, xv[u]);
-      wg_store_transposed(Dt, (chunk0 + 8 * u) * 8, px4, dv[u]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (xraw & (1u << (u * 4 + j))) xv[u][j] = fd_xform8(xv[u][j], sc_s + (chunk0 + CHUNK_STEP * u) * 8, sh_s + (chunk0 + CHUNK_STEP * u) * 8, a.p_slope);
+      wg_store_transposed(At, (chunk0 + CHUNK_STEP * u) * 8, px4, xv[u]);
+      wg_store_transposed(Dt, (chunk0 + CHUNK_STEP * u) * 8, px4, dv[u]);
     }
     __syncthreads();
     if (p0 + WG_KPX < p_end) load_step(p0 + WG_KPX);
+    if (!(a.dbg_skip & 4))
 #pragma unroll
     for (int sub = 0; sub < WG_KPX / 32; ++sub) {
-      bf16x8 af[NT], bf[NT];
+      bf16x8 af[NTM], bf[NTN];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // A: rows = cout
-        bf[i] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + i * 16 + m) * WG_ROWB + sub * 64 + g * 16));   // B: cols = cin
-      }
+      for (int i = 0; i < NTM; ++i)
+        af[i] = __builtin_bit_cast(bf16x8, lds_read16(Dt + (wco + i * 16 + m) * WG_ROWB + (((sub * 4 + g) ^ (((wco + i * 16 + m) >> 3) & 7)) << 4)));   // A: rows = cout
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NTN; ++j)
+        bf[j] = __builtin_bit_cast(bf16x8, lds_read16(At + (wci + j * 16 + m) * WG_ROWB + (((sub * 4 + g) ^ (((wci + j * 16 + m) >> 3) & 7)) << 4)));   // B: cols = cin
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NTM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   }
   // D layout: column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout
   const int kk = a.ks * a.ks;
   float* dwp = a.dw + (long long)split * a.Cout * a.Cin * kk;
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NTM; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wco + i * 16 + g * 4 + r, ci = ci0 + wci + j * 16 + m;
@@ -211,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int u = 0; u < UPT; ++u)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bsum[px4 * T + (chunk0 + 8 * u) * 8 + e] = bs[u][e];
+      for (int e = 0; e < 8; ++e) bsum[px4 * T + (chunk0 + CHUNK_STEP * u) * 8 + e] = bs[u][e];
     __syncthreads();
     if (tid < T && co0 + tid < a.Cout) {
       float t = 0.f;
@@ -373,12 +415,31 @@ struct WredArgs {
   long long numel;
   int nsplit, accumulate;
 };
+// 64 outputs x 4 split lanes per workgroup, eight loads in flight per thread, fixed summation order.  (One thread
+// per output walking all splits took 80 us for 256 splits of a 128 x 224 filter: a quarter of that layer's backward.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.numel) return;
+  __shared__ float sh[4][64];
+  const int col = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + col;
   float t = 0.f;
-  for (int s_ = 0; s_ < a.nsplit; ++s_) t += a.part[(long long)s_ * a.numel + i];
-  a.out[i] = a.accumulate ? a.out[i] + t : t;
+  if (i < a.numel) {
+    const float* src = a.part + i;
+    int s_ = ty;
+    for (; s_ + 28 < a.nsplit; s_ += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[(long long)(s_ + 4 * k) * a.numel];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
+    }
+    for (; s_ < a.nsplit; s_ += 4) t += src[(long long)s_ * a.numel];
+  }
+  sh[ty][col] = t;
+  __syncthreads();
+  if (ty == 0 && i < a.numel) {
+    t = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+    a.out[i] = a.accumulate ? a.out[i] + t : t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,6 +823,22 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
+  // the dense-layer growth conv, transpose-read kernel (conv_wgrad_tr.hip)
+  if (workspace != nullptr && dbias == nullptr && conv_wgrad3x3_tr_fits(cout, a.Cin, d->ksize, d->stride, d->pad, pool)) {
+    WgradRowsArgs w{};
+    w.x = a.x, w.x_sn = a.x_sn, w.x_sh = a.x_sh, w.x_sw = a.x_sw;
+    w.dy = a.dy, w.dy_sn = a.dy_sn, w.dy_sh = a.dy_sh, w.dy_sw = a.dy_sw;
+    w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin;
+    w.pro_mode = a.pro_mode, w.p_slope = a.p_slope, w.eps = a.eps;
+    w.p_mean = a.p_mean, w.p_var = a.p_var, w.p_gamma = a.p_gamma, w.p_beta = a.p_beta;
+    w.part = workspace;
+    long long items = 0;
+    hipStream_t stt = static_cast<hipStream_t>(stream);
+    if (int rc = conv_wgrad3x3_tr_launch(w, x->n, workspace_floats, &items, stt)) return rc;
+    const long long numel3 = 32LL * a.Cin * 9;
+    WredArgs r3{workspace, dw, numel3, (int)items, accumulate};
+    return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 63) / 64)), dim3(256), 0, r3, stt);
+  }
   // the dense-layer growth conv: all nine taps in one workgroup
   if (workspace != nullptr && dbias == nullptr && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !pool && cout <= 32 &&
       a.Cin % 32 == 0 && a.Ws % 4 == 0 && getenv("FDGAN_DEBUG_NO_WGRAD3") == nullptr) {
@@ -794,19 +871,20 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
                           W3_XS_B + W3_DT_B + 256, w, st3);
       if (rc3 != FD_OK) return rc3;
       WredArgs r3{workspace, dw, numel3, (int)(strips * segs), accumulate};
-      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 255) / 256)), dim3(256), 0, r3, st3);
+      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 63) / 64)), dim3(256), 0, r3, st3);
     }
   }
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
-  // workgroup tile edge.  The 128 x 128 instantiation (4x the MFMA work per 2x staging) measured SLOWER on the
-  // training step (91.3 vs 87.2 ms): half the workgroups per CU and twice the serial staging per step; tuning aid only
-  static const bool big = getenv("FDGAN_DEBUG_WGRAD_T128") != nullptr;
-  const int T = (big && cout >= 128 && a.Cin >= 128) ? 128 : 64;
+  // workgroup tile: 64 x 64 with 4 waves, or 128 x 128 with 8 waves (half the L2 -> LDS traffic per flop: the 64-tile
+  // kernel runs at the ~5 TB/s its operand re-reads can be served at) when both channel counts fill it
+  static const char* tsel = getenv("FDGAN_DEBUG_WGRAD_T");   // tuning aid: force 64 / 128
+  const bool fits128 = cout >= 96 && a.Cin >= 96 && (cout % 128 == 0 || cout % 128 > 64) && (a.Cin % 128 == 0 || a.Cin % 128 > 32);
+  const int T = tsel ? atoi(tsel) : (fits128 ? 128 : 64);
   const long long base = (long long)((a.Cin + T - 1) / T) * ((cout + T - 1) / T) * d->ksize * d->ksize;
-  // split the pixel axis until ~768 workgroups exist (one pass over all pixels per workgroup otherwise)
+  // split the pixel axis until ~768 (T = 64: 3-4 resident per CU) / ~512 (T = 128: 2 per CU) workgroups exist
   long long nsplit = 1;
   if (workspace != nullptr) {
-    nsplit = 768 / base;
+    nsplit = (T == 128 ? 512 : 768) / base;
     const long long max_by_px = (a.P + 2047) / 2048;
     if (nsplit > max_by_px) nsplit = max_by_px;
     const long long per = numel + (dbias ? cout : 0);
@@ -816,28 +894,31 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   FD_REQUIRE(workspace != nullptr || !accumulate, "conv2d_bwd_weight: accumulate needs a workspace");
   const bool direct = workspace == nullptr;
   FD_REQUIRE(direct || numel + (dbias ? cout : 0) <= workspace_floats, "conv2d_bwd_weight: workspace too small (%lld floats)", numel + cout);
+  static const char* ph = getenv("FDGAN_DEBUG_PHASES");
+  a.dbg_skip = ph ? atoi(ph) : 0;
   a.nsplit = (int)nsplit;
   a.split_px = ((a.P + nsplit - 1) / nsplit + WG_KPX - 1) / WG_KPX * WG_KPX;
   a.dw = direct ? dw : workspace;
   a.dbias = dbias ? (direct ? dbias : workspace + nsplit * numel) : nullptr;
-  dim3 grid((unsigned)((a.Cin + T - 1) / T), (unsigned)((cout + T - 1) / T), (unsigned)(d->ksize * d->ksize * nsplit));
+  a.tiles_ci = (a.Cin + T - 1) / T, a.tiles_co = (cout + T - 1) / T;
+  dim3 grid((unsigned)(base * nsplit));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned lds = 2u * T * WG_ROWB + 2u * T * 4 + (dbias ? 32u * T * 4 : 0u);
   static bool attr128 = false;
   if (T == 128 && !attr128) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_wgrad<128>): %s", hipGetErrorString(e));
     attr128 = true;
   }
-  int rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128>, "conv_wgrad_t128", grid, dim3(256), lds, a, st)
-                    : fd_launch(&conv_wgrad_kernel<64>, "conv_wgrad", grid, dim3(256), lds, a, st);
+  int rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128, 8>, "conv_wgrad_t128", grid, dim3(512), lds, a, st)
+                    : fd_launch(&conv_wgrad_kernel<64, 4>, "conv_wgrad", grid, dim3(256), lds, a, st);
   if (rc != FD_OK || direct) return rc;
   WredArgs r{workspace, dw, numel, (int)nsplit, accumulate};
-  rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, r, st);
+  rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, st);
   if (rc != FD_OK || !dbias) return rc;
   WredArgs rb{workspace + nsplit * numel, dbias, cout, (int)nsplit, accumulate};
-  return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, rb, st);
+  return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, rb, st);
 }
 
 extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,

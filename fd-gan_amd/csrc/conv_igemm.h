@@ -678,6 +678,24 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
                      long long stats_cap, bool dry, hipStream_t stream);
 bool conv3x3_pw_fits(int cout_total, int cin);
 bool conv3x3_rs_fits(const ConvArgs& a, int cout_total);
+// weight gradient of the growth conv, rows staged in their memory layout and read with ds_read_b64_tr_b16 (conv_wgrad_tr.hip)
+struct WgradRowsArgs {
+  const unsigned short* x;       // raw forward input (NHWC bf16 view)
+  long long x_sn;
+  int x_sh, x_sw;
+  const unsigned short* dy;      // gradient of the conv output (NHWC bf16 view, 32 channels)
+  long long dy_sn;
+  int dy_sh, dy_sw;
+  int H, W, Cin;
+  int xblocks, seg_rows, segs;   // column blocks per image; rows per work item; row segments per (image, block)
+  int pro_mode;
+  float p_slope, eps;
+  const float *p_mean, *p_var, *p_gamma, *p_beta;
+  float* part;                   // [items][32][Cin][9] partial sums, reduced by wgrad_reduce
+};
+bool conv_wgrad3x3_tr_fits(int cout, int cin, int ksize, int stride, int pad, bool pool);
+int conv_wgrad3x3_tr_launch(WgradRowsArgs& a, long long nimg, long long workspace_floats, long long* items_out, hipStream_t stream);
+
 int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream);
 int conv_dispatch_k3_pw(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,

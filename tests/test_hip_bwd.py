@@ -212,9 +212,11 @@ def test_gradient_plumbing_kernels(E):
         assert float(g[..., cc:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 32, 21, 40), (2, 256, 24, 9, 132), (1, 64, 32, 64, 64), (2, 128, 32, 5, 8)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 32, 21, 40), (2, 256, 24, 9, 132), (1, 64, 32, 64, 64), (2, 128, 32, 5, 8),
+                                             (2, 256, 32, 9, 132), (1, 128, 32, 70, 64), (1, 128, 32, 3, 100)])
 def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
-    """conv_wgrad3x3 (growth-conv shape: 3x3 s1 p1, Cout <= 32, Cin % 32 == 0): ragged column blocks, several
+    """conv_wgrad3x3_tr (32 filters, Cin % 128 == 0: transpose-read kernel) and conv_wgrad3x3 (Cout <= 32,
+    Cin % 32 == 0), the growth-conv shape 3x3 s1 p1: ragged column blocks, several
     row segments, rows above / below the image, against torch on identical bf16 operands; also equal (up to
     summation order) to the per-tap kernel."""
     import os

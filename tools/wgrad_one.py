@@ -1,0 +1,28 @@
+"""Time one weight-gradient shape (experiment aid): python tools/wgrad_one.py HW CIN COUT KS [CT]"""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "fd-gan_amd"))
+from fdgan_hip import engine as E, lib as L
+hw, cin, cout, ks = [int(v) for v in sys.argv[1:5]]
+ct = int(sys.argv[5]) if len(sys.argv) > 5 else cin
+N = 16
+dev = "cuda"
+x = torch.randn(N, hw, hw, ct, device=dev).bfloat16()
+pad = ks // 2 if ks == 3 else 0
+ho = hw + 2 * pad - ks + 1
+dy = torch.randn(N, ho, ho, cout, device=dev).bfloat16()
+xv, dv = E.View(x, 0, cin), E.View(dy, 0, cout)
+mean = torch.zeros(cin, device=dev); var = torch.ones(cin, device=dev); gamma = torch.ones(cin, device=dev); beta = torch.zeros(cin, device=dev)
+pro = E.make_prologue(mean=mean, var=var, gamma=gamma, beta=beta, act=1)
+desc = L.FdConvDesc(ks, 1, pad, 0, 0, cout, 0)
+dw = torch.zeros(cout, cin, ks, ks, device=dev)
+ws = torch.empty(64 << 20, device=dev)
+def run(): E.conv_bwd_weight(xv.fd, pro, dv.fd, desc, dw, None, ws, False)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 10 * 1e3
+fl = 2.0 * N * ho * ho * cin * cout * ks * ks
+print(f"hw {hw} {cin}->{cout} k{ks}: {t:8.1f} us  {fl/t/1e6:7.1f} TFLOP/s  phases={os.environ.get('FDGAN_DEBUG_PHASES','0')} T={os.environ.get('FDGAN_DEBUG_WGRAD_T','auto')}")
