@@ -823,21 +823,17 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
-  // the dense-layer growth conv, transpose-read kernel (conv_wgrad_tr.hip)
-  if (workspace != nullptr && dbias == nullptr && conv_wgrad3x3_tr_fits(cout, a.Cin, d->ksize, d->stride, d->pad, pool)) {
+  // row-walking transpose-read kernels (conv_wgrad_tr.hip): the growth conv and the discriminator's 4x4 conv
+  const int trv = (workspace != nullptr && dbias == nullptr) ? conv_wgrad_tr_variant(cout, a.Cin, d->ksize, d->stride, d->pad, pool) : 0;
+  if (trv != 0) {
     WgradRowsArgs w{};
     w.x = a.x, w.x_sn = a.x_sn, w.x_sh = a.x_sh, w.x_sw = a.x_sw;
     w.dy = a.dy, w.dy_sn = a.dy_sn, w.dy_sh = a.dy_sh, w.dy_sw = a.dy_sw;
-    w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin;
+    w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin, w.Cout = cout, w.Ho = a.Ho, w.Wo = a.Wo, w.pad = a.pad;
     w.pro_mode = a.pro_mode, w.p_slope = a.p_slope, w.eps = a.eps;
     w.p_mean = a.p_mean, w.p_var = a.p_var, w.p_gamma = a.p_gamma, w.p_beta = a.p_beta;
-    w.part = workspace;
-    long long items = 0;
-    hipStream_t stt = static_cast<hipStream_t>(stream);
-    if (int rc = conv_wgrad3x3_tr_launch(w, x->n, workspace_floats, &items, stt)) return rc;
-    const long long numel3 = 32LL * a.Cin * 9;
-    WredArgs r3{workspace, dw, numel3, (int)items, accumulate};
-    return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 63) / 64)), dim3(256), 0, r3, stt);
+    const int rc = conv_wgrad_tr_launch(trv, w, x->n, workspace, workspace_floats, dw, accumulate, static_cast<hipStream_t>(stream));
+    if (rc != 1) return rc;   // 1: workspace too small for this kernel's partials
   }
   // the dense-layer growth conv: all nine taps in one workgroup
   if (workspace != nullptr && dbias == nullptr && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !pool && cout <= 32 &&

@@ -686,15 +686,17 @@ struct WgradRowsArgs {
   const unsigned short* dy;      // gradient of the conv output (NHWC bf16 view, 32 channels)
   long long dy_sn;
   int dy_sh, dy_sw;
-  int H, W, Cin;
-  int xblocks, seg_rows, segs;   // column blocks per image; rows per work item; row segments per (image, block)
+  int H, W, Cin, Cout, Ho, Wo, pad;
+  int xblocks, seg_rows, segs;   // column blocks per image; output rows per work item; row segments per (image, block)
   int pro_mode;
   float p_slope, eps;
   const float *p_mean, *p_var, *p_gamma, *p_beta;
-  float* part;                   // [items][32][Cin][9] partial sums, reduced by wgrad_reduce
+  float* part;                   // per-item partial sums in accumulator order (conv_wgrad_tr.hip)
+  int dbg_skip;                  // FDGAN_DEBUG_PHASES (results wrong): 1 no partial stores, 2 no MFMA loop, 4 no staging in the row loop
 };
-bool conv_wgrad3x3_tr_fits(int cout, int cin, int ksize, int stride, int pad, bool pool);
-int conv_wgrad3x3_tr_launch(WgradRowsArgs& a, long long nimg, long long workspace_floats, long long* items_out, hipStream_t stream);
+int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
+int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
+                         int accumulate, hipStream_t stream);
 
 int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream);

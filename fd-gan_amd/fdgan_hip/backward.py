@@ -97,7 +97,7 @@ class PlanBackward:
                     self.multi_version.add(rx[0])
                     break
         dev = plan.device
-        self.ws = torch.empty(1 << 24, dtype=torch.float32, device=dev)      # split-K partials (64 MiB)
+        self.ws = torch.empty(1 << 25, dtype=torch.float32, device=dev)      # split-K partials (128 MiB)
         self.ws_bn = torch.empty(512 * 1024 * 2, dtype=torch.float32, device=dev)
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
 

@@ -242,6 +242,33 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 144, 64, 13, 70), (1, 144, 288, 6, 131), (1, 288, 32, 9, 20)])
+def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
+    """conv_wgrad4x4_tr (the Fusion-discriminator's 4x4 stride-1 pad-1 conv behind BatchNorm + LeakyReLU(0.2),
+    /root/reference/models/dehaze1113.py:200-207): ragged column blocks, rows outside the image, two cin slices."""
+    from fdgan_hip import lib as L
+    x = bf16_round(seeded((n, cin, h, w), 61, -1.5, 1.5))
+    ho, wo = h - 1, w - 1
+    dy = bf16_round(seeded((n, cout, ho, wo), 62, -1.0, 1.0))
+    p = _bn_params(cin, 63)
+    keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
+    sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+    sh = (p["beta"] - p["mean"] * sc).float()
+    a = bf16_round(F.leaky_relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)).double()
+    wref = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a, wref, None, 1, 1).backward(dy.double())
+    pro = E.make_prologue(act=L.ACT_LEAKY02, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+    xb, dyb = _nhwc(x), _nhwc(dy, pitch=cout + 8)
+    ws = torch.zeros(1 << 24, dtype=torch.float32, device=DEV)
+    dw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(4, 1, 1, cout=cout), dw, None, ws, False)
+    dw_direct = torch.empty_like(dw)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(4, 1, 1, cout=cout), dw_direct, None, None, False)
+    torch.cuda.synchronize()
+    assert rel_rms(dw.cpu().double(), wref.grad) < 5e-3
+    assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
+
+
 def test_flat_adam_matches_torch_adam():
     from fdgan_hip.optim import FlatAdam
     torch.manual_seed(3)
