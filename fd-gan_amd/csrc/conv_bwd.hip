@@ -824,7 +824,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
   // row-walking transpose-read kernels (conv_wgrad_tr.hip): the growth conv and the discriminator's 4x4 conv
-  const int trv = (workspace != nullptr && dbias == nullptr) ? conv_wgrad_tr_variant(cout, a.Cin, d->ksize, d->stride, d->pad, pool) : 0;
+  const int trv = workspace != nullptr ? conv_wgrad_tr_variant(cout, a.Cin, d->ksize, d->stride, d->pad, pool) : 0;
   if (trv != 0) {
     WgradRowsArgs w{};
     w.x = a.x, w.x_sn = a.x_sn, w.x_sh = a.x_sh, w.x_sw = a.x_sw;
@@ -832,7 +832,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
     w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin, w.Cout = cout, w.Ho = a.Ho, w.Wo = a.Wo, w.pad = a.pad;
     w.pro_mode = a.pro_mode, w.p_slope = a.p_slope, w.eps = a.eps;
     w.p_mean = a.p_mean, w.p_var = a.p_var, w.p_gamma = a.p_gamma, w.p_beta = a.p_beta;
-    const int rc = conv_wgrad_tr_launch(trv, w, x->n, workspace, workspace_floats, dw, accumulate, static_cast<hipStream_t>(stream));
+    const int rc = conv_wgrad_tr_launch(trv, w, x->n, workspace, workspace_floats, dw, dbias, accumulate, static_cast<hipStream_t>(stream));
     if (rc != 1) return rc;   // 1: workspace too small for this kernel's partials
   }
   // the dense-layer growth conv: all nine taps in one workgroup

@@ -692,11 +692,12 @@ struct WgradRowsArgs {
   float p_slope, eps;
   const float *p_mean, *p_var, *p_gamma, *p_beta;
   float* part;                   // per-item partial sums in accumulator order (conv_wgrad_tr.hip)
+  float* bias_part;              // [items][cout tiles][32] per-item sums of dy (bias gradient) or NULL
   int dbg_skip;                  // FDGAN_DEBUG_PHASES (results wrong): 1 no partial stores, 2 no MFMA loop, 4 no staging in the row loop
 };
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
-                         int accumulate, hipStream_t stream);
+                         float* dbias, int accumulate, hipStream_t stream);
 
 int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream);

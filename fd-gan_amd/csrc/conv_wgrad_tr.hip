@@ -108,16 +108,23 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   const int xchunk = tid % (2 * NW), xpix0 = tid / (2 * NW);
   constexpr int XPSTEP = C::NT / (2 * NW);   // 32
   const bool xc_ok = ci0 + xchunk * 8 < a.Cin;
-  const int dpix = (tid >> 2) & 63, dpiece = tid & 3;
-  const bool is_d = tid < 256, dc_ok = co0 + dpiece * 8 < a.Cout;
+  static_assert(C::NT >= 256 || NW == 3, "dy row staging: 256 units");
+  constexpr int DK = C::NT >= 256 ? 1 : 2;        // dy units per thread (192 threads: 2 rounds, the second partly idle)
+  const int dpiece = tid & 3;
+  const bool dc_ok = co0 + dpiece * 8 < a.Cout;
   const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0 + xchunk * 8;
   const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + co0 + dpiece * 8;
   int xdst[C::XK];
 #pragma unroll
   for (int k = 0; k < C::XK; ++k) xdst[k] = C::xoff(xpix0 + XPSTEP * k, xchunk >> 1) + ((xchunk & 1) << 4);
-  const int ddst = g3_doff(dpix, dpiece >> 1) + ((dpiece & 1) << 4);
-
-  u32x4 xr[C::XK], dr;
+  u32x4 xr[C::XK], dr[DK];
+  // bias gradient = per-channel sum of dy: the workgroups of cin slice 0 / filter-row group 0 add up the dy rows they stage
+  const bool want_bias = a.bias_part != nullptr && blockIdx.x == 0 && ky0 == 0;
+  float bs[DK][8];
+#pragma unroll
+  for (int k = 0; k < DK; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[k][e] = 0.f;
   unsigned xok = 0;   // bit k: xr[k] holds raw data (else the unit is zero padding)
   auto load_x_row = [&](int row) __attribute__((always_inline)) {
     xok = 0;
@@ -147,12 +154,25 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     }
   };
   auto load_d_row = [&](int row) __attribute__((always_inline)) {
-    dr = zero4;
-    if (is_d && dc_ok && row < y_end && xbase + dpix < a.Wo)
-      dr = *reinterpret_cast<const u32x4*>(dimg + (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw);
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      const int dpix = (tid + k * C::NT) >> 2;
+      dr[k] = zero4;
+      if (dpix < G3_PB && dc_ok && row < y_end && xbase + dpix < a.Wo)
+        dr[k] = *reinterpret_cast<const u32x4*>(dimg + (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw);
+    }
   };
   auto store_d_row = [&](int row) __attribute__((always_inline)) {
-    if (is_d) lds_write16(Ds + (row & 1) * C::DROW_B + ddst, dr);
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      const int dpix = (tid + k * C::NT) >> 2;
+      if (dpix < G3_PB) lds_write16(Ds + (row & 1) * C::DROW_B + g3_doff(dpix, dpiece >> 1) + ((dpiece & 1) << 4), dr[k]);
+      if (want_bias) {   // rows >= y_end were loaded as zeros
+        const f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, dr[k]), f32x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[k][e] += f[e];
+      }
+    }
   };
 
   // ---- fragment addresses: lane (g, i): k rows 8 g + (i >> 2) (+ 4 for the second read), 4-channel piece i & 3
@@ -198,6 +218,22 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     if (!(a.dbg_skip & 4)) store_x_row(y + row_off + KYN);   // its slot held the row above this step's first: last read one barrier ago
     store_d_row(y + 1);
     __syncthreads();
+  }
+  if (want_bias) {   // after the loop's last barrier: the x slots are free
+    float* red = reinterpret_cast<float*>(Xs);   // [64 pixels][32 channels]
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      const int dpix = (tid + k * C::NT) >> 2;
+      if (dpix < G3_PB)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[dpix * 32 + dpiece * 8 + e] = bs[k][e];
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int q = 0; q < G3_PB; ++q) t += red[q * 32 + tid];
+      a.bias_part[((long long)item * (gridDim.z / KYG) + blockIdx.z / KYG) * 32 + tid] = t;
+    }
   }
   // partial sums in accumulator order, [item][cin slice][z][wave][tap][cout tile][r][lane]: every store is 256
   // contiguous bytes (scattering them to [co][ci][tap] here cost 50 us per launch); wgrad_tr_reduce_kernel maps back
@@ -254,19 +290,33 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(TrRedArgs a) {
   }
 }
 
+struct TrBiasRedArgs {
+  const float* part;   // [items][ctiles * 32]
+  float* out;
+  int items, width, Cout, accumulate;
+};
+__global__ __launch_bounds__(64) void wgrad_tr_bias_reduce_kernel(TrBiasRedArgs a) {
+  const int co = blockIdx.x * 64 + threadIdx.x;
+  if (co >= a.Cout) return;
+  float t = 0.f;
+  for (int s_ = 0; s_ < a.items; ++s_) t += a.part[(long long)s_ * a.width + co];
+  a.out[co] = a.accumulate ? a.out[co] + t : t;
+}
+
 template <int KS, int KYN, int NW>
-int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, int accumulate,
+int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, float* dbias, int accumulate,
               hipStream_t stream, const char* name) {
   using C = G3Cfg<KS, KYN, NW>;
   a.xblocks = (a.Wo + G3_PB - 1) / G3_PB;
   const long long strips = nimg * a.xblocks, ci_tiles = (a.Cin + NW * 16 - 1) / (NW * 16), zt = (a.Cout + 31) / 32 * (KS / KYN);
-  const long long item_stride = ci_tiles * zt * NW * C::TAPS * 512;
-  if (strips * item_stride > workspace_floats || strips >= 65536) return 1;   // caller falls back to the per-tap kernel
+  const long long ctiles = (a.Cout + 31) / 32;
+  const long long item_stride = ci_tiles * zt * NW * C::TAPS * 512, item_floats = item_stride + (dbias ? ctiles * 32 : 0);
+  if (strips * item_floats > workspace_floats || strips >= 65536) return 1;   // caller falls back to the per-tap kernel
   static const char* wgs_env = getenv("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
   long long segs = (wgs_env ? atoll(wgs_env) : 256) / (strips * ci_tiles * zt);   // one resident workgroup per CU
   if (segs < 1) segs = 1;
   if (segs > (a.Ho + 1) / 2) segs = (a.Ho + 1) / 2;             // at least 2 rows per item (KYN - 1 halo rows re-staged per item)
-  while (segs > 1 && (strips * segs * item_stride > workspace_floats || strips * segs >= 65536)) --segs;
+  while (segs > 1 && (strips * segs * item_floats > workspace_floats || strips * segs >= 65536)) --segs;
   a.seg_rows = (int)((a.Ho + segs - 1) / segs);
   a.segs = (int)((a.Ho + a.seg_rows - 1) / a.seg_rows);
   a.part = workspace;
@@ -280,29 +330,48 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   static const char* ph = getenv("FDGAN_DEBUG_PHASES");
   a.dbg_skip = ph ? atoi(ph) : 0;
   const long long items = strips * a.segs;
+  a.bias_part = dbias ? workspace + items * item_stride : nullptr;
   if (int rc = fd_launch(&conv_wgrad_tr_kernel<KS, KYN, NW>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(64 * NW),
                          C::LDS, a, stream))
     return rc;
   TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, KS / KYN, KYN, KS, NW, C::TAPS, a.Cin, a.Cout, accumulate};
-  return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
+  if (int rc = fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream)) return rc;
+  if (!dbias) return FD_OK;
+  TrBiasRedArgs rb{a.bias_part, dbias, (int)items, (int)(ctiles * 32), a.Cout, accumulate};
+  return fd_launch(&wgrad_tr_bias_reduce_kernel, "wgrad_tr_bias_reduce", dim3((unsigned)((a.Cout + 63) / 64)), dim3(64), 0, rb, stream);
 }
 
 }  // namespace
 
-// 1: growth conv (3x3, 32 filters, Cin % 128 == 0); 2: 4x4 stride-1 conv with Cin % 144 == 0 (the Fusion-discriminator's
-// 144 -> 288 layer, /root/reference/models/dehaze1113.py:200-207); 0: not covered
+// Which instantiation covers a stride-1 conv (0: none, the caller uses the per-tap kernel).  3x3 pad 1: 8, 5 or 3 cin
+// tiles per workgroup, whichever pads Cin least (growth conv 128 -> 32, the dy blocks, the discriminator's 36 -> 72 and
+// 72 -> 144); 4x4: 9 cin tiles, two filter rows per workgroup (the Fusion-discriminator's 144 -> 288 and 288 -> 1,
+// /root/reference/models/dehaze1113.py:200-207).
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool) {
-  if (stride != 1 || pool || getenv("FDGAN_DEBUG_NO_WGRAD_TR") != nullptr) return 0;
-  if (ksize == 3 && pad == 1 && cout == 32 && cin % 128 == 0) return 1;
-  if (ksize == 4 && pad <= 3 && cin % 144 == 0 && cout % 32 == 0) return 2;
+  if (stride != 1 || pool || cin < 32 || getenv("FDGAN_DEBUG_NO_WGRAD_TR") != nullptr) return 0;
+  if (ksize == 3 && pad == 1) {
+    int best = 0;
+    long long best_pad = 0;
+    const int nws[3] = {8, 5, 3};
+    for (int v = 0; v < 3; ++v) {
+      const long long padded = (long long)((cin + nws[v] * 16 - 1) / (nws[v] * 16)) * nws[v] * 16;
+      if (best == 0 || padded < best_pad) best = nws[v], best_pad = padded;
+    }
+    return best_pad * 4 <= (long long)cin * 6 ? best : 0;   // at most 1.5x padding
+  }
+  if (ksize == 4 && pad <= 3 && cin % 144 == 0) return 9;
   return 0;
 }
 
 /* Weight gradient into dw (+= when accumulate) through `workspace`.  Returns 1 (nothing launched) when the workspace
  * cannot hold one partial per (image, column block): the caller uses the per-tap kernel then. */
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
-                         int accumulate, hipStream_t stream) {
-  if (variant == 1) return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_tr");
-  if (variant == 2) return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_tr");
+                         float* dbias, int accumulate, hipStream_t stream) {
+  switch (variant) {
+    case 8: return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8");
+    case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5");
+    case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3");
+    case 9: return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr");
+  }
   FD_FAIL(FD_EINVAL, "conv_wgrad_tr_launch: variant %d", variant);
 }

@@ -213,7 +213,8 @@ def test_gradient_plumbing_kernels(E):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 32, 21, 40), (2, 256, 24, 9, 132), (1, 64, 32, 64, 64), (2, 128, 32, 5, 8),
-                                             (2, 256, 32, 9, 132), (1, 128, 32, 70, 64), (1, 128, 32, 3, 100)])
+                                             (2, 256, 32, 9, 132), (1, 128, 32, 70, 64), (1, 128, 32, 3, 100),
+                                             (1, 72, 144, 20, 70), (2, 36, 72, 9, 33), (1, 160, 128, 8, 64), (1, 640, 40, 6, 32)])
 def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     """conv_wgrad3x3_tr (32 filters, Cin % 128 == 0: transpose-read kernel) and conv_wgrad3x3 (Cout <= 32,
     Cin % 32 == 0), the growth-conv shape 3x3 s1 p1: ragged column blocks, several
@@ -237,12 +238,17 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw, None, ws, False)
     dw_direct = torch.empty_like(dw)
     E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw_direct, None, None, False)
+    # with a bias gradient, accumulating onto existing values (conv_refin6 / conv_refine4 of the generator have biases)
+    dw_acc, db_acc = torch.full_like(dw, 0.5), torch.full((cout,), -2.0, dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw_acc, db_acc, ws, True)
     torch.cuda.synchronize()
     assert rel_rms(dw.cpu().double(), wref.grad) < 5e-3
     assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
+    assert rel_rms(dw_acc.cpu() - 0.5, dw.cpu()) < 1e-4
+    assert rel_rms(db_acc.cpu().double() + 2.0, dy.double().sum(dim=(0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 144, 64, 13, 70), (1, 144, 288, 6, 131), (1, 288, 32, 9, 20)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 144, 64, 13, 70), (1, 144, 288, 6, 131), (1, 288, 32, 9, 20), (2, 288, 1, 12, 67)])
 def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     """conv_wgrad4x4_tr (the Fusion-discriminator's 4x4 stride-1 pad-1 conv behind BatchNorm + LeakyReLU(0.2),
     /root/reference/models/dehaze1113.py:200-207): ragged column blocks, rows outside the image, two cin slices."""
@@ -258,7 +264,7 @@ def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     wref = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
     F.conv2d(a, wref, None, 1, 1).backward(dy.double())
     pro = E.make_prologue(act=L.ACT_LEAKY02, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
-    xb, dyb = _nhwc(x), _nhwc(dy, pitch=cout + 8)
+    xb, dyb = _nhwc(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 8)
     ws = torch.zeros(1 << 24, dtype=torch.float32, device=DEV)
     dw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
     E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(4, 1, 1, cout=cout), dw, None, ws, False)
