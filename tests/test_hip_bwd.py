@@ -144,6 +144,20 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     E.conv_bwd_data_direct(dyv.fd, wdev, E.conv_desc(k, s, pad, cout=cout), dx)
     torch.cuda.synchronize()
     assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5
+    # pixel-per-thread variant (3 / 9 / 16 input channels, dy rows padded to whole 8-channel vectors holding junk)
+    for (cin, cout, k, s, pad) in ((9, 36, 4, 2, 1), (3, 64, 3, 1, 1), (16, 3, 3, 1, 1)):
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        dy = bf16_round(seeded((n, cout, ho, wo), 11, -1.0, 1.0))
+        wt = seeded((cout, cin, k, k), 12, -0.3, 0.3)
+        xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, bf16_round(wt).double(), None, s, pad).backward(dy.double())
+        dx = torch.full((n, cin, h, w), 5.0, dtype=torch.float32, device=DEV)
+        buf = _nhwc(dy, pitch=(cout + 7) // 8 * 8)
+        buf[..., cout:] = float("nan")
+        dyv, wdev = E.View(buf, 0, cout), wt.to(DEV).contiguous()
+        E.conv_bwd_data_direct(dyv.fd, wdev, E.conv_desc(k, s, pad, cout=cout), dx)
+        torch.cuda.synchronize()
+        assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5, (cin, cout, k, s)
 
 
 def test_weight_gradient_split_k_pool_and_accumulate(E):

@@ -7,6 +7,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"void conv_igemm_kernel<(.*?)>\(ConvArgs\)", name)
     if m:
         return "conv_igemm<%s>" % m.group(1).replace(" ", "")
