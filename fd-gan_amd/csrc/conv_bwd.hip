@@ -544,6 +544,7 @@ struct SumFinArgs {
   long long rows, cpad, channels;
   float *dbeta, *dgamma;
   int accumulate;
+  float *sink_dbeta, *sink_dgamma;   // optional: also added into the parameters' own gradient buffers
 };
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
   __shared__ double sh[2][32][33];
@@ -572,6 +573,8 @@ __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
       a.dbeta[c] = (float)t1;
       a.dgamma[c] = (float)t2;
     }
+    if (a.sink_dbeta != nullptr) a.sink_dbeta[c] += (float)t1;
+    if (a.sink_dgamma != nullptr) a.sink_dgamma[c] += (float)t2;
   }
 }
 
@@ -1002,8 +1005,13 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
 
 extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                      float* dbeta, int accumulate, FdStream stream) {
+  return fdgan_bn_bwd_finalize_sink(partial, rows, cpad, channels, dgamma, dbeta, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
+                                          float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate};
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma};
   return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
                    static_cast<hipStream_t>(stream));
 }

@@ -63,6 +63,45 @@ def _overlap(a, b):
     return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
 
 
+class _InPlace:
+    """Marker in a `grads` dict: the gradient was accumulated straight into the parameter's own `.grad` (a view of an
+    optimizer's flat gradient buffer, see optim.FlatAdam); the autograd bridge returns None for it."""
+
+    def __repr__(self):
+        return "IN_PLACE"
+
+
+IN_PLACE = _InPlace()
+
+
+def grad_sink(p):
+    """The fp32 tensor gradients of `p` may be added into directly, or None: FlatAdam marks its parameters with
+    `_fd_grad_sink` (= their `.grad` view); anything else goes through autograd's own accumulation."""
+    sink = getattr(p, "_fd_grad_sink", None)
+    if sink is not None and p.grad is not None and p.grad.data_ptr() == sink.data_ptr():
+        return sink
+    return None
+
+
+def grad_target(grads, p):
+    """Tensor to accumulate the gradient of `p` into during this backward walk (registered in `grads`)."""
+    t = grads.get(p)
+    if t is IN_PLACE:
+        return p._fd_grad_sink
+    if t is None:
+        sink = grad_sink(p)
+        if sink is not None:
+            grads[p] = IN_PLACE
+            return sink
+        t = grads[p] = torch.zeros_like(p)
+    return t
+
+
+def autograd_grads(grads, params):
+    """What an autograd.Function returns for `params`: None where the gradient already sits in `.grad`."""
+    return tuple(None if grads.get(p) is IN_PLACE else grads.get(p) for p in params)
+
+
 class PlanBackward:
     def __init__(self, plan):
         self.plan = plan
@@ -122,16 +161,12 @@ class PlanBackward:
             if w.transposed:                      # ConvTranspose2d 1x1: weight is (cin, cout, 1, 1)
                 tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
                 E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
-                grads[p] = grads.get(p, 0) + tmp.permute(1, 0, 2, 3)
+                grad_target(grads, p).add_(tmp.permute(1, 0, 2, 3))
             else:
-                if p not in grads:
-                    grads[p] = torch.zeros_like(p)
                 db = None
                 if r["bias"] is not None and r["bias"].requires_grad:
-                    if r["bias"] not in grads:
-                        grads[r["bias"]] = torch.zeros_like(r["bias"])
-                    db = grads[r["bias"]]
-                E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grads[p], db, self.ws, True)
+                    db = grad_target(grads, r["bias"])
+                E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grad_target(grads, p), db, self.ws, True)
         check = self.checks is not None
         if check:
             dw_ref, dx_ref = _op_reference(r, dy_view, meta)
@@ -187,11 +222,11 @@ class PlanBackward:
             rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
             dg = torch.empty(cin, dtype=torch.float32, device=p.device)
             dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
-            E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt)
+            train_bn = bn.weight is not None and bn.weight.requires_grad
+            E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt,
+                              sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                              sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
             E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
-            if bn.weight is not None and bn.weight.requires_grad:
-                grads[bn.weight] = grads.get(bn.weight, 0) + dg
-                grads[bn.bias] = grads.get(bn.bias, 0) + dbt
         else:
             if meta["act"] != L.ACT_NONE:
                 E.bn_act_bwd(Tv.fd, x.fd, E.make_prologue(act=meta["act"]))

@@ -287,9 +287,13 @@ def bn_act_bwd(da_fd, x_fd, pro, ws=None):
     return rows.value, cpad.value
 
 
-def bn_bwd_finalize(ws, rows, cpad, channels, dgamma, dbeta, accumulate=False):
-    L.check(L.load().fdgan_bn_bwd_finalize(ws.data_ptr(), rows, cpad, channels, dgamma.data_ptr(), dbeta.data_ptr(),
-                                           int(bool(accumulate)), stream_ptr()), "bn_bwd_finalize")
+def bn_bwd_finalize(ws, rows, cpad, channels, dgamma, dbeta, accumulate=False, sink_dgamma=None, sink_dbeta=None):
+    """(dgamma, dbeta) <- the reduced partials of bn_act_bwd; sink_*: fp32 gradient buffers the sums are also added to."""
+    L.check(L.load().fdgan_bn_bwd_finalize_sink(ws.data_ptr(), rows, cpad, channels, dgamma.data_ptr(), dbeta.data_ptr(),
+                                                int(bool(accumulate)),
+                                                sink_dgamma.data_ptr() if sink_dgamma is not None else None,
+                                                sink_dbeta.data_ptr() if sink_dbeta is not None else None, stream_ptr()),
+            "bn_bwd_finalize")
 
 
 def bn_bwd_apply(dpre_fd, x_fd, pro, dgamma, dbeta, dx_fd, accumulate=False):

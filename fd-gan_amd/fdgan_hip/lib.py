@@ -102,6 +102,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p]),
+    "fdgan_bn_bwd_finalize_sink": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_bn_bwd_apply": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.c_void_p,
                                      C.c_void_p, C.POINTER(FdTensor), C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_data_direct": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_int, C.c_int, C.POINTER(FdConvDesc),

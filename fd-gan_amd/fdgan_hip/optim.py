@@ -27,6 +27,7 @@ class FlatAdam:
             seg.copy_(p.data)
             p.data = seg                                                          # the parameter now aliases the flat buffer
             p.grad = self.grad[o:o + p.numel()].view_as(p)                        # and so does its gradient
+            p._fd_grad_sink = p.grad                # the planned modules' backward adds into it directly (backward.grad_sink)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
         self.param_groups = [{"lr": lr, "params": self.params}]                  # misc.adjust_learning_rate compatibility
 
@@ -35,6 +36,7 @@ class FlatAdam:
         for p, o in zip(self.params, self.offsets):                              # re-attach if someone dropped .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p._fd_grad_sink = p.grad
 
     def step(self):
         E.require_gpu(self.flat, "FlatAdam.step")          # the update is a HIP kernel; no CPU fallback

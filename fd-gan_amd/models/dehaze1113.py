@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
-from fdgan_hip.backward import PlanBackward
+from fdgan_hip.backward import PlanBackward, autograd_grads
 from fdgan_hip.netplan import ChanStats, NetPlan, bn_flags
 
 from . import tv_densenet121 as _tv
@@ -70,7 +70,7 @@ class _PlanFunction(torch.autograd.Function):
     def backward(ctx, dout):
         _check_generation(ctx.plan, ctx.gen)
         dx, grads = ctx.module._autograd_backward(ctx.state, dout.detach().float().contiguous())
-        return (None, dx) + tuple(grads.get(p) for p in ctx.params)
+        return (None, dx) + autograd_grads(grads, ctx.params)
 
 
 def _bump_generation(plan):

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
+from fdgan_hip.backward import autograd_grads
 from fdgan_hip.netplan import NetPlan
 
 _CFG = [("conv1_1", 3, 64), ("conv1_2", 64, 64), "tap", "pool",
@@ -118,4 +119,4 @@ class _VggFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *douts):
         dx, grads = ctx.module._backward(ctx.plan, douts, ctx.need_dx)
-        return (None, dx) + tuple(grads.get(p) for p in ctx.params)
+        return (None, dx) + autograd_grads(grads, ctx.params)

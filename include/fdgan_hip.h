@@ -240,6 +240,10 @@ int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pr
                      int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
 int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                           float* dbeta, int accumulate, FdStream stream);
+/* Same, and the sums are ALSO added into sink_dgamma / sink_dbeta when non-NULL: the BatchNorm parameters' own
+ * gradient buffers (an optimizer's flat gradient), so a training step needs no per-parameter add kernels. */
+int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
+                               float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream);
 int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
