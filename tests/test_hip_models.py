@@ -678,6 +678,31 @@ def test_training_step_smoke():
         y1.mean().backward()
 
 
+def test_flat_gradient_sink_equals_autograd_accumulation():
+    """With FlatAdam the backward walk adds weight / bias / BatchNorm gradients straight into the flat gradient views
+    (no autograd accumulation): two backward passes (the real and the fake half of a discriminator step) must leave
+    exactly what autograd's own `.grad +=` leaves."""
+    import copy
+    import models.dehaze1113 as net
+    from fdgan_hip.optim import FlatAdam
+    torch.manual_seed(5)
+    d_ref = net.D(9, 36).to(DEV)
+    d_snk = copy.deepcopy(d_ref)
+    xa, xb = torch.rand(2, 9, 64, 64, device=DEV), torch.rand(2, 9, 64, 64, device=DEV) * 0.5
+    opt = FlatAdam(d_snk.parameters())
+    opt.zero_grad()
+    for d in (d_ref, d_snk):
+        d(xa).mean().backward()
+        (d(xb) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    n = 0
+    for (name, p), q in zip(d_ref.named_parameters(), d_snk.parameters()):
+        assert q.grad.data_ptr() >= opt.grad.data_ptr() and q.grad.data_ptr() < opt.grad.data_ptr() + 4 * opt.grad.numel()
+        assert torch.allclose(q.grad, p.grad, rtol=1e-5, atol=1e-7), name
+        n += 1
+    assert n == 9 and float(opt.grad.abs().sum()) > 0          # 5 conv weights + 2 BatchNorm (weight, bias) pairs
+
+
 def test_dehaze22_d_backward():
     """PatchGAN D (4x4 stride-2 convs: any-stride direct data gradient) under autograd vs the bf16-emulating oracle."""
     from hiputil import emulate_bf16_operands
