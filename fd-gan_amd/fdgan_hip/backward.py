@@ -107,14 +107,23 @@ class PlanBackward:
         self.plan = plan
         self.recs = plan.records
         self.gbuf = {}          # activation buffer data_ptr -> gradient buffer
+        self.multi_version = set()
+        alias = getattr(plan, "grad_alias", {})
         for r in self.recs:
             for key in ("x", "y", "src", "dst"):
                 v = r.get(key)
-                if v is not None and v.buf.data_ptr() not in self.gbuf:
-                    self.gbuf[v.buf.data_ptr()] = torch.zeros_like(v.buf)
+                if v is None or v.buf.data_ptr() in self.gbuf:
+                    continue
+                ptr = v.buf.data_ptr()
+                if ptr in alias:          # per-layer activation buffers whose gradients are consumed one at a time
+                    if alias[ptr] not in self.gbuf:
+                        self.gbuf[alias[ptr]] = torch.zeros_like(v.buf)
+                    self.gbuf[ptr] = self.gbuf[alias[ptr]]
+                    self.multi_version.update((ptr, alias[ptr]))
+                else:
+                    self.gbuf[ptr] = torch.zeros_like(v.buf)
         # recomputation: op i's input was produced by op j and overwritten afterwards
         self.recompute = {}
-        self.multi_version = set()
         for i, r in enumerate(self.recs):
             if r["kind"] != "conv":
                 continue
@@ -144,7 +153,7 @@ class PlanBackward:
         return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
 
     def zero_(self):
-        for g in self.gbuf.values():
+        for g in {id(g): g for g in self.gbuf.values()}.values():      # aliased gradient buffers once
             g.zero_()
 
     # ---- one fused convolution ---------------------------------------------------------------

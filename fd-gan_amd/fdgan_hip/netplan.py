@@ -35,6 +35,7 @@ class NetPlan:
         self.main = None
         self.packp = None
         self.keep = []             # anything that must outlive the plan
+        self.grad_alias = {}       # activation buffer data_ptr -> data_ptr of the buffer whose GRADIENT buffer it shares
         self._param_versions = None
         self.records = []          # per op, in forward order: what the backward pass needs (fdgan_hip/backward.py)
         import os

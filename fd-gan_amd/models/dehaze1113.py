@@ -29,7 +29,10 @@ class _PlannedModule(nn.Module):
         if x.dim() != 4:
             raise ValueError("expected a BxCxHxW tensor, got %s" % (tuple(x.shape),))
         cache = self.__dict__.setdefault("_plans", {})
-        key = (tuple(x.shape), x.device.index, bn_flags(self))
+        # a plan built for training keeps every intermediate the backward reads (2.8 GB more at 16 x 256 x 256: nothing
+        # next to 288 GB); an inference plan reuses one bottleneck buffer per dense block
+        keep = self.__dict__.get("_in_autograd", False) or _wants_grad(self, x)    # grad mode is off inside Function.forward
+        key = (tuple(x.shape), x.device.index, bn_flags(self), keep)
         plan = cache.get(key)
         if plan is not None and plan.param_ptrs() != plan._built_ptrs:
             plan = None                                   # parameters were moved / re-allocated
@@ -37,17 +40,24 @@ class _PlannedModule(nn.Module):
             for p in self.parameters():
                 if p.device != x.device:
                     raise RuntimeError("module parameters are on %s but the input is on %s" % (p.device, x.device))
+            self.__dict__["_plan_keep"] = keep
             plan = self._build_plan(tuple(x.shape), x.device)
             plan._built_ptrs = plan.param_ptrs()
             cache[key] = plan
+        self.__dict__.setdefault("_last_plan", {})[key[:3]] = plan
         return plan
 
     def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
         self.__dict__.pop("_plans", None)
+        self.__dict__.pop("_last_plan", None)
         return super()._apply(fn, *a, **k)
 
     def hip_plan(self, x):
-        """The NetPlan serving inputs shaped like `x` (for benchmarks / profiling)."""
+        """The NetPlan serving inputs shaped like `x` (for benchmarks / profiling): the one the last forward of that
+        shape ran (training and inference plans differ in what they keep), else a new one for the current grad mode."""
+        last = self.__dict__.get("_last_plan", {}).get((tuple(x.shape), x.device.index, bn_flags(self)))
+        if last is not None and last.param_ptrs() == last._built_ptrs:
+            return last
         return self._plan_for(x)
 
 
@@ -60,7 +70,11 @@ class _PlanFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, x, *params):
-        out, state = module._autograd_forward(x)
+        module.__dict__["_in_autograd"] = True
+        try:
+            out, state = module._autograd_forward(x)
+        finally:
+            module.__dict__["_in_autograd"] = False
         ctx.module, ctx.state, ctx.params = module, state, params
         ctx.plan = state[0] if isinstance(state, tuple) else state
         ctx.gen = _bump_generation(ctx.plan)
@@ -247,14 +261,23 @@ class TransitionBlockdy(_PlannedModule):
 # ---------------------------------------------------------------------------------------
 # generator
 # ---------------------------------------------------------------------------------------
-def _emit_dense_block(P, block, blk_buf, stats, bott_buf, count):
+def _emit_dense_block(P, block, blk_buf, stats, bott_buf, count, keep=False):
     """torchvision _DenseBlock on a pre-allocated concat buffer: layer i reads channels
-    [0, cin_i) and writes its 32 new channels at [cin_i, cin_i+32)."""
+    [0, cin_i) and writes its 32 new channels at [cin_i, cin_i+32).  keep: every layer gets its own bottleneck
+    buffer and statistics (training: the backward reads them instead of re-running the 1x1 conv); their gradients
+    still share one buffer, each being consumed before the next is produced."""
     bott = E.View(bott_buf)
     bstats = ChanStats(_tv.BN_SIZE * _tv.GROWTH, P.device)
     P.keep.append(bstats)
     cin = block.cin
-    for layer in block.values():
+    for li, layer in enumerate(block.values()):
+        if keep and li > 0:
+            own = torch.empty_like(bott_buf)
+            P.keep.append(own)
+            P.grad_alias[own.data_ptr()] = bott_buf.data_ptr()
+            bott = E.View(own)
+            bstats = ChanStats(_tv.BN_SIZE * _tv.GROWTH, P.device)
+            P.keep.append(bstats)
         w1 = P.weight(layer.conv1.weight, _tv.BN_SIZE * _tv.GROWTH, cin, 1)
         w2 = P.weight(layer.conv2.weight, _tv.GROWTH, _tv.BN_SIZE * _tv.GROWTH, 3)
         P.conv(E.View(blk_buf, 0, cin), w1, bott, 1, pro=P.bn_prologue(layer.norm1, stats, count),
@@ -312,6 +335,7 @@ class FDGAN(_PlannedModule):
         if h % 8 or w % 8:
             raise ValueError("FDGAN needs H and W to be multiples of 8 (skip concats), got %dx%d" % (h, w))
         P = NetPlan(dev)
+        keep = self.__dict__.get("_plan_keep", False)
         h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
         A = lambda hh, ww, cc: E.new_act(n, hh, ww, cc, dev)
         P.in8 = E.new_act(n, h, w, 8, dev, zero=True)
@@ -339,17 +363,17 @@ class FDGAN(_PlannedModule):
         P.conv(E.View(blk1, 0, 64), P.weight(self.conv_refin2.weight, 32, 64, 1), E.View(cat1, 0, 32), 1,
                bias=self.conv_refin2.bias, pro=E.make_prologue(pool=True))
         # x1 = trans_block1(dense_block1(x0))                                     (:767-769)
-        _emit_dense_block(P, self.dense_block1, blk1, st1, bott1, cnt1)
+        _emit_dense_block(P, self.dense_block1, blk1, st1, bott1, cnt1, keep)
         _emit_transition(P, self.trans_block1, E.View(blk1), st1, E.View(cat1, 32, 128), cnt1)
         # x10 = conv_refine4(cat[x01, x1])                                        (:773)
         P.conv(E.View(cat1), P.weight(self.conv_refine4.weight, 128, 160, 3), E.View(blk2, 0, 128), 3, pad=1,
                bias=self.conv_refine4.bias, stats=st2)
         # x2 = trans_block2(dense_block2(x10))                                    (:774)
-        _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt2)
+        _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt2, keep)
         _emit_transition(P, self.trans_block2, E.View(blk2), st2, E.View(blk3, 0, 256), cnt2, out_stats=st3)
         P.copy(E.View(blk3, 0, 256), E.View(blk5, 128, 256))                      # x2 half of x42 (:786)
         # x3 = trans_block3(dense_block3(x2))                                     (:778)
-        _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt3)
+        _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt3, keep)
         _emit_transition(P, self.trans_block3, E.View(blk3), st3, E.View(cat6, 0, 512), cnt3)
         # x22 = conv_refin5(avg_pool2d(x2, 2))                                    (:780)
         P.conv(E.View(blk3, 0, 256), P.weight(self.conv_refin5.weight, 128, 256, 1), E.View(cat6, 512, 128), 1,
