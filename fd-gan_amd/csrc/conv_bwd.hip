@@ -545,6 +545,9 @@ struct SumFinArgs {
   float *dbeta, *dgamma;
   int accumulate;
   float *sink_dbeta, *sink_dgamma;   // optional: also added into the parameters' own gradient buffers
+  // raw moments: the second sum is sum(dpre * x), turned into sum(dpre * xhat) = rstd * (S2 - mean * S1) here
+  const float *raw_mean, *raw_var;
+  float raw_eps;
 };
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
   __shared__ double sh[2][32][33];
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
       t1 += sh[0][g][cl];
       t2 += sh[1][g][cl];
     }
+    if (a.raw_mean != nullptr) t2 = (t2 - (double)a.raw_mean[c] * t1) / sqrt((double)a.raw_var[c] + (double)a.raw_eps);
     if (a.accumulate) {
       a.dbeta[c] += (float)t1;
       a.dgamma[c] += (float)t2;
@@ -1011,7 +1015,16 @@ extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t
 extern "C" int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                           float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma};
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma, nullptr, nullptr, 0.f};
+  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const float* mean,
+                                         const float* var, float eps, float* dgamma, float* dbeta, float* sink_dgamma,
+                                         float* sink_dbeta, FdStream stream) {
+  FD_REQUIRE(partial && dgamma && dbeta && mean && var && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize_raw: bad arguments");
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, 0, sink_dbeta, sink_dgamma, mean, var, eps};
   return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
                    static_cast<hipStream_t>(stream));
 }

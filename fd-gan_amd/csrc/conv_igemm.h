@@ -56,6 +56,14 @@ struct ConvArgs {
   int out_nchw_f32, upsample;
   float* stats;
   int stats_cpad;
+  // backward-data epilogue (generic kernel only): the stored value is acc * act'(bn(fx)) with fx the FORWARD conv's raw
+  // input at the output position, and the statistics are (sum v, sum v * fx) instead of (sum y, sum y^2)
+  int mk_mode;                  // 0 off, 1 activation only, 2 BatchNorm + activation
+  const unsigned short* mk_x;   // NHWC bf16, same n/h/w as y, >= Cout channels
+  long long mk_sn;
+  int mk_sh, mk_sw;
+  float mk_slope, mk_eps;
+  const float *mk_mean, *mk_var, *mk_gamma, *mk_beta;
   // in-kernel finalize by the last workgroup (kernels that set FdConvInfo.fused_finalize)
   float *fin_mean, *fin_var;
   unsigned* fin_counter;
@@ -366,7 +374,9 @@ struct ConvCfg {
   static unsigned lds_bytes(int nchunk) { return 2 * IN_BYTES + 2 * W_BYTES + nchunk * 32 * 8; }
 };
 
-template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS>
+// MK = 1: the backward-data instantiation (masked epilogue, ConvArgs.mk_*); kept out of the forward kernels, whose
+// register budget it would double
+template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS, int MK = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a) {
   using C = ConvCfg<KS, STRIDE, POOL, PT, CT, WM, WN, TPS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -554,6 +564,67 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       const int co = cbase + c * 16 + kgl * 4 + r;
       bv[c][r] = (a.bias != nullptr && co < a.CoutW) ? a.bias[co] : 0.f;
     }
+  if constexpr (MK != 0) {
+    // backward data: mask the accumulators in place with the derivative of the forward prologue's activation and sum
+    // (v, v * fx) per channel -- what a separate pass over the stored tensor did before (bn_act_bwd: 7 ms per step)
+    float* msc = red + WM * WN * CT * 16 * 2;   // [BN] scale, [BN] shift of this workgroup's channels
+    float* msh = msc + C::BN;
+    for (int cl = tid; cl < C::BN; cl += C::NT) {
+      const int co = by * C::BN + cl;
+      float sc = 1.f, sh = 0.f;
+      if (a.mk_mode == 2 && co < a.Cout) {
+        const float gm = a.mk_gamma ? a.mk_gamma[co] : 1.f, bt = a.mk_beta ? a.mk_beta[co] : 0.f;
+        sc = gm / sqrtf(a.mk_var[co] + a.mk_eps);
+        sh = bt - a.mk_mean[co] * sc;
+      }
+      msc[cl] = sc;
+      msh[cl] = sh;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int co0 = cbase + c * 16 + kgl * 4;
+      const f32x4 sc4 = *reinterpret_cast<const f32x4*>(msc + (co0 - by * C::BN));
+      const f32x4 sh4 = *reinterpret_cast<const f32x4*>(msh + (co0 - by * C::BN));
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      u32x2 xv[PT];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const int row = oy0 + wm * PT + p;
+        xv[p] = u32x2{0u, 0u};
+        if (row < a.Ho && col < a.Wo && co0 < a.Cout)
+          xv[p] = *reinterpret_cast<const u32x2*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)col * a.mk_sw + co0);
+      }
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const bool valid = (oy0 + wm * PT + p) < a.Ho && col < a.Wo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float fx = __uint_as_float(((xv[p][r >> 1] >> ((r & 1) * 16)) & 0xffffu) << 16);
+          const float pre = fmaf(fx, sc4[r], sh4[r]);
+          const float v = acc[p][c][r] * (pre > 0.f ? 1.f : a.mk_slope);
+          acc[p][c][r] = v;
+          s1[r] += valid ? v : 0.f;
+          s2[r] += valid ? v * fx : 0.f;
+        }
+      }
+      if (a.stats != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1[r] = fd_row_sum16(s1[r]);
+          s2[r] = fd_row_sum16(s2[r]);
+        }
+        if (m == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (wave * CT * 16 + c * 16 + kgl * 4 + r) * 2;
+            red[idx] = s1[r];
+            red[idx + 1] = s2[r];
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int row = oy0 + wm * PT + p;
@@ -580,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       }
     }
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr && MK == 0) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -635,7 +706,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
 //   narrow: BN = 32  (PT=4, CT=2, 4x1 waves, all taps of a chunk staged at once)
 //   wide  : BN = 128 (PT=4, CT=8, 4x1 waves, one tap per stage for 3x3 / 4x4)
 //   pool  : BN = 128, TH = 8 (PT=2): 4 source pixels per staged unit
-#define FD_CONV_DISPATCH(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, NAME_)                                       \
+#define FD_CONV_DISPATCH(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, NAME_) FD_CONV_DISPATCH_X(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, 0, NAME_)
+#define FD_CONV_DISPATCH_X(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, NAME_)                                \
   do {                                                                                                          \
     using C = ConvCfg<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_>;                                                \
     a.tiles_x = (a.Wo + C::TW - 1) / C::TW;                                                                     \
@@ -652,7 +724,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       info->lds_bytes = lds;                                                                                    \
     }                                                                                                           \
     if (dry) return FD_OK;                                                                                      \
-    auto kfn = &conv_igemm_kernel<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_>;                                   \
+    auto kfn = &conv_igemm_kernel<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_>;                              \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                    \

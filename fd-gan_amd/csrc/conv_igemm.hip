@@ -180,3 +180,46 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
     return fd_act_inplace(y, d->epilogue_act, static_cast<hipStream_t>(stream));
   return FD_OK;
 }
+
+/* Data gradient of a stride-1 conv fused with the backward of the conv's input-side prologue (include/fdgan_hip.h). */
+extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x,
+                                     const FdPrologue* fwd_pro, const FdTensor* dpre, float* partial, int64_t capacity_floats,
+                                     int64_t* rows_out, int64_t* cpad_out, const FdConvDesc* d, FdStream stream) {
+  FD_REQUIRE(w_packed_flipped && d && dpre && fwd_x, "conv2d_bwd_data: NULL argument");
+  FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv2d_bwd_data: packed weights must be 16-byte aligned");
+  FD_REQUIRE(d->stride == 1 && !d->upsample2 && d->epilogue_act == FD_ACT_NONE && d->w_layout == FD_WLAYOUT_CHUNK32,
+             "conv2d_bwd_data: stride-1 conv with the chunk32 filter image, no epilogue");
+  FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv2d_bwd_data: a pooled prologue is differentiated at full resolution");
+  FD_REQUIRE(dpre->dtype == FD_BF16 && fwd_x->dtype == FD_BF16 && fwd_x->n == dpre->n && fwd_x->h == dpre->h &&
+                 fwd_x->w == dpre->w && fwd_x->c >= dpre->c && fwd_x->stride[3] == 1 && fwd_x->stride[2] % 4 == 0 &&
+                 fwd_x->stride[1] % 4 == 0 && fwd_x->stride[0] % 4 == 0 && ((uintptr_t)fwd_x->ptr & 7) == 0 && dpre->c % 4 == 0,
+             "conv2d_bwd_data: fwd_x must be an NHWC bf16 view shaped like dpre (channels a multiple of 4, 8-byte aligned)");
+  ConvArgs a;
+  long long nimg;
+  bool pool;
+  const int cout = d->cout > 0 ? d->cout : (int)dpre->c;
+  FdStats st{};
+  st.partial = partial;
+  st.capacity_floats = capacity_floats;
+  const bool norm = fwd_pro && fwd_pro->mean;
+  FD_REQUIRE(!norm || partial, "conv2d_bwd_data: a BatchNorm prologue needs the partial-sum workspace");
+  int rc = conv_setup(dy, w_packed_flipped, nullptr, nullptr, dpre, cout, norm ? &st : nullptr, d, a, nimg, pool);
+  if (rc != FD_OK) return rc;
+  const int act = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
+  FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_LEAKY02, "conv2d_bwd_data: prologue activation %d", act);
+  a.mk_mode = norm ? 2 : 1;
+  a.mk_slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
+  a.mk_x = static_cast<const unsigned short*>(fwd_x->ptr);
+  a.mk_sn = fwd_x->stride[0], a.mk_sh = (int)fwd_x->stride[1], a.mk_sw = (int)fwd_x->stride[2];
+  if (norm) {
+    FD_REQUIRE(fwd_pro->var, "conv2d_bwd_data: prologue mean without var");
+    a.mk_mean = fwd_pro->mean, a.mk_var = fwd_pro->var, a.mk_gamma = fwd_pro->gamma, a.mk_beta = fwd_pro->beta, a.mk_eps = fwd_pro->eps;
+  }
+  FdConvInfo info{};
+  rc = conv_dispatch(a, nimg, cout, d->ksize, d->stride, false, d->w_layout, &info, -1, true, nullptr);
+  if (rc != FD_OK) return rc;
+  if (rows_out) *rows_out = info.stats_rows;
+  if (cpad_out) *cpad_out = info.stats_cpad;
+  return conv_dispatch(a, nimg, cout, d->ksize, d->stride, false, d->w_layout, nullptr, norm ? capacity_floats : -1, false,
+                       static_cast<hipStream_t>(stream));
+}

@@ -8,10 +8,14 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
   const bool narrow = cout_total <= 32;
   if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
   if (stride != 1) FD_FAIL(FD_EUNSUPPORTED, "3x3 conv with stride %d", stride);
-  if (conv3x3_rs_fits(a, cout_total) && getenv("FDGAN_DEBUG_NO_RS") == nullptr)
+  if (a.mk_mode == 0 && conv3x3_rs_fits(a, cout_total) && getenv("FDGAN_DEBUG_NO_RS") == nullptr)
     return conv_dispatch_k3_rs(a, nimg, cout_total, info, stats_cap, dry, stream);
-  if (narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && getenv("FDGAN_DEBUG_NO_PW") == nullptr)
+  if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && getenv("FDGAN_DEBUG_NO_PW") == nullptr)
     return conv_dispatch_k3_pw(a, nimg, cout_total, info, stats_cap, dry, stream);
+  if (a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
+    if (narrow) FD_CONV_DISPATCH_X(3, 1, 0, 4, 2, 4, 1, 9, 1, "conv3x3_bn32_bwd");
+    FD_CONV_DISPATCH_X(3, 1, 0, 4, 8, 4, 1, 1, 1, "conv3x3_bn128_bwd");
+  }
   if (narrow) FD_CONV_DISPATCH(3, 1, 0, 4, 2, 4, 1, 9, "conv3x3_bn32");
   FD_CONV_DISPATCH(3, 1, 0, 4, 8, 4, 1, 1, "conv3x3_bn128");
 }

@@ -5,6 +5,10 @@ int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bo
                      long long stats_cap, bool dry, hipStream_t stream) {
   const bool narrow = cout_total <= 32;
   if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
+  if (stride == 1 && a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
+    if (narrow) FD_CONV_DISPATCH_X(4, 1, 0, 4, 2, 4, 1, 4, 1, "conv4x4_bn32_bwd");
+    FD_CONV_DISPATCH_X(4, 1, 0, 4, 8, 4, 1, 1, 1, "conv4x4_bn128_bwd");
+  }
   if (stride == 1) {
     if (narrow) FD_CONV_DISPATCH(4, 1, 0, 4, 2, 4, 1, 4, "conv4x4_bn32");
     FD_CONV_DISPATCH(4, 1, 0, 4, 8, 4, 1, 1, "conv4x4_bn128");

@@ -19,6 +19,8 @@ consumer's backward needs them: one extra 1x1 forward per dense layer instead of
 Reference semantics: torch.autograd over /root/reference/models/dehaze1113.py:703-801 (FDGAN), :256-275,
 :358-370 (dy blocks).
 """
+import os
+
 import torch
 
 from . import engine as E
@@ -146,7 +148,8 @@ class PlanBackward:
                     break
         dev = plan.device
         self.ws = torch.empty(1 << 25, dtype=torch.float32, device=dev)      # split-K partials (128 MiB)
-        self.ws_bn = torch.empty(512 * 1024 * 2, dtype=torch.float32, device=dev)
+        self.ws_bn = torch.empty(1 << 24, dtype=torch.float32, device=dev)   # BatchNorm-backward partial sums (64 MiB)
+        self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
 
     def G(self, view):
@@ -205,11 +208,23 @@ class PlanBackward:
         else:
             pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=True, layout=L.WLAYOUT_CHUNK32)
         pw.pack()
-        E.conv2d(dy_view.fd, pw, None, None, E.View(T).fd, E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32))
-        return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
+        ddesc = E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32)
+        masked = None
+        if not meta["pool"] and cin % 4 == 0 and self.fuse_mask:
+            # the activation mask and the BatchNorm sums ride in the data-gradient kernel's epilogue
+            bn = meta.get("bn")
+            if bn is not None and not meta.get("batch_stats", False):
+                raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
+            act_pro = (E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"], beta=meta["beta"],
+                                       eps=meta["eps"]) if bn is not None else E.make_prologue(act=meta["act"]))
+            masked = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, E.View(T, 0, cin).fd, ddesc, self.ws_bn if bn is not None else None)
+        else:
+            E.conv2d(dy_view.fd, pw, None, None, E.View(T).fd, ddesc)
+        return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None, masked=masked)
 
-    def _prologue_backward(self, r, T, meta, grads, check_state=None):
-        """G[x] += backward of (pool?, activation, BatchNorm) applied to da = T."""
+    def _prologue_backward(self, r, T, meta, grads, check_state=None, masked=None):
+        """G[x] += backward of (pool?, activation, BatchNorm) applied to da = T.  masked = (rows, cpad): T already holds
+        dpre = da * act'(bn(x)) and ws_bn the raw-moment partials (conv_bwd_data did the first pass)."""
         x, w = r["x"], r["w"]
         p, cin = w.param, w.cin
         n, hin, win = T.shape[0], T.shape[1], T.shape[2]
@@ -228,16 +243,19 @@ class PlanBackward:
                 raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
             act_pro = E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
                                       beta=meta["beta"], eps=meta["eps"])
-            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
             dg = torch.empty(cin, dtype=torch.float32, device=p.device)
             dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
             train_bn = bn.weight is not None and bn.weight.requires_grad
-            E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt,
-                              sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
-                              sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            sinks = dict(sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                         sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            if masked is not None:
+                E.bn_bwd_finalize_raw(self.ws_bn, masked[0], masked[1], cin, meta["mean"], meta["var"], meta["eps"], dg, dbt, **sinks)
+            else:
+                rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
+                E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, **sinks)
             E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
         else:
-            if meta["act"] != L.ACT_NONE:
+            if meta["act"] != L.ACT_NONE and masked is None:
                 E.bn_act_bwd(Tv.fd, x.fd, E.make_prologue(act=meta["act"]))
             E.grad_ew(E.GRAD_ADD, Tv, gx)
         if check:

@@ -296,6 +296,26 @@ def bn_bwd_finalize(ws, rows, cpad, channels, dgamma, dbeta, accumulate=False, s
             "bn_bwd_finalize")
 
 
+def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta, sink_dgamma=None, sink_dbeta=None):
+    """(dgamma, dbeta) from the (sum dpre, sum dpre * x) partials of conv_bwd_data."""
+    L.check(L.load().fdgan_bn_bwd_finalize_raw(ws.data_ptr(), rows, cpad, channels, mean.data_ptr(), var.data_ptr(), eps,
+                                               dgamma.data_ptr(), dbeta.data_ptr(),
+                                               sink_dgamma.data_ptr() if sink_dgamma is not None else None,
+                                               sink_dbeta.data_ptr() if sink_dbeta is not None else None, stream_ptr()),
+            "bn_bwd_finalize_raw")
+
+
+def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None):
+    """dpre <- conv^T(dy, W) * act'(bn(fwd_x)) (stride-1 convs); with a norm in fwd_pro fills `ws` and returns
+    (rows, cpad) for bn_bwd_finalize_raw."""
+    rows, cpad = C.c_int64(0), C.c_int64(0)
+    L.check(L.load().fdgan_conv2d_bwd_data(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
+                                           C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd),
+                                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                           C.byref(rows), C.byref(cpad), C.byref(desc), stream_ptr()), "conv2d_bwd_data")
+    return rows.value, cpad.value
+
+
 def bn_bwd_apply(dpre_fd, x_fd, pro, dgamma, dbeta, dx_fd, accumulate=False):
     L.check(L.load().fdgan_bn_bwd_apply(C.byref(dpre_fd), C.byref(x_fd), C.byref(pro), dgamma.data_ptr(), dbeta.data_ptr(),
                                         C.byref(dx_fd), int(bool(accumulate)), stream_ptr()), "bn_bwd_apply")

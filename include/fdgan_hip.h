@@ -244,6 +244,22 @@ int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int6
  * gradient buffers (an optimizer's flat gradient), so a training step needs no per-parameter add kernels. */
 int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream);
+/* (dgamma, dbeta) from RAW moments: partial rows of (sum dpre, sum dpre * x) as fdgan_conv2d_bwd_data writes them;
+ * dgamma = (S2 - mean * S1) / sqrt(var + eps), dbeta = S1.  sink_*: as above. */
+int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const float* mean,
+                              const float* var, float eps, float* dgamma, float* dbeta, float* sink_dgamma,
+                              float* sink_dbeta, FdStream stream);
+/* Data gradient of a stride-1 conv (reference: autograd of nn.Conv2d as composed in models/dehaze1113.py:188-230,
+ * :703-801) fused with the first backward pass of the conv's input-side prologue: runs the FORWARD kernel on dy with
+ * the flipped filter (fdgan_pack_conv_weight(..., flip = 1), d->pad = k - 1 - pad) and stores
+ *     dpre = conv^T(dy, W) * act'(bn(fwd_x))
+ * where fwd_x is the forward conv's raw input and fwd_pro its prologue (BatchNorm batch statistics + activation, no
+ * pooling; NULL: identity).  With a norm, `partial` receives rows x cpad x {sum dpre, sum dpre * fwd_x} per channel
+ * (rows / cpad returned) for fdgan_bn_bwd_finalize_raw; fdgan_bn_bwd_apply completes dx.  Replaces
+ * fdgan_conv2d_fwd + fdgan_bn_act_bwd: one pass less over the gradient tensor. */
+int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
+                          const FdTensor* dpre, float* partial, int64_t capacity_floats, int64_t* rows_out,
+                          int64_t* cpad_out, const FdConvDesc* d, FdStream stream);
 int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,

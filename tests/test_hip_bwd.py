@@ -160,6 +160,54 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
         assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5, (cin, cout, k, s)
 
 
+@pytest.mark.parametrize("k,pad,cin,cout,act", [(1, 0, 96, 128, "relu"), (3, 1, 128, 32, "relu"), (4, 1, 72, 144, "leaky"), (3, 1, 16, 40, "relu")])
+def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act):
+    """fdgan_conv2d_bwd_data: conv^T(dy, W) * act'(bn(x)) stored by the data-gradient kernel itself, with the raw
+    moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
+    from fdgan_hip import lib as L
+    n, h, w = 2, 13, 19
+    x = bf16_round(seeded((n, cin, h, w), 71, -1.5, 1.5))
+    ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+    dy = bf16_round(seeded((n, cout, ho, wo), 72, -1.0, 1.0))
+    wt = bf16_round(seeded((cout, cin, k, k), 73, -1.0, 1.0) * (2.0 / (cin * k * k)) ** 0.5)
+    p = _bn_params(cin, 74)
+    slope = 0.0 if act == "relu" else 0.2
+    rstd = 1.0 / torch.sqrt(p["var"].double() + 1e-5)
+    xhat = (x.double() - p["mean"].double().view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    pre = xhat * p["gamma"].double().view(1, -1, 1, 1) + p["beta"].double().view(1, -1, 1, 1)
+    da = torch.nn.grad.conv2d_input((n, cin, h, w), wt.double(), dy.double(), stride=1, padding=pad)
+    dpre_ref = da * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
+    keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
+    pro = E.make_prologue(act=L.ACT_RELU if act == "relu" else L.ACT_LEAKY02, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+    wd = wt.to(DEV).contiguous()
+    pw = E.PackedWeight(wd, cin, cout, k, transposed=False, flip=True, stride=1, layout=L.WLAYOUT_CHUNK32)
+    pw.pack()
+    xb, dyb = _nhwc(x, pitch=cin + 8), _nhwc(dy)
+    T = torch.full((n, h, w, cin + 8), 7.0, dtype=torch.bfloat16, device=DEV)
+    ws = torch.zeros(1 << 20, dtype=torch.float32, device=DEV)
+    rows, cpad = E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro, E.View(T, 0, cin).fd,
+                                 E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32), ws)
+    dg, db = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    sink_g, sink_b = torch.full((cin,), 1.0, device=DEV), torch.full((cin,), -1.0, device=DEV)
+    E.bn_bwd_finalize_raw(ws, rows, cpad, cin, keep[0], keep[1], 1e-5, dg, db, sink_g, sink_b)
+    torch.cuda.synchronize()
+    got = _from_nhwc(T, cin).double()
+    # a pre-activation within bf16 rounding of zero may fall on the other side of the kink: compare away from it
+    safe = pre.abs() > 2e-2
+    assert rel_rms(got[safe], dpre_ref[safe]) < 8e-3
+    assert float(T[..., cin:].float().min()) == 7.0                       # channels outside the view untouched
+    dpre_dev = got                                                        # sums of what the kernel stored (fp32 in-kernel, bf16 stored)
+    assert rel_rms(db.cpu().double(), dpre_dev.sum(dim=(0, 2, 3))) < 5e-3
+    assert rel_rms(dg.cpu().double(), (dpre_dev * xhat).sum(dim=(0, 2, 3))) < 2e-2
+    assert torch.allclose(sink_g.cpu() - 1.0, dg.cpu(), atol=1e-4, rtol=1e-4) and torch.allclose(sink_b.cpu() + 1.0, db.cpu(), atol=1e-4, rtol=1e-4)
+    # activation only (no norm): mask by the sign of x, no workspace
+    pro1 = E.make_prologue(act=L.ACT_RELU)
+    E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro1, E.View(T, 0, cin).fd,
+                    E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32), None)
+    torch.cuda.synchronize()
+    assert rel_rms(_from_nhwc(T, cin).double(), da * (x.double() > 0)) < 8e-3
+
+
 def test_weight_gradient_split_k_pool_and_accumulate(E):
     """Split-K partials + fixed-order reduction, accumulation into an existing gradient, and the pooled
     prologue (transition: BN + ReLU + 2x2 average in front of a 1x1 conv)."""
