@@ -1,19 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- FD-GAN hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): netG (`models.dehaze1113.FDGAN`) forward, bf16
-storage / fp32 accumulate, batch 16 @ 3x256x256 per GPU, train-mode BatchNorm (what the
-reference runs at inference, README.md:38), synthetic U[0,1) input resident in HBM
-before the timed region.  One "step" = one forward of one batch.  N > 1: one process
-per GPU, each rank runs its own batch (data parallel, no exchange in the forward path);
-value = N*B*K / max-over-ranks time.
+Default workload (BASELINE.json configs[2]; configs[3] when N > 1 -- the configurations the metric "training
+images/sec @256x256 (1/2/4/8 GPUs)" is quoted on): ONE FULL TRAINING STEP of fd-gan_amd/train.py per "step" -- netG
+forward + backward, Fusion-D 3 forwards + 3 backwards, VGG16 2 forwards + 1 backward, SSIM, L1 / MSE / BCE, Adam(D),
+Adam(G) -- bf16 storage / fp32 accumulate, batch 16 @ 3x256x256 per GPU, train-mode BatchNorm, synthetic images
+resident in HBM before the timed region.  N > 1: one process per GPU, each rank its own batch (weak scaling, global
+batch 16 N), RCCL all-reduce of the two flat gradient buffers inside the step; value = N*B*K / max-over-ranks time.
+
+`--forward`: BASELINE.json configs[1] instead (netG forward only; the number DESIGN.md tracks kernel by kernel).  The
+default line carries it as the `forward_only` object as well (rank 0, N = 1).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel class (largest share of GPU time): algorithmic
-                  bytes (or flops) of its launches / their hipEvent-measured duration
-                  inside the timed region, against 8 TB/s HBM or 2.5 PFLOP/s bf16 MFMA.
-  cpu_baseline -- the CPU oracle (oracle/, PyTorch-CPU fp32 restatement of the reference,
-                  parity-checked against it) timed on this host's cores, N=1 only.
+  roofline     -- the dominant kernel of the timed workload (largest share of GPU time in an instrumented warm-up
+                  step): algorithmic bytes (or flops) of sampled launches / their hipEvent-measured duration inside
+                  the timed region (events on the launch stream, fdgan_kernel_timer_*), against 8 TB/s HBM or
+                  2.5 PFLOP/s bf16 MFMA.
+  cpu_baseline -- the CPU oracle (oracle/, PyTorch-CPU fp32 restatement of the reference, parity-checked against
+                  it) running the same step on this host's cores, bounded sample, N = 1 only.
 """
 import argparse
 import json
@@ -42,9 +46,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--breakdown", default="", help="write the per-kernel-class breakdown JSON here")
     ap.add_argument("--graph", action="store_true", help="replay the plan as a hipGraph (no per-kernel events)")
-    ap.add_argument("--train", action="store_true",
-                    help="NOT the default workload: time the full training step of fd-gan_amd/train.py (G + Fusion-D + VGG16 "
-                         "+ SSIM, Adam; BASELINE configs[2], a reconstructed loss composition); no roofline / cpu_baseline")
+    ap.add_argument("--train", action="store_true", help="the default workload (kept for older command lines)")
+    ap.add_argument("--forward", action="store_true",
+                    help="BASELINE configs[1] instead of the training step: netG forward only, with its per-kernel roofline")
+    ap.add_argument("--no-forward-leg", action="store_true", help="skip the forward_only object of the default line")
     ap.add_argument("--train-g", action="store_true",
                     help="NOT the default workload: time netG forward + backward (mse loss), the part of the training "
                          "step (BASELINE configs[2]) that exists; no roofline / cpu_baseline objects")
@@ -100,6 +105,134 @@ def cpu_baseline(state_dict, size, seconds):
                       % (n, size, size, dt)}
 
 
+def cpu_baseline_train(size, seconds):
+    """The oracle training step (oracle/train_ref.py) on the host cores.  Bounded sample: batch-1 steps for ~`seconds`."""
+    import torch
+    from oracle.train_ref import TrainStepRef
+    from oracle.detweights import det_input
+    cores = min(os.cpu_count() or 1, 16)               # see cpu_baseline: the measured optimum for batch 1 on the GPU box's host
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    ts = TrainStepRef()
+    gt = det_input((1, 3, size, size), seed=99)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    ts.step(haze, gt)                                  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ts.step(haze, gt)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 20:
+            break
+    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full training steps (G + Fusion-D + VGG16 + SSIM, Adam), batch 1 @%dx%d, fp32 PyTorch-CPU oracle "
+                      "(oracle/train_ref.py), %.1f s" % (n, size, size, dt)}
+
+
+# Algorithmic HBM bytes / flops of one launch of the kernels that can dominate the training step, from the arguments
+# of the engine call that issues it (exactly one launch of that name per call).
+def _bytes_bn_bwd_apply(args, kw):
+    dpre_fd, accumulate = args[0], (args[6] if len(args) > 6 else kw.get("accumulate", False))
+    px = dpre_fd.n * dpre_fd.h * dpre_fd.w
+    return px * dpre_fd.c * 2 * (4 if accumulate else 3), 0.0      # read dpre, x (and dx), write dx; bf16
+
+
+def _bytes_bn_act_bwd(args, kw):
+    da_fd = args[0]
+    return da_fd.n * da_fd.h * da_fd.w * da_fd.c * 2 * 3, 0.0      # read da, x, write da
+
+
+MODELS = {"bn_bwd_apply": ("bn_bwd_apply", _bytes_bn_bwd_apply), "bn_act_bwd": ("bn_act_bwd", _bytes_bn_act_bwd)}
+
+
+def train_bench(a, dp, dev, B, S):
+    import numpy as np
+    import torch
+    import train as train_mod
+    from fdgan_hip import engine as E
+    world, rank = dp.world, dp.rank
+    ts = train_mod.TrainStep(dev, dp=dp)
+    gt = torch.from_numpy(np.random.default_rng(99 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    for _ in range(max(a.warmup, 1)):
+        ts.step(haze, gt)
+    torch.cuda.synchronize()
+    # ---- one instrumented step (every launch bracketed) -> GPU time per launcher name
+    E.kernel_timer_arm(None, 1, 16384)
+    ts.step(haze, gt)
+    torch.cuda.synchronize()
+    samples, n_launch = E.kernel_timer_read(16384)
+    by_name = {}
+    for _, ms, name in samples:
+        d = by_name.setdefault(name, [0, 0.0])
+        d[0] += 1
+        d[1] += ms
+    lib_ms = sum(v[1] for v in by_name.values())
+    ranking = sorted(by_name.items(), key=lambda kv: -kv[1][1])
+    dom_name = next((n for n, _ in ranking if n in MODELS), None)   # the top kernel with a byte model (see `roofline.ranking`)
+    # ---- per-call algorithmic bytes of the dominant kernel, recorded by wrapping its engine entry point
+    per_call = []
+    if dom_name is not None:
+        fn_name, model = MODELS[dom_name]
+        orig = getattr(E, fn_name)
+
+        def wrapped(*args, **kw):
+            per_call.append(model(args, kw))
+            return orig(*args, **kw)
+        setattr(E, fn_name, wrapped)               # backward.py looks the function up on the module at call time
+    if dom_name is not None:
+        stride = max(1, by_name[dom_name][0] // 8)                  # ~8 bracketed launches per step
+        E.kernel_timer_arm(dom_name, stride, min(65536, 16 * a.steps + 16))
+    dp.barrier()                                   # torch.cuda.synchronize() + a collective barrier when world > 1
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = ts.step(haze, gt)
+    dp.barrier()
+    dt = dp.max_over_ranks(time.perf_counter() - t0)
+    images = dp.sum_over_ranks(B * a.steps)
+    roof = None
+    if dom_name is not None:
+        timed, seen = E.kernel_timer_read(65536)
+        setattr(E, MODELS[dom_name][0], orig)
+        assert seen == len(per_call), (seen, len(per_call))
+        byts = sum(per_call[i][0] for i, _, _ in timed)
+        t_ms = sum(ms for _, ms, _ in timed)
+        ach = byts / (t_ms * 1e-3) / 1e9
+        n_step = by_name[dom_name][0]
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": dom_name, "launches_per_step": n_step, "launches_timed": len(timed),
+                "avg_launch_us": round(t_ms / max(len(timed), 1) * 1e3, 2),
+                "algorithmic_mb_per_launch": round(sum(b for b, _ in per_call) / max(len(per_call), 1) / 1e6, 2),
+                "share_of_library_gpu_time": round(by_name[dom_name][1] / lib_ms, 3),
+                "ranking_ms_per_step": {n: round(v[1], 3) for n, v in ranking[:8]}}
+        try:   # HBM bytes of this kernel from the committed PMC passes (same workload), else null
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f).get("%s@train_B%d_%d" % (dom_name, B, S))
+            if pmc:
+                traffic_mb = (2.0 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024 / 1e6
+                roof["traffic_mb_per_launch"] = round(traffic_mb, 2)
+                roof["traffic"] = round(ach * traffic_mb / roof["algorithmic_mb_per_launch"], 1)
+        except (OSError, ValueError):
+            pass
+    res = None
+    if rank == 0:
+        res = {"metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "full training step (fd-gan_amd/train.py; BASELINE.json configs[%d]): G fwd+bwd, Fusion-D 3 fwd + 3 "
+                                      "bwd, VGG16 2 fwd + 1 bwd, SSIM, Adam(G), Adam(D), gradient all-reduce when n_gpus > 1; batch %d @ "
+                                      "%dx%d per GPU; loss composition reconstructed (the reference ships no training loop)"
+                                      % (2 if world == 1 else 3, B, S, S),
+                          "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
+                          "library_launches_per_step": n_launch, "library_gpu_ms_per_step_instrumented": round(lib_ms, 2),
+                          "last_losses": {k: round(v, 4) for k, v in last.items()}},
+               "roofline": roof, "cpu_baseline": None}
+    del ts
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -124,34 +257,16 @@ def main():
     x = torch.from_numpy(np.random.default_rng(1234 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
 
     barrier = dp.barrier
-    if a.train:
-        import train as train_mod
-        ts = train_mod.TrainStep(dev, dp=dp)
-        gt = torch.from_numpy(np.random.default_rng(99 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
-        haze = (gt * 0.6 + 0.3).clamp(0, 1)
-        for _ in range(max(a.warmup, 1)):
-            ts.step(haze, gt)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            last = ts.step(haze, gt)
-        barrier()
-        dt = dp.max_over_ranks(time.perf_counter() - t0)
-        images = dp.sum_over_ranks(B * a.steps)
-        if rank == 0:
-            print(json.dumps({
-                "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
-                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "full training step (fd-gan_amd/train.py): G fwd+bwd, Fusion-D 3 fwd + 3 bwd, VGG16 2 fwd + 1 "
-                                       "bwd, SSIM, Adam(G), Adam(D), gradient all-reduce when n_gpus > 1; batch %d @ %dx%d per GPU; "
-                                       "loss composition reconstructed (the reference ships no training loop)" % (B, S, S),
-                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
-                           "last_losses": {k: round(v, 4) for k, v in last.items()}},
-                "roofline": None, "cpu_baseline": None}), flush=True)
-        dp.close()
-        return
+    train_res = None
+    if not a.forward and not a.train_g:
+        train_res = train_bench(a, dp, dev, B, S)
+        if a.no_forward_leg or world != 1:
+            if rank == 0:
+                if world == 1 and not a.no_cpu_baseline:
+                    train_res["cpu_baseline"] = cpu_baseline_train(S, a.cpu_seconds)
+                print(json.dumps(train_res), flush=True)
+            dp.close()
+            return
     if a.train_g:
         tgt = torch.rand(B, 3, S, S, device=dev) * 2 - 1
 
@@ -294,9 +409,16 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
             with open(a.breakdown, "w") as f:
                 json.dump({"total_ms_instrumented": total_ms, "rows": rows}, f, indent=1)
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cpu_sd, S, a.cpu_seconds)
-        print(json.dumps(res), flush=True)
+        if train_res is not None:       # default line: the training step, with the forward-only measurement attached
+            train_res["forward_only"] = {"value": res["value"], "unit": "images/sec", "ms_per_step": res["ms_per_step"],
+                                         "workload": res["config"]["workload"], "roofline": res["roofline"]}
+            if world == 1 and not a.no_cpu_baseline:
+                train_res["cpu_baseline"] = cpu_baseline_train(S, a.cpu_seconds)
+            print(json.dumps(train_res), flush=True)
+        else:
+            if world == 1 and not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(cpu_sd, S, a.cpu_seconds)
+            print(json.dumps(res), flush=True)
     dp.close()
 
 

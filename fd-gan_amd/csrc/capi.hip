@@ -29,11 +29,81 @@ extern "C" const char* fdgan_device_arch(void) {
   return arch;
 }
 
+// ---- kernel timer: hipEvent pairs around selected launches, on the stream they are launched on -----------------
+// (bench.py's roofline leg: the average duration of the dominant kernel inside the timed region; every launch of
+// the library -- eager or replayed from a plan -- passes through do_launch)
+namespace {
+struct KernelTimer {
+  bool armed = false, all = false;
+  char name[64] = "";
+  int stride = 1, seen = 0, launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // pre-created pool
+  std::vector<int> call;                               // index of the sampled launch among the matching launches
+  std::vector<const char*> names;                      // launcher name of each sample
+};
+KernelTimer g_kt;
+}  // namespace
+
 static int do_launch(const FdLaunch& L, hipStream_t stream) {
   void* argv[1] = {const_cast<char*>(L.arg.data())};
+  int slot = -1;
+  if (g_kt.armed && (g_kt.all || strcmp(L.name, g_kt.name) == 0)) {
+    if (g_kt.seen % g_kt.stride == 0 && g_kt.call.size() < g_kt.ev.size()) {
+      slot = (int)g_kt.call.size();
+      g_kt.call.push_back(g_kt.seen);
+      g_kt.names.push_back(L.name);
+      (void)hipEventRecord(g_kt.ev[slot].first, stream);
+    }
+    ++g_kt.seen;
+  }
   hipError_t e = hipLaunchKernel(L.fn, L.grid, L.block, argv, L.shmem, stream);
+  if (slot >= 0) (void)hipEventRecord(g_kt.ev[slot].second, stream);
   if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "launch %s grid=(%u,%u,%u) block=%u lds=%u: %s", L.name, L.grid.x, L.grid.y,
                                L.grid.z, L.block.x, L.shmem, hipGetErrorString(e));
+  return FD_OK;
+}
+
+extern "C" int fdgan_kernel_timer_arm(const char* name, int stride, int max_samples) {
+  FD_REQUIRE(stride >= 1 && max_samples >= 1 && max_samples <= (1 << 16), "kernel_timer_arm: stride %d, max_samples %d", stride, max_samples);
+  FD_REQUIRE(!g_kt.armed, "kernel_timer_arm: already armed (read it first)");
+  g_kt.all = name == nullptr || strcmp(name, "*") == 0;
+  strncpy(g_kt.name, g_kt.all ? "*" : name, sizeof(g_kt.name) - 1);
+  g_kt.name[sizeof(g_kt.name) - 1] = 0;
+  g_kt.stride = stride, g_kt.seen = 0;
+  g_kt.call.clear(), g_kt.names.clear();
+  while ((int)g_kt.ev.size() < max_samples) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) FD_FAIL(FD_ELAUNCH, "kernel_timer_arm: hipEventCreate failed");
+    g_kt.ev.emplace_back(a, b);
+  }
+  while ((int)g_kt.ev.size() > max_samples) {
+    hipEventDestroy(g_kt.ev.back().first), hipEventDestroy(g_kt.ev.back().second);
+    g_kt.ev.pop_back();
+  }
+  g_kt.armed = true;
+  return FD_OK;
+}
+
+extern "C" int fdgan_kernel_timer_read(int capacity, int* n_out, int* matching_launches_out, int* call_index, float* ms,
+                                       char* names48) {
+  FD_REQUIRE(g_kt.armed, "kernel_timer_read: not armed");
+  FD_REQUIRE(n_out && capacity >= 0, "kernel_timer_read: bad arguments");
+  g_kt.armed = false;
+  const int n = (int)g_kt.call.size() < capacity ? (int)g_kt.call.size() : capacity;
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipEventSynchronize(g_kt.ev[i].second);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, g_kt.ev[i].first, g_kt.ev[i].second);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "kernel_timer_read: %s", hipGetErrorString(e));
+    if (ms) ms[i] = t;
+    if (call_index) call_index[i] = g_kt.call[i];
+    if (names48) {
+      strncpy(names48 + 48 * i, g_kt.names[i], 47);
+      names48[48 * i + 47] = 0;
+    }
+  }
+  *n_out = n;
+  if (matching_launches_out) *matching_launches_out = g_kt.seen;
   return FD_OK;
 }
 

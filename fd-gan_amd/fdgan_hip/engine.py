@@ -347,3 +347,17 @@ GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK = 0, 1, 2, 3
 def grad_ew(mode, src, dst, ref=None):
     L.check(L.load().fdgan_grad_ew(mode, C.byref(src.fd), C.byref(ref.fd) if ref is not None else None, C.byref(dst.fd),
                                    stream_ptr()), "grad_ew")
+
+
+def kernel_timer_arm(name=None, stride=1, max_samples=4096):
+    """Bracket every `stride`-th launch named `name` (None: every launch) with hipEvents on its stream."""
+    L.check(L.load().fdgan_kernel_timer_arm(name.encode() if name else None, stride, max_samples), "kernel_timer_arm")
+
+
+def kernel_timer_read(capacity=65536):
+    """-> (list of (launch index among the matching launches, ms, launcher name), number of matching launches)."""
+    n, seen = C.c_int(0), C.c_int(0)
+    idx, ms, names = (C.c_int * capacity)(), (C.c_float * capacity)(), C.create_string_buffer(48 * capacity)
+    L.check(L.load().fdgan_kernel_timer_read(capacity, C.byref(n), C.byref(seen), idx, ms, names), "kernel_timer_read")
+    out = [(idx[i], ms[i], names.raw[48 * i:48 * i + 48].split(b"\0", 1)[0].decode()) for i in range(n.value)]
+    return out, seen.value

@@ -318,6 +318,14 @@ int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, i
  * in DESIGN.md was taken this way).  The shipped kernels carry no instrumentation; NULL disables. */
 int fdgan_debug_timing(void* device_buf);
 
+/* Kernel timer (measurement aid, used by bench.py's roofline leg): while armed, every `stride`-th launch whose launcher
+ * name equals `name` (NULL or "*": every launch of the library, eager or replayed from a plan) is bracketed by a
+ * hipEvent pair on the stream it is launched on, up to max_samples.  fdgan_kernel_timer_read waits for the events,
+ * returns per sample the index of the launch among the matching launches, its duration in ms and (names48: 48 bytes
+ * per sample, may be NULL) its launcher name, and disarms.  One timer per process; not thread-safe. */
+int fdgan_kernel_timer_arm(const char* name, int stride, int max_samples);
+int fdgan_kernel_timer_read(int capacity, int* n_out, int* matching_launches_out, int* call_index, float* ms, char* names48);
+
 #ifdef __cplusplus
 }
 #endif
