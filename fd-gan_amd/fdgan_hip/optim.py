@@ -45,6 +45,9 @@ class FlatAdam:
         L.check(L.load().fdgan_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          self.flat.numel(), lr, self.betas[0], self.betas[1], self.eps, self.t, E.stream_ptr()),
                 "adam_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters, which is what the
+        # planned modules watch to re-pack their MFMA filter images (netplan.refresh_weights)
+        torch.autograd.graph.increment_version(self.params)
 
     def allreduce_grads(self, ctx, bucket_mb=8.0):
         """Data-parallel gradient averaging on the flat buffer: RCCL all-reduce of contiguous slices, last slice

@@ -666,6 +666,12 @@ def test_training_step_smoke():
     for r in (r1, r2):
         assert all(np.isfinite(v) for v in r.values()), r
     assert not torch.equal(w0, ts.netG.conv_refin3.weight) and not torch.equal(d0, ts.netD.main.layer4.conv.weight)
+    with torch.no_grad():                                         # the next forward runs on the UPDATED weights
+        probe = torch.rand(2, 9, 64, 64, device=DEV)
+        y_now = ts.netD(probe).clone()
+        fresh = type(ts.netD)(9, 36).to(DEV)
+        fresh.load_state_dict(ts.netD.state_dict())
+        assert torch.allclose(y_now, fresh(probe), atol=2e-3), float((y_now - fresh(probe)).abs().max())
     assert int(ts.netG.trans_block3.norm.num_batches_tracked) == 2
     assert ts.netG.conv0.weight.grad is None                      # never-called modules stay untouched
     _report("train_step_smoke", {"step1": r1, "step2": r2})
@@ -676,6 +682,47 @@ def test_training_step_smoke():
     _ = ts.netD(fusion)
     with pytest.raises(RuntimeError, match="another forward"):
         y1.mean().backward()
+
+
+def test_training_step_matches_oracle_step():
+    """One full training step (fd-gan_amd/train.py) against the CPU oracle's step (oracle/train_ref.py) from the same
+    weights and images: every loss term, and the direction of the first Adam update of both networks (Adam's first step is
+    lr * sign(g) up to eps: compared where the oracle's gradient is well away from zero)."""
+    import train
+    from oracle.train_ref import TrainStepRef
+    from oracle.detweights import det_input
+    ts = train.TrainStep(torch.device(DEV))
+    sd_g = {k: v.detach().cpu().clone() for k, v in ts.netG.state_dict().items()}
+    sd_d = {k: v.detach().cpu().clone() for k, v in ts.netD.state_dict().items()}
+    sd_v = {k: v.detach().cpu().clone() for k, v in ts.vgg.state_dict().items()}
+    ref = TrainStepRef(sd_g, sd_d, sd_v)
+    gt = det_input((2, 3, 64, 64), seed=5)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    r_ref = ref.step(haze, gt)
+    r = ts.step(haze.to(DEV), gt.to(DEV))
+    torch.cuda.synchronize()
+    rep = {"hip": r, "oracle": r_ref}
+    tol = {"lossD": 0.02, "lossG": 0.02, "l1": 0.02, "ssim": 0.05, "perc": 0.05, "adv": 0.02}
+    for k, t in tol.items():
+        assert abs(r[k] - r_ref[k]) <= t * max(abs(r_ref[k]), 0.05), (k, r[k], r_ref[k])
+    # first Adam step: w <- w - lr * g / (|g| + eps): the update's sign is the gradient's sign
+    agree = {}
+    for name, net_hip, net_ref, sd0 in (("D", ts.netD, ref.netD, sd_d), ("G", ts.netG, ref.netG, sd_g)):
+        same = total = 0
+        for (k, p), (_, q) in zip(net_hip.named_parameters(), net_ref.named_parameters()):
+            du_ref = (q.detach() - sd0[k]).flatten()
+            du_hip = (p.detach().cpu() - sd0[k]).flatten()
+            g = q.grad
+            if g is None or float(du_ref.abs().max()) == 0.0:
+                continue
+            g = g.flatten()
+            sel = g.abs() > 0.2 * g.abs().mean()                 # gradients well away from zero
+            same += int((torch.sign(du_ref[sel]) == torch.sign(du_hip[sel])).sum())
+            total += int(sel.sum())
+        agree[name] = same / max(total, 1)
+    rep["first_update_sign_agreement"] = agree
+    _report("train_step_vs_oracle", rep)
+    assert agree["D"] > 0.97 and agree["G"] > 0.90, agree
 
 
 def test_flat_gradient_sink_equals_autograd_accumulation():

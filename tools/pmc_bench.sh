@@ -19,13 +19,16 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-names = {"conv1x1_ds_kernel": "conv1x1_ds_bn128", "conv3x3_rs_kernel": "conv3x3_rs_bn32"}
-res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (netG fwd B=16 @256^2); KiB; "
+# kernel symbol -> (launcher name, workload key): the forward kernels are keyed on the forward-only workload, the
+# BatchNorm-backward pass on the training step (both run in the default bench.py)
+names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
+         "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256")}
+res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (training step + netG forward leg, B=16 @256^2); KiB; "
                    "FETCH_SIZE is x2-corrected by bench.py per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
 for k, cs in agg.items():
-    for sym, nm in names.items():
+    for sym, (nm, wl) in names.items():
         if sym in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            res["%s@netG_B16_256" % nm] = {"fetch_kib": sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]),
+            res["%s@%s" % (nm, wl)] = {"fetch_kib": sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]),
                                            "write_kib": sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]),
                                            "launches": len(cs["FETCH_SIZE"]), "symbol": k[:80]}
 json.dump(res, open(dst, "w"), indent=1)

@@ -24,6 +24,15 @@ def main(db):
     print("# total kernel time %.3f ms over %d dispatches" % (tot / 1e6, sum(r[7] for r in rows)))
     print("%-58s %9s %5s %6s %5s %6s %10s %9s %9s %9s %6s" % ("kernel", "grid", "wg", "lds", "vgpr", "calls",
                                                             "total_us", "avg_us", "min_us", "max_us", "pct"))
+    # per kernel over all grids: the average duration bench.py's roofline object is checked against
+    agg = {}
+    for r in rows:
+        d = agg.setdefault(short(r[0]), [0, 0.0])
+        d[0] += r[7]
+        d[1] += r[8]
+    print("# per kernel, all grids:  calls  total_us  avg_us  pct")
+    for k, (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print("#   %-56s %7d %11.1f %9.2f %6.2f" % (k, n, s / 1e3, s / n / 1e3, 100.0 * s / tot))
     for r in rows:
         name, gx, gy, wx, lds, vg, ag, n, s, a, mn, mx = r
         print("%-58s %9s %5d %6d %5d %6d %10.1f %9.2f %9.2f %9.2f %6.2f" % (
