@@ -75,6 +75,10 @@ class _InPlace:
 
 IN_PLACE = _InPlace()
 
+# Called as PROGRESS_HOOK(plan_backward, record_index) after each record of a reverse walk is done: the optimizer's
+# gradient all-reduce rides on it (optim.FlatAdam.overlap), so RCCL runs while the rest of the backward computes.
+PROGRESS_HOOK = None
+
 
 def grad_sink(p):
     """The fp32 tensor gradients of `p` may be added into directly, or None: FlatAdam marks its parameters with
@@ -151,6 +155,19 @@ class PlanBackward:
         self.ws_bn = torch.empty(1 << 24, dtype=torch.float32, device=dev)   # BatchNorm-backward partial sums (64 MiB)
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
+
+    def record_params(self, i):
+        """Parameters whose gradient record i's backward adds to (conv weight, bias, the prologue's BatchNorm pair)."""
+        r = self.recs[i]
+        if r["kind"] != "conv":
+            return []
+        out = [r["w"].param]
+        if r.get("bias") is not None:
+            out.append(r["bias"])
+        bn = r["pro"]._meta.get("bn") if r.get("pro") is not None else None
+        if bn is not None and bn.weight is not None:
+            out += [bn.weight, bn.bias]
+        return [p for p in out if p.requires_grad]
 
     def G(self, view):
         return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
@@ -293,3 +310,5 @@ class PlanBackward:
             self.conv_backward(r, dyv, grads, need_dx=(id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of))
             if y.buf.data_ptr() in self.multi_version:
                 self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer writes a fresh gradient here
+            if PROGRESS_HOOK is not None:
+                PROGRESS_HOOK(self, i)

@@ -49,6 +49,14 @@ class FlatAdam:
         # planned modules watch to re-pack their MFMA filter images (netplan.refresh_weights)
         torch.autograd.graph.increment_version(self.params)
 
+    def overlap(self, ctx, bucket_mb=8.0, reduce_fn=None):
+        """Context manager around a backward(): all-reduce slices of the flat gradient AS SOON AS every layer that
+        contributes to them has run its backward, while the rest of the backward keeps computing (RCCL on its own stream;
+        xGMI rings are per-link bound, so slices are >= bucket_mb to stay bandwidth- rather than latency-priced).
+        Leaving the context reduces whatever is left, waits, and divides by the world size.  reduce_fn(lo, hi): test
+        hook replacing the collective."""
+        return _Overlap(self, ctx, bucket_mb, reduce_fn)
+
     def allreduce_grads(self, ctx, bucket_mb=8.0):
         """Data-parallel gradient averaging on the flat buffer: RCCL all-reduce of contiguous slices, last slice
         first (the parameters whose gradients are produced first by the backward walk live at the end)."""
@@ -64,3 +72,76 @@ class FlatAdam:
             w.wait()
         self.grad.div_(ctx.world)
         return len(works)
+
+
+class _Overlap:
+    def __init__(self, opt, ctx, bucket_mb, reduce_fn):
+        self.opt, self.ctx, self.reduce_fn = opt, ctx, reduce_fn
+        self.active = reduce_fn is not None or (ctx is not None and ctx.world > 1)
+        self.bucket = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.index = {id(p): k for k, p in enumerate(opt.params)}
+        self.tables = {}                    # id(PlanBackward) -> per-record parameter indices
+        self.pending = None                 # per parameter: records of the walks seen so far that still have to run
+        self.sent = [False] * len(opt.params)
+        self.touched = [False] * len(opt.params)
+        self.works, self.sent_early = [], 0
+
+    def __enter__(self):
+        if self.active:
+            from . import backward as BW
+            self._prev, BW.PROGRESS_HOOK = BW.PROGRESS_HOOK, self._progress
+        return self
+
+    def _progress(self, B, i):
+        tab = self.tables.get(id(B))
+        if tab is None:                     # first record of this walk: count every record's contributions
+            tab = self.tables[id(B)] = [[self.index[id(p)] for p in B.record_params(j) if id(p) in self.index]
+                                        for j in range(len(B.recs))]
+            if self.pending is None:
+                self.pending = [0] * len(self.opt.params)
+            for idxs in tab:
+                for k in idxs:
+                    self.pending[k] += 1
+                    self.touched[k] = True
+        for k in tab[i]:
+            self.pending[k] -= 1
+        self._sweep(final=False)
+
+    def _send(self, k0, k1):
+        lo, hi = self.opt.offsets[k0], self.opt.offsets[k1]
+        for k in range(k0, k1):
+            self.sent[k] = True
+        if self.reduce_fn is not None:
+            self.reduce_fn(lo, hi)
+        else:
+            import torch.distributed as dist
+            self.works.append(dist.all_reduce(self.opt.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _sweep(self, final):
+        """Contiguous runs of complete, not yet reduced parameters: reduce those of at least one bucket (all, at the end)."""
+        n, k = len(self.sent), 0
+        while k < n:
+            ready = lambda j: not self.sent[j] and (final or (self.touched[j] and self.pending[j] == 0))
+            if not ready(k):
+                k += 1
+                continue
+            k0 = k
+            while k < n and ready(k):
+                k += 1
+            if final or self.opt.offsets[k] - self.opt.offsets[k0] >= self.bucket:
+                self._send(k0, k)
+                if not final:
+                    self.sent_early += 1
+
+    def __exit__(self, et, ev, tb):
+        if not self.active:
+            return False
+        from . import backward as BW
+        BW.PROGRESS_HOOK = self._prev
+        if et is None:
+            self._sweep(final=True)
+            for w in self.works:
+                w.wait()
+            if self.reduce_fn is None:
+                self.opt.grad.div_(self.ctx.world)
+        return False

@@ -100,8 +100,8 @@ class TrainStep:
         p_adv = self.netD(fusion_input(fake))
         l_adv = F.binary_cross_entropy(p_adv, torch.ones_like(p_adv))
         lossG = self.w["l1"] * l_l1 + self.w["ssim"] * l_ssim + self.w["perc"] * l_perc + self.w["adv"] * l_adv
-        lossG.backward()
-        self.optG.allreduce_grads(self.dp)
+        with self.optG.overlap(self.dp):            # slices of the flat gradient are all-reduced while the backward still runs
+            lossG.backward()
         self.optG.step()
         out.update({k: float(v.detach()) for k, v in dict(lossG=lossG, l1=l_l1, ssim=1.0 - l_ssim, perc=l_perc, adv=l_adv).items()})
         return out

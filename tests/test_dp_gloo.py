@@ -113,3 +113,56 @@ def test_two_rank_flat_gradient_allreduce(tmp_path):
         assert x["nb"] >= 2 and x["ok_alias"] and x["stepped"] is False      # the Adam update itself needs the GPU
         for g in x["g"]:
             assert torch.allclose(g, torch.full_like(g, 1.5))                  # mean of 1 and 2
+
+
+class _FakeWalk:
+    """Stands in for fdgan_hip.backward.PlanBackward: records -> the parameters their backward adds to."""
+
+    def __init__(self, per_record):
+        self.recs = per_record
+
+    def record_params(self, i):
+        return list(self.recs[i])
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from fdgan_hip import backward as BW
+    from fdgan_hip.dp import DpContext
+    from fdgan_hip.optim import FlatAdam
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(0)
+    sizes = [300, 5, 700, 64, 1200, 9, 800, 33]
+    params = [torch.nn.Parameter(torch.randn(n)) for n in sizes]
+    opt = FlatAdam(params)
+    # forward order of use: p6 (registered late, used first), p0, p1+p2, p3, p4+p5, p7; p1 is used twice
+    walk = _FakeWalk([[params[6]], [params[0]], [params[1], params[2]], [params[3]], [params[4], params[5], params[1]], [params[7]]])
+    opt.zero_grad()
+    with opt.overlap(dp, bucket_mb=1000 * 4 / (1 << 20)) as ov:                  # bucket = 1000 floats
+        for i in range(len(walk.recs) - 1, -1, -1):                               # the reverse walk
+            for p in walk.recs[i]:
+                p.grad.add_(float(rank + 1) * (i + 1))                            # this record's contribution on this rank
+            BW.PROGRESS_HOOK(walk, i)
+        early = ov.sent_early
+    assert BW.PROGRESS_HOOK is None
+    torch.save(dict(grad=opt.grad.clone(), early=early), os.path.join(out_dir, "ov%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_overlapped_allreduce_of_the_flat_gradient(tmp_path):
+    """FlatAdam.overlap: slices go out during the walk once every contributing record has run (a parameter used by two
+    records, one registered late but used first), the rest at the end; both ranks end with the mean."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "ov%d.pt" % i)) for i in range(world)]
+    assert torch.equal(r[0]["grad"], r[1]["grad"])
+    # expected mean over ranks of (rank + 1) * sum over records using the parameter of (record index + 1)
+    uses = {0: [2], 1: [3, 5], 2: [3], 3: [4], 4: [5], 5: [5], 6: [1], 7: [6]}
+    sizes = [300, 5, 700, 64, 1200, 9, 800, 33]
+    off = 0
+    for k, n in enumerate(sizes):
+        want = 1.5 * sum(uses[k])
+        assert torch.allclose(r[0]["grad"][off:off + n], torch.full((n,), want)), k
+        off += (n + 3) // 4 * 4
+    assert r[0]["early"] >= 1            # at least one slice left before the walk ended

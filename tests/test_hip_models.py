@@ -725,6 +725,37 @@ def test_training_step_matches_oracle_step():
     assert agree["D"] > 0.97 and agree["G"] > 0.85, agree      # bf16 storage flips the sign of some near-zero generator gradients
 
 
+def test_overlapped_allreduce_slices_are_final_when_sent():
+    """FlatAdam.overlap on the real generator backward: every slice handed to the collective during the walk already
+    holds its final gradient (snapshot at send time == gradient after backward), the slices tile the flat buffer
+    exactly once, and most of the bytes leave before the walk ends."""
+    import models.dehaze1113 as net
+    from fdgan_hip.optim import FlatAdam
+    import train
+    torch.manual_seed(11)
+    g = net.FDGAN().to(DEV)
+    params = train.TrainStep._params_with_grad(g, torch.device(DEV))
+    opt = FlatAdam(params)
+    opt.zero_grad()
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    tgt = torch.rand(2, 3, 64, 64, device=DEV) * 2 - 1
+    y = g(x)
+    sent = []
+    ov = opt.overlap(None, bucket_mb=4.0, reduce_fn=lambda lo, hi: sent.append((lo, hi, opt.grad[lo:hi].clone())))
+    with ov:
+        ((y - tgt) ** 2).mean().backward()
+        n_early = len(sent)
+    torch.cuda.synchronize()
+    cover = sorted((lo, hi) for lo, hi, _ in sent)
+    assert cover[0][0] == 0 and cover[-1][1] == opt.grad.numel()
+    assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))                    # no gap, no overlap
+    for lo, hi, snap in sent:
+        assert torch.equal(snap, opt.grad[lo:hi]), (lo, hi)
+    early_bytes = sum(hi - lo for lo, hi, _ in sent[:n_early])
+    assert n_early >= 3 and early_bytes > 0.5 * opt.grad.numel(), (n_early, early_bytes, opt.grad.numel())
+    assert float(opt.grad.abs().sum()) > 0
+
+
 def test_flat_gradient_sink_equals_autograd_accumulation():
     """With FlatAdam the backward walk adds weight / bias / BatchNorm gradients straight into the flat gradient views
     (no autograd accumulation): two backward passes (the real and the fake half of a discriminator step) must leave
