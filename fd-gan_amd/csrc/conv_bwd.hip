@@ -1029,6 +1029,105 @@ extern "C" int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int
                    static_cast<hipStream_t>(stream));
 }
 
+// ---- deferred affine part of BatchNorm's backward ---------------------------------------------------------------
+// dx = A * dpre + B * x + C (see bn_bwd_apply).  fdgan_conv2d_bwd_data(accumulate = 1) already added A * dpre to the
+// gradient buffer from its epilogue; B and C depend on the reductions, are per channel, and are LINEAR in x -- so the
+// layers of a dense block that normalise the same channels add their (B, C) into one coefficient pair and a single
+// pass dx += Bsum * x + Csum serves them all, right before the gradient of those channels is consumed.
+struct BnCoefArgs {
+  const float *dgamma, *dbeta, *mean, *var, *gamma;
+  float eps, inv_m;
+  int channels;
+  float *bsum, *csum;
+};
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(BnCoefArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.channels) return;
+  const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f;
+  const float A = gmm * rs, B = -gmm * rs * rs * a.dgamma[c] * a.inv_m;
+  a.bsum[c] += B;
+  a.csum[c] += -A * a.dbeta[c] * a.inv_m - B * a.mean[c];
+}
+
+struct AffineAccArgs {
+  const unsigned short* x;
+  long long x_sn;
+  int x_sh, x_sw;
+  unsigned short* dx;
+  long long dx_sn;
+  int dx_sh, dx_sw;
+  int H, W, C, C8;
+  long long P;
+  const float *bsum, *csum;
+};
+__global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
+  const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
+  const long long HW = (long long)a.H * a.W;
+  const int c8 = blockIdx.y * 8 + grp;
+  if (c8 >= a.C8) return;
+  float B[8], Cc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    B[e] = c < a.C ? a.bsum[c] : 0.f;
+    Cc[e] = c < a.C ? a.csum[c] : 0.f;
+  }
+  const long long stride = (long long)gridDim.x * 32;
+  for (long long p0 = (long long)blockIdx.x * 32 + slot; p0 < a.P; p0 += 4 * stride) {
+    u32x4 xv[4], gv[4];
+    unsigned short* op[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long p = p0 + k * stride;
+      op[k] = nullptr;
+      if (p < a.P) {
+        const long long n = p / HW, r = p - n * HW;
+        const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+        xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+        op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+        gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (op[k] == nullptr) continue;
+      const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[k]), f32x8);
+      f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += fmaf(B[e], xf[e], Cc[e]);
+      *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+    }
+  }
+}
+
+extern "C" int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,
+                                 float* bsum, float* csum, FdStream stream) {
+  FD_REQUIRE(dgamma && dbeta && pro && pro->mean && pro->var && bsum && csum && channels > 0 && count > 0, "bn_bwd_coef: bad arguments");
+  BnCoefArgs a{dgamma, dbeta, pro->mean, pro->var, pro->gamma, pro->eps, 1.f / (float)count, (int)channels, bsum, csum};
+  return fd_launch(&bn_bwd_coef_kernel, "bn_bwd_coef", dim3((unsigned)((channels + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream) {
+  if (int rc = check_view(x, "affine_accumulate(x)")) return rc;
+  if (int rc = check_view(dx, "affine_accumulate(dx)")) return rc;
+  FD_REQUIRE(bsum && csum && dx->n == x->n && dx->h == x->h && dx->w == x->w && dx->c == x->c, "affine_accumulate: shape mismatch");
+  AffineAccArgs a{};
+  a.x = static_cast<const unsigned short*>(x->ptr);
+  a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
+  a.dx = static_cast<unsigned short*>(dx->ptr);
+  a.dx_sn = dx->stride[0], a.dx_sh = (int)dx->stride[1], a.dx_sw = (int)dx->stride[2];
+  a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
+  a.P = (long long)x->n * x->h * x->w;
+  a.bsum = bsum, a.csum = csum;
+  const long long chunks = (a.C8 + 7) / 8;
+  long long rows = (a.P + 31) / 32, cap = 512 / chunks;
+  if (cap < 16) cap = 16;
+  if (rows > cap) rows = cap;
+  return fd_launch(&affine_acc_kernel, "affine_accumulate", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}
+
 extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                                   const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream) {
   if (int rc = check_view(dpre, "bn_bwd_apply(dpre)")) return rc;

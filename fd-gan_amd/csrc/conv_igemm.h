@@ -64,6 +64,7 @@ struct ConvArgs {
   int mk_sh, mk_sw;
   float mk_slope, mk_eps;
   const float *mk_mean, *mk_var, *mk_gamma, *mk_beta;
+  int mk_acc;                   // 1: y is the gradient buffer of x, updated as y += gamma * rstd * dpre (dpre itself is not stored)
   // in-kernel finalize by the last workgroup (kernels that set FdConvInfo.fused_finalize)
   float *fin_mean, *fin_var;
   unsigned* fin_counter;
@@ -247,12 +248,17 @@ __device__ __forceinline__ float fd_row_sum16(float v) {
 // Store 4 consecutive output channels (cout0 .. cout0+3) of one pixel; `off` is the element
 // offset of the pixel (n, up*oy, up*ox) in y.  Handles NCHW fp32 / NHWC bf16, the 2x2
 // replication of the nearest upsample and the ragged last channel group.
+template <bool ACC = false>
 __device__ __forceinline__ void fd_store4(const ConvArgs& a, long long off, int cout0, const float (&v)[4]) {
   if (!a.out_nchw_f32) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
     typedef __attribute__((ext_vector_type(4))) float f4_t;
-    const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[0], v[1], v[2], v[3]}, bf16x4_t));
     unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + off + cout0;
+    f4_t fv = {v[0], v[1], v[2], v[3]};
+    if constexpr (ACC) {   // backward data into a gradient buffer (no upsample, Cout % 4 == 0 checked by the host)
+      fv += __builtin_convertvector(__builtin_bit_cast(bf16x4_t, *reinterpret_cast<const u32x2*>(yp)), f4_t);
+    }
+    const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector(fv, bf16x4_t));
     if (cout0 + 4 <= a.Cout && !a.upsample) {  // the common case
       *reinterpret_cast<u32x2*>(yp) = bits;
       return;
@@ -296,7 +302,7 @@ struct RowStore {
   static constexpr int LPP = RB / 16;            // lanes per pixel on the way out
   static constexpr int PPI = 64 / LPP;           // pixels per store instruction
 };
-template <int CT, typename F>
+template <int CT, bool ACC = false, typename F>
 __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, const float (&v)[CT][4], int lane,
                                               int cout_base, F pixoff) {
   using R = RowStore<CT>;
@@ -315,10 +321,17 @@ __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, cons
 #pragma unroll
   for (int i = 0; i < 16 / R::PPI; ++i) {
     const int q = i * R::PPI + q0;
-    const u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
+    u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
     const long long off = pixoff(q);
-    if (off >= 0)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8) = row;
+    if (off >= 0) {
+      u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8);
+      if constexpr (ACC) {   // y += row (the gradient buffer of the forward input), whole 16-byte pieces of a pixel row
+        const f32x8 sum = __builtin_convertvector(__builtin_bit_cast(bf16x8, *dst), f32x8) +
+                          __builtin_convertvector(__builtin_bit_cast(bf16x8, row), f32x8);
+        row = __builtin_bit_cast(u32x4, __builtin_convertvector(sum, bf16x8));
+      }
+      *dst = row;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -565,8 +578,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       bv[c][r] = (a.bias != nullptr && co < a.CoutW) ? a.bias[co] : 0.f;
     }
   if constexpr (MK != 0) {
-    // backward data: mask the accumulators in place with the derivative of the forward prologue's activation and sum
-    // (v, v * fx) per channel -- what a separate pass over the stored tensor did before (bn_act_bwd: 7 ms per step)
+    // Backward data.  Row phase only: each 16-pixel x (CT*16)-channel accumulator tile goes through the wave's LDS staging
+    // area (as the forward's row stores do) and comes back as 16-byte pieces of pixel rows; the forward input x and (in
+    // accumulate mode) the gradient buffer are read in that same shape -- whole coalesced rows, one latency for both --
+    // and the lane keeps the 8 channels it owns for the whole tile: 16 coefficient registers, 16 running sums.
+    // v = da * act'(bn(x));  sums (v, v * x) per channel;  store v, or y += gamma * rstd * v.
+    using R = RowStore<CT>;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((ext_vector_type(4))) float f4_t;
     float* msc = red + WM * WN * CT * 16 * 2;   // [BN] scale, [BN] shift of this workgroup's channels
     float* msh = msc + C::BN;
     for (int cl = tid; cl < C::BN; cl += C::NT) {
@@ -581,50 +600,78 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       msh[cl] = sh;
     }
     __syncthreads();
+    const int piece = lane % R::LPP, q0 = lane / R::LPP;
+    const int cg = cbase + piece * 8;             // first of this lane's 8 channels
+    const bool ch_ok = cg < a.Cout;               // host: pixel pitch >= Cout rounded up to 8
+    float sc8[8], sh8[8], s1[8], s2[8];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int co0 = cbase + c * 16 + kgl * 4;
-      const f32x4 sc4 = *reinterpret_cast<const f32x4*>(msc + (co0 - by * C::BN));
-      const f32x4 sh4 = *reinterpret_cast<const f32x4*>(msh + (co0 - by * C::BN));
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-      u32x2 xv[PT];
-#pragma unroll
-      for (int p = 0; p < PT; ++p) {
-        const int row = oy0 + wm * PT + p;
-        xv[p] = u32x2{0u, 0u};
-        if (row < a.Ho && col < a.Wo && co0 < a.Cout)
-          xv[p] = *reinterpret_cast<const u32x2*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)col * a.mk_sw + co0);
-      }
-#pragma unroll
-      for (int p = 0; p < PT; ++p) {
-        const bool valid = (oy0 + wm * PT + p) < a.Ho && col < a.Wo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float fx = __uint_as_float(((xv[p][r >> 1] >> ((r & 1) * 16)) & 0xffffu) << 16);
-          const float pre = fmaf(fx, sc4[r], sh4[r]);
-          const float v = acc[p][c][r] * (pre > 0.f ? 1.f : a.mk_slope);
-          acc[p][c][r] = v;
-          s1[r] += valid ? v : 0.f;
-          s2[r] += valid ? v * fx : 0.f;
-        }
-      }
-      if (a.stats != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1[r] = fd_row_sum16(s1[r]);
-          s2[r] = fd_row_sum16(s2[r]);
-        }
-        if (m == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int idx = (wave * CT * 16 + c * 16 + kgl * 4 + r) * 2;
-            red[idx] = s1[r];
-            red[idx + 1] = s2[r];
-          }
-        }
-      }
+    for (int e = 0; e < 8; ++e) {
+      sc8[e] = msc[wn * CT * 16 + piece * 8 + e];
+      sh8[e] = msh[wn * CT * 16 + piece * 8 + e];
+      s1[e] = s2[e] = 0.f;
     }
-  }
+    unsigned short* ybase = reinterpret_cast<unsigned short*>(a.y);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int row = oy0 + wm * PT + p;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const u32x2 bits = __builtin_bit_cast(
+            u32x2, __builtin_convertvector((f4_t){acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]}, bf16x4_t));
+        *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + kgl * 8) = bits;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      u32x4 dav[16 / R::PPI], xv[16 / R::PPI], gv[16 / R::PPI];
+      long long offs[16 / R::PPI];
+#pragma unroll
+      for (int i = 0; i < 16 / R::PPI; ++i) {
+        const int q = i * R::PPI + q0;
+        const bool ok = ch_ok && row < a.Ho && ox0 + q < a.Wo;
+        offs[i] = ok ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw + cg : -1;
+        dav[i] = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
+        xv[i] = gv[i] = u32x4{0u, 0u, 0u, 0u};
+        if (ok) {
+          xv[i] = *reinterpret_cast<const u32x4*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)(ox0 + q) * a.mk_sw + cg);
+          if (a.mk_acc) gv[i] = *reinterpret_cast<const u32x4*>(ybase + offs[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16 / R::PPI; ++i) {
+        if (offs[i] < 0) continue;
+        const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dav[i]), f32x8);
+        const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+        f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pre = fmaf(fx[e], sc8[e], sh8[e]);
+          const float v = (cg + e < a.Cout) ? da[e] * (pre > 0.f ? 1.f : a.mk_slope) : 0.f;
+          s1[e] += v;
+          s2[e] += v * fx[e];
+          o[e] = a.mk_acc ? fmaf(sc8[e], v, o[e]) : v;
+        }
+        *reinterpret_cast<u32x4*>(ybase + offs[i]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (a.stats != nullptr) {   // lanes LPP apart own the same channels
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int dlt = R::LPP; dlt < 64; dlt <<= 1) {
+          s1[e] += __shfl_xor(s1[e], dlt, 64);
+          s2[e] += __shfl_xor(s2[e], dlt, 64);
+        }
+      }
+      if (q0 == 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = (wave * CT * 16 + piece * 8 + e) * 2;
+          red[idx] = s1[e];
+          red[idx + 1] = s2[e];
+        }
+    }
+  } else {
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int row = oy0 + wm * PT + p;
@@ -636,12 +683,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
         const float t = acc[p][c][r] + bv[c][r];
         v[c][r] = fmaxf(t, a.e_slope * t);
       }
+    auto pixoff = [&](int q) -> long long {
+      return (row < a.Ho && ox0 + q < a.Wo) ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw : -1;
+    };
     if (rowstore) {
-      fd_store_row16<CT>(a, tb, v, lane, cbase, [&](int q) -> long long {
-        return (row < a.Ho && ox0 + q < a.Wo)
-                   ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw
-                   : -1;
-      });
+      fd_store_row16<CT>(a, tb, v, lane, cbase, pixoff);
     } else if (row < a.Ho && col < a.Wo) {
       const long long off = (long long)n * a.y_sn + (long long)(up * row) * a.y_sh + (long long)(up * col) * a.y_sw;
 #pragma unroll
@@ -651,6 +697,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       }
     }
   }
+  }   // MK == 0: the forward epilogue
   if (a.stats != nullptr && MK == 0) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) {

@@ -183,17 +183,22 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
 
 /* Data gradient of a stride-1 conv fused with the backward of the conv's input-side prologue (include/fdgan_hip.h). */
 extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x,
-                                     const FdPrologue* fwd_pro, const FdTensor* dpre, float* partial, int64_t capacity_floats,
-                                     int64_t* rows_out, int64_t* cpad_out, const FdConvDesc* d, FdStream stream) {
+                                     const FdPrologue* fwd_pro, const FdTensor* dpre, int accumulate, float* partial,
+                                     int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, const FdConvDesc* d,
+                                     FdStream stream) {
   FD_REQUIRE(w_packed_flipped && d && dpre && fwd_x, "conv2d_bwd_data: NULL argument");
   FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv2d_bwd_data: packed weights must be 16-byte aligned");
   FD_REQUIRE(d->stride == 1 && !d->upsample2 && d->epilogue_act == FD_ACT_NONE && d->w_layout == FD_WLAYOUT_CHUNK32,
              "conv2d_bwd_data: stride-1 conv with the chunk32 filter image, no epilogue");
   FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv2d_bwd_data: a pooled prologue is differentiated at full resolution");
+  const int64_t c8 = (dpre->c + 7) / 8 * 8;
   FD_REQUIRE(dpre->dtype == FD_BF16 && fwd_x->dtype == FD_BF16 && fwd_x->n == dpre->n && fwd_x->h == dpre->h &&
-                 fwd_x->w == dpre->w && fwd_x->c >= dpre->c && fwd_x->stride[3] == 1 && fwd_x->stride[2] % 4 == 0 &&
-                 fwd_x->stride[1] % 4 == 0 && fwd_x->stride[0] % 4 == 0 && ((uintptr_t)fwd_x->ptr & 7) == 0 && dpre->c % 4 == 0,
-             "conv2d_bwd_data: fwd_x must be an NHWC bf16 view shaped like dpre (channels a multiple of 4, 8-byte aligned)");
+                 fwd_x->w == dpre->w && fwd_x->c >= dpre->c && fwd_x->stride[3] == 1 && dpre->stride[3] == 1,
+             "conv2d_bwd_data: fwd_x must be an NHWC bf16 view shaped like dpre");
+  for (const FdTensor* t : {fwd_x, dpre})   // the epilogue moves whole 16-byte pieces of pixel rows, pad channels included
+    FD_REQUIRE(t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0 &&
+                   (t->stride[2] >= c8 || t->w == 1),
+               "conv2d_bwd_data: fwd_x / dpre need 16-byte aligned pixel rows with the channels padded to a multiple of 8");
   ConvArgs a;
   long long nimg;
   bool pool;
@@ -208,6 +213,7 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
   const int act = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
   FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_LEAKY02, "conv2d_bwd_data: prologue activation %d", act);
   a.mk_mode = norm ? 2 : 1;
+  a.mk_acc = accumulate ? 1 : 0;
   a.mk_slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   a.mk_x = static_cast<const unsigned short*>(fwd_x->ptr);
   a.mk_sn = fwd_x->stride[0], a.mk_sh = (int)fwd_x->stride[1], a.mk_sw = (int)fwd_x->stride[2];

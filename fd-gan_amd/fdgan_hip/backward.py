@@ -154,6 +154,8 @@ class PlanBackward:
         self.ws = torch.empty(1 << 25, dtype=torch.float32, device=dev)      # split-K partials (128 MiB)
         self.ws_bn = torch.empty(1 << 24, dtype=torch.float32, device=dev)   # BatchNorm-backward partial sums (64 MiB)
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
+        self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
+        self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
 
     def record_params(self, i):
@@ -175,6 +177,10 @@ class PlanBackward:
     def zero_(self):
         for g in {id(g): g for g in self.gbuf.values()}.values():      # aliased gradient buffers once
             g.zero_()
+        for d in self.deferred.values():                                # nothing pending from an interrupted walk
+            if d["dirty"]:
+                d["coef"].zero_()
+                d["dirty"].clear()
 
     # ---- one fused convolution ---------------------------------------------------------------
     def conv_backward(self, r, dy_view, grads, need_dx=True):
@@ -218,7 +224,6 @@ class PlanBackward:
             E.conv_bwd_data_direct_nhwc(dy_view.fd, p.detach().contiguous(), desc, E.View(T, 0, cin), cin)
             return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
         hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
-        T = E.new_act(n, hin, win, _r8(cin), p.device)
         # the forward filter tensor in OIHW terms: ConvTranspose2d stores (cin, cout): already the transposed one
         if w.transposed:
             pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=False, layout=L.WLAYOUT_CHUNK32)
@@ -226,18 +231,76 @@ class PlanBackward:
             pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=True, layout=L.WLAYOUT_CHUNK32)
         pw.pack()
         ddesc = E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32)
-        masked = None
-        if not meta["pool"] and cin % 4 == 0 and self.fuse_mask:
-            # the activation mask and the BatchNorm sums ride in the data-gradient kernel's epilogue
-            bn = meta.get("bn")
-            if bn is not None and not meta.get("batch_stats", False):
-                raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
+        fusable = not meta["pool"] and x.c0 % 8 == 0 and self.fuse_mask
+        bn = meta.get("bn")
+        if fusable and bn is not None and not meta.get("batch_stats", False):
+            raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
+        if fusable:
             act_pro = (E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"], beta=meta["beta"],
                                        eps=meta["eps"]) if bn is not None else E.make_prologue(act=meta["act"]))
+        if fusable and self.defer_affine:
+            # One pass: the data-gradient kernel masks, sums BatchNorm's two reductions and adds gamma * rstd * dpre straight
+            # into G[x]; what is left of BatchNorm's backward, B * x + C per channel, is linear in x and waits in the buffer's
+            # coefficient pair until the gradient of those channels is read (flush) -- shared by every layer that normalises
+            # them (dense blocks).  dpre is never stored.
+            gx = self.G(x)
+            rows, cpad = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
+                                         accumulate=True)
+            if bn is not None:
+                dg = torch.empty(cin, dtype=torch.float32, device=p.device)
+                dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
+                train_bn = bn.weight is not None and bn.weight.requires_grad
+                E.bn_bwd_finalize_raw(self.ws_bn, rows, cpad, cin, meta["mean"], meta["var"], meta["eps"], dg, dbt,
+                                      sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                                      sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+                d = self._deferred(x)
+                E.bn_bwd_coef(dg, dbt, act_pro, cin, n * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
+                d["dirty"].update(range(x.c0, x.c0 + cin))
+            if check:
+                self.flush(x)
+                added = self.G(x).torch_nchw() - gx_before
+                rec["dx"] = float((added - dx_ref).norm() / (dx_ref.norm() + 1e-30))
+                rec["dx_scale"] = float(dx_ref.abs().mean() / (gx_before.abs().mean() + 1e-30))
+                self.checks.append(rec)
+            return
+        T = E.new_act(n, hin, win, _r8(cin), p.device)
+        masked = None
+        if fusable:     # the activation mask and the BatchNorm sums ride in the data-gradient kernel's epilogue
             masked = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, E.View(T, 0, cin).fd, ddesc, self.ws_bn if bn is not None else None)
         else:
             E.conv2d(dy_view.fd, pw, None, None, E.View(T).fd, ddesc)
         return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None, masked=masked)
+
+    # ---- deferred affine part of BatchNorm's backward (see conv_backward) ----------------------------------------
+    def _deferred(self, view):
+        d = self.deferred.get(view.buf.data_ptr())
+        if d is None:
+            d = self.deferred[view.buf.data_ptr()] = dict(
+                buf=view.buf, coef=torch.zeros((2, view.buf.shape[-1]), dtype=torch.float32, device=view.buf.device), dirty=set())
+        return d
+
+    def flush(self, view):
+        """Before G[view] is read: add the pending Bsum * x + Csum of its channels."""
+        d = self.deferred.get(view.buf.data_ptr())
+        if d is None or not d["dirty"]:
+            return
+        c0, c1 = view.c0, view.c0 + view.c
+        if d["dirty"].isdisjoint(range(c0, c1)):
+            return
+        lo, hi = c0 - c0 % 8, min(d["buf"].shape[-1], (c1 + 7) // 8 * 8)      # whole 8-channel groups (clean ones add zero)
+        xv = E.View(d["buf"], lo, hi - lo)
+        E.affine_accumulate(xv.fd, d["coef"][0, lo:hi], d["coef"][1, lo:hi], self.G(xv).fd)
+        d["coef"][:, lo:hi].zero_()
+        d["dirty"].difference_update(range(lo, hi))
+
+    def flush_all(self):
+        for d in self.deferred.values():
+            while d["dirty"]:
+                c = min(d["dirty"])
+                hi = c
+                while hi in d["dirty"]:
+                    hi += 1
+                self.flush(E.View(d["buf"], c, hi - c))
 
     def _prologue_backward(self, r, T, meta, grads, check_state=None, masked=None):
         """G[x] += backward of (pool?, activation, BatchNorm) applied to da = T.  masked = (rows, cpad): T already holds
@@ -288,14 +351,17 @@ class PlanBackward:
         for i in range(len(self.recs) - 1, -1, -1):
             r = self.recs[i]
             if r["kind"] == "copy":
+                self.flush(r["dst"])
                 E.grad_ew(E.GRAD_ADD, self.G(r["dst"]), self.G(r["src"]))
                 continue
             if r["kind"] == "maxpool":
+                self.flush(r["dst"])
                 E.maxpool2_bwd(r["src"], self.G(r["dst"]), self.G(r["src"]))
                 continue
             if i in self.recompute:
                 self.recs[self.recompute[i]]["rerun"]()
             y = r["y"]
+            self.flush(y)
             gy = self.G(y)
             dyv = gy
             if r["upsample"]:
@@ -312,3 +378,4 @@ class PlanBackward:
                 self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer writes a fresh gradient here
             if PROGRESS_HOOK is not None:
                 PROGRESS_HOOK(self, i)
+        self.flush_all()      # plan inputs: their gradients are read by the caller

@@ -305,15 +305,27 @@ def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta,
             "bn_bwd_finalize_raw")
 
 
-def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None):
+def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None, accumulate=False):
     """dpre <- conv^T(dy, W) * act'(bn(fwd_x)) (stride-1 convs); with a norm in fwd_pro fills `ws` and returns
-    (rows, cpad) for bn_bwd_finalize_raw."""
+    (rows, cpad) for bn_bwd_finalize_raw.  accumulate: dpre_fd is the gradient buffer of fwd_x, += gamma * rstd * dpre."""
     rows, cpad = C.c_int64(0), C.c_int64(0)
     L.check(L.load().fdgan_conv2d_bwd_data(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
                                            C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd),
-                                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                           int(bool(accumulate)), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
                                            C.byref(rows), C.byref(cpad), C.byref(desc), stream_ptr()), "conv2d_bwd_data")
     return rows.value, cpad.value
+
+
+def bn_bwd_coef(dgamma, dbeta, pro, channels, count, bsum, csum):
+    """bsum / csum (fp32 views) += this layer's (B, C) of dx = A*dpre + B*x + C."""
+    L.check(L.load().fdgan_bn_bwd_coef(dgamma.data_ptr(), dbeta.data_ptr(), C.byref(pro), channels, count, bsum.data_ptr(),
+                                       csum.data_ptr(), stream_ptr()), "bn_bwd_coef")
+
+
+def affine_accumulate(x_fd, bsum, csum, dx_fd):
+    """dx += bsum * x + csum per channel."""
+    L.check(L.load().fdgan_affine_accumulate(C.byref(x_fd), bsum.data_ptr(), csum.data_ptr(), C.byref(dx_fd), stream_ptr()),
+            "affine_accumulate")
 
 
 def bn_bwd_apply(dpre_fd, x_fd, pro, dgamma, dbeta, dx_fd, accumulate=False):

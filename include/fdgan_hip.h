@@ -256,10 +256,20 @@ int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, 
  * where fwd_x is the forward conv's raw input and fwd_pro its prologue (BatchNorm batch statistics + activation, no
  * pooling; NULL: identity).  With a norm, `partial` receives rows x cpad x {sum dpre, sum dpre * fwd_x} per channel
  * (rows / cpad returned) for fdgan_bn_bwd_finalize_raw; fdgan_bn_bwd_apply completes dx.  Replaces
- * fdgan_conv2d_fwd + fdgan_bn_act_bwd: one pass less over the gradient tensor. */
+ * fdgan_conv2d_fwd + fdgan_bn_act_bwd: one pass less over the gradient tensor.
+ * accumulate = 1: `dpre` is the GRADIENT BUFFER of fwd_x instead and receives dx += gamma * rstd * dpre (dx += dpre
+ * without a norm); dpre itself is never stored.  The rest of BatchNorm's backward, B * x + C per channel, is linear in x:
+ * fdgan_bn_bwd_coef adds a layer's (B, C) into a coefficient pair shared by every layer that normalises those channels
+ * (the layers of a dense block) and one fdgan_affine_accumulate pass, dx += Bsum * x + Csum, serves them all. */
 int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
-                          const FdTensor* dpre, float* partial, int64_t capacity_floats, int64_t* rows_out,
+                          const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                           int64_t* cpad_out, const FdConvDesc* d, FdStream stream);
+/* bsum[c] += B, csum[c] += C of dx = A*dpre + B*x + C for channels [0, channels): B = -gamma*rstd^2*dgamma/count,
+ * C = -gamma*rstd*dbeta/count - B*mean (pro: the forward prologue's mean / var / gamma / eps). */
+int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,
+                      float* bsum, float* csum, FdStream stream);
+/* dx += bsum[c] * x + csum[c] (NHWC bf16 views of equal shape). */
+int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
 int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
