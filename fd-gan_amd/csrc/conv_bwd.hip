@@ -1,17 +1,23 @@
-// conv_bwd.hip -- backward pieces of the fused convolution (first, correctness-first version):
+// conv_bwd.hip -- backward pieces of the fused convolution:
 //
 //   forward (conv_igemm.h):   a = act_p(bn(x));  y = conv(a, W) (+ bias);  stored tensor = y
 //
-//   * data gradient   da = conv^T(dy, W) is a FORWARD convolution of dy with the flipped, transposed
-//                     filter (fdgan_pack_conv_weight(..., flip = 1), pad' = k - 1 - pad): no kernel here.
+//   * data gradient   da = conv^T(dy, W) is a FORWARD convolution of dy with the flipped, transposed filter
+//                     (fdgan_pack_conv_weight(..., flip = 1), pad' = k - 1 - pad).  fdgan_conv2d_bwd_data
+//                     (conv_igemm.hip, the MK = 1 instantiations of the forward kernel) runs it with the first pass
+//                     of the prologue's backward in its epilogue: dpre = da * act'(bn(x)), BatchNorm's two sums,
+//                     and optionally dx += gamma * rstd * dpre -- no kernel for it here.
 //   * weight gradient dW[co][ci][tap] = sum_px dy[px][co] * a[px + tap][ci]      fdgan_conv2d_bwd_weight
 //                     with `a` recomputed from the raw input and the forward prologue (BatchNorm batch
-//                     statistics + activation), exactly as the forward staged it (bf16, zero padding).
-//   * prologue        dpre = da * act'(bn(x)) and the two BatchNorm reductions (sum dpre, sum dpre*xhat):
-//                     fdgan_bn_act_bwd;  dx = scale * (dpre - dbeta/M - xhat * dgamma/M): fdgan_bn_bwd_apply.
-//   * fdgan_conv2d_bwd_data_direct: any-stride data gradient into an NCHW fp32 tensor, one thread per
-//                     element -- for the gradient w.r.t. a network INPUT (3 / 9 channels), where a GEMM
-//                     formulation would waste the matrix pipe anyway.
+//                     statistics + activation), exactly as the forward staged it (bf16, zero padding).  This file:
+//                     the per-tap kernel (1x1 convs, odd shapes) and the split reductions; stride-1 3x3 / 4x4 convs
+//                     go to the transpose-read kernels in conv_wgrad_tr.hip.
+//   * prologue        the unfused passes, still used behind pooled prologues and strided convs: fdgan_bn_act_bwd
+//                     (dpre = da * act'(bn(x)) in place + sums), fdgan_bn_bwd_finalize*, fdgan_bn_bwd_apply
+//                     (dx = A * dpre + B * x + C); and the deferred form of the latter's linear part:
+//                     fdgan_bn_bwd_coef / fdgan_affine_accumulate.
+//   * fdgan_conv2d_bwd_data_direct: any-stride data gradient into an NCHW fp32 tensor (network inputs with 3 / 9 / 16
+//                     channels: a thread per pixel, filter in LDS) or an NHWC bf16 view (strided convs in a plan).
 // Reference: autograd of nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU / nn.Sigmoid as composed in
 // /root/reference/models/dehaze1113.py:188-230 (D) and :703-801 (FDGAN).
 #include <stdlib.h>

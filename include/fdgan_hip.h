@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 1
+#define FDGAN_ABI_VERSION 2
 
 enum FdStatus {
   FD_OK = 0,
