@@ -814,6 +814,11 @@ struct WgradRowsArgs {
   float* bias_part;              // [items][cout tiles][32] per-item sums of dy (bias gradient) or NULL
   int dbg_skip;                  // FDGAN_DEBUG_PHASES (results wrong): 1 no partial stores, 2 no MFMA loop, 4 no staging in the row loop
 };
+// streaming 1x1 data gradient + prologue backward (conv1x1_bwd.hip)
+bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre);
+int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
+                       int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
+                       hipStream_t stream);
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
                          float* dbias, int accumulate, hipStream_t stream);

@@ -199,6 +199,18 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
     FD_REQUIRE(t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0 &&
                    (t->stride[2] >= c8 || t->w == 1),
                "conv2d_bwd_data: fwd_x / dpre need 16-byte aligned pixel rows with the channels padded to a multiple of 8");
+  const int act0 = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
+  FD_REQUIRE(act0 == FD_ACT_NONE || act0 == FD_ACT_RELU || act0 == FD_ACT_LEAKY02, "conv2d_bwd_data: prologue activation %d", act0);
+  if (d->ksize == 1 && d->pad == 0 && dy->dtype == FD_BF16 && dy->n == dpre->n && dy->h == dpre->h && dy->w == dpre->w &&
+      (d->cout <= 0 || d->cout == dpre->c) && conv1x1_bwd_fits(dy, fwd_x, dpre)) {
+    FD_REQUIRE(!(fwd_pro && fwd_pro->mean) || (fwd_pro->var && partial), "conv2d_bwd_data: a BatchNorm prologue needs var and the partial-sum workspace");
+    long long rows = 0, cpad = 0;
+    const int rc = conv1x1_bwd_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, partial, capacity_floats, &rows, &cpad,
+                                      static_cast<hipStream_t>(stream));
+    if (rows_out) *rows_out = rows;
+    if (cpad_out) *cpad_out = cpad;
+    return rc;
+  }
   ConvArgs a;
   long long nimg;
   bool pool;

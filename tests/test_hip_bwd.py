@@ -160,12 +160,17 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
         assert rel_rms(dx.cpu().double(), xr.grad) < 1e-5, (cin, cout, k, s)
 
 
-@pytest.mark.parametrize("k,pad,cin,cout,act", [(1, 0, 96, 128, "relu"), (3, 1, 128, 32, "relu"), (4, 1, 72, 144, "leaky"), (3, 1, 16, 40, "relu")])
-def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act):
+@pytest.mark.parametrize("k,pad,cin,cout,act,dims", [
+    (1, 0, 96, 128, "relu", (2, 13, 19)), (3, 1, 128, 32, "relu", (2, 13, 19)), (4, 1, 72, 144, "leaky", (2, 13, 19)),
+    (3, 1, 16, 40, "relu", (2, 13, 19)),
+    # N*H*W a multiple of 64 and at most 128 forward filters: the streaming 1x1 kernel (conv1x1_bwd.hip)
+    (1, 0, 96, 128, "relu", (2, 16, 24)), (1, 0, 224, 128, "relu", (1, 8, 64)), (1, 0, 40, 64, "leaky", (2, 8, 8)),
+    (1, 0, 992, 128, "relu", (1, 8, 8))])
+def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     """fdgan_conv2d_bwd_data: conv^T(dy, W) * act'(bn(x)) stored by the data-gradient kernel itself, with the raw
     moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
     from fdgan_hip import lib as L
-    n, h, w = 2, 13, 19
+    n, h, w = dims
     x = bf16_round(seeded((n, cin, h, w), 71, -1.5, 1.5))
     ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
     dy = bf16_round(seeded((n, cout, ho, wo), 72, -1.0, 1.0))
@@ -200,6 +205,20 @@ def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act):
     assert rel_rms(db.cpu().double(), dpre_dev.sum(dim=(0, 2, 3))) < 5e-3
     assert rel_rms(dg.cpu().double(), (dpre_dev * xhat).sum(dim=(0, 2, 3))) < 2e-2
     assert torch.allclose(sink_g.cpu() - 1.0, dg.cpu(), atol=1e-4, rtol=1e-4) and torch.allclose(sink_b.cpu() + 1.0, db.cpu(), atol=1e-4, rtol=1e-4)
+    # accumulate mode: the gradient buffer of x receives gamma * rstd * dpre on top of what it holds, dpre is not stored
+    g0 = bf16_round(seeded((n, cin, h, w), 75, -0.5, 0.5))
+    G = _nhwc(g0, pitch=cin + 8)
+    ws.zero_()
+    rows2, cpad2 = E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro, E.View(G, 0, cin).fd,
+                                   E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32), ws, accumulate=True)
+    dg2, db2 = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    E.bn_bwd_finalize_raw(ws, rows2, cpad2, cin, keep[0], keep[1], 1e-5, dg2, db2)
+    torch.cuda.synchronize()
+    A = (p["gamma"].double() * rstd).view(1, -1, 1, 1)
+    want = g0.double() + A * dpre_ref
+    gotG = _from_nhwc(G, cin).double()
+    assert rel_rms(gotG[safe], want[safe]) < 8e-3
+    assert rel_rms(db2.cpu().double(), db.cpu().double()) < 2e-3 and rel_rms(dg2.cpu().double(), dg.cpu().double()) < 2e-2
     # activation only (no norm): mask by the sign of x, no workspace
     pro1 = E.make_prologue(act=L.ACT_RELU)
     E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro1, E.View(T, 0, cin).fd,
