@@ -5,8 +5,10 @@ the batch dimension is split, every replica holds the same weights and BatchNorm
 statistics of ITS shard.  Here that is one process per GPU (torchrun / `torch.distributed`,
 backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests), each rank owning a
 contiguous slice of the global batch (or every world-th dataset index for demo.py).  The forward
-path exchanges nothing; the only collectives are the timing ones (barrier, MAX of elapsed time).
-The gradient all-reduce of the training step belongs to the backward path and is not built yet.
+path exchanges nothing; its only collectives are the timing ones (barrier, MAX of elapsed time).
+The training step's one exchange is the gradient all-reduce: optim.FlatAdam reduces slices of its flat
+gradient buffer, for the generator overlapped with the backward walk (FlatAdam.overlap); GradBuckets below
+is the generic variant for optimizers without a flat buffer.
 """
 import os
 

@@ -49,13 +49,13 @@ class FlatAdam:
         # planned modules watch to re-pack their MFMA filter images (netplan.refresh_weights)
         torch.autograd.graph.increment_version(self.params)
 
-    def overlap(self, ctx, bucket_mb=8.0, reduce_fn=None):
+    def overlap(self, ctx, bucket_mb=8.0, reduce_fn=None, force=False):
         """Context manager around a backward(): all-reduce slices of the flat gradient AS SOON AS every layer that
         contributes to them has run its backward, while the rest of the backward keeps computing (RCCL on its own stream;
         xGMI rings are per-link bound, so slices are >= bucket_mb to stay bandwidth- rather than latency-priced).
         Leaving the context reduces whatever is left, waits, and divides by the world size.  reduce_fn(lo, hi): test
-        hook replacing the collective."""
-        return _Overlap(self, ctx, bucket_mb, reduce_fn)
+        hook replacing the collective; force: also on a one-rank process group."""
+        return _Overlap(self, ctx, bucket_mb, reduce_fn, force)
 
     def allreduce_grads(self, ctx, bucket_mb=8.0):
         """Data-parallel gradient averaging on the flat buffer: RCCL all-reduce of contiguous slices, last slice
@@ -75,9 +75,10 @@ class FlatAdam:
 
 
 class _Overlap:
-    def __init__(self, opt, ctx, bucket_mb, reduce_fn):
+    def __init__(self, opt, ctx, bucket_mb, reduce_fn, force=False):
         self.opt, self.ctx, self.reduce_fn = opt, ctx, reduce_fn
-        self.active = reduce_fn is not None or (ctx is not None and ctx.world > 1)
+        # force: run the collectives even on a one-rank group (exercises the RCCL path on a single-GPU box)
+        self.active = reduce_fn is not None or (ctx is not None and (ctx.world > 1 or force))
         self.bucket = max(1, int(bucket_mb * (1 << 20) / 4))
         self.index = {id(p): k for k, p in enumerate(opt.params)}
         self.tables = {}                    # id(PlanBackward) -> per-record parameter indices

@@ -756,6 +756,46 @@ def test_overlapped_allreduce_slices_are_final_when_sent():
     assert float(opt.grad.abs().sum()) > 0
 
 
+def test_overlapped_allreduce_on_rccl_one_rank_group():
+    """The same walk with the REAL collective: a one-rank nccl (= RCCL) process group on this GPU, async all_reduce of
+    flat-gradient slices issued from inside the backward.  Sum over one rank / 1 must leave exactly the gradients of a
+    plain backward."""
+    import socket
+    import torch.distributed as dist
+    import models.dehaze1113 as net
+    from fdgan_hip.dp import DpContext
+    from fdgan_hip.optim import FlatAdam
+    import train
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        ctx = DpContext(0, 1, 0, torch.device(DEV))
+        torch.manual_seed(12)
+        g = net.FDGAN().to(DEV)
+        opt = FlatAdam(train.TrainStep._params_with_grad(g, torch.device(DEV)))
+        x = torch.rand(2, 3, 64, 64, device=DEV)
+        tgt = torch.rand(2, 3, 64, 64, device=DEV) * 2 - 1
+        opt.zero_grad()
+        ((g(x) - tgt) ** 2).mean().backward()
+        torch.cuda.synchronize()
+        plain = opt.grad.clone()
+        opt.zero_grad()
+        y = g(x)
+        ov = opt.overlap(ctx, bucket_mb=4.0, force=True)
+        with ov:
+            ((y - tgt) ** 2).mean().backward()
+        torch.cuda.synchronize()
+        assert len(ov.works) >= 4 and ov.sent_early >= 3
+        assert torch.equal(opt.grad, plain)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_flat_gradient_sink_equals_autograd_accumulation():
     """With FlatAdam the backward walk adds weight / bias / BatchNorm gradients straight into the flat gradient views
     (no autograd accumulation): two backward passes (the real and the fake half of a discriminator step) must leave
