@@ -45,7 +45,7 @@ struct Bwd1Args {
   int C, nct;                 // channels, channel tiles
   long long P;
   int ntiles;                 // P / 64
-  int mode, acc;              // 1 activation only, 2 BatchNorm + activation; acc: G += gamma*rstd*v
+  int mode, acc;              // 1 activation only, 2 BatchNorm + activation; acc 1: G += gamma*rstd*v, 2: G = gamma*rstd*v, 0: G = v
   float slope, eps;
   const float *mean, *var, *gamma, *beta;
   float* partial;             // [gridDim.x][nct * 128][2] or NULL
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
       xv[i] = gv[i] = zero4;
       if (it < n_it && cg < a.C && !(a.dbg & 8)) {
         xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg);
-        if (a.acc) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg);
+        if (a.acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg);
       }
     }
   };
@@ -273,7 +273,7 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   a.P = dpre->n * dpre->h * dpre->w, a.ntiles = (int)(a.P / B1_PX);
   const bool norm = pro && pro->mean;
   const int act = pro ? pro->act : FD_ACT_NONE;
-  a.mode = norm ? 2 : 1, a.acc = accumulate ? 1 : 0;
+  a.mode = norm ? 2 : 1, a.acc = accumulate;
   a.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
   long long grid = a.ntiles < 512 ? a.ntiles : 512;            // two resident workgroups per CU

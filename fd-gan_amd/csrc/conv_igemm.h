@@ -64,7 +64,7 @@ struct ConvArgs {
   int mk_sh, mk_sw;
   float mk_slope, mk_eps;
   const float *mk_mean, *mk_var, *mk_gamma, *mk_beta;
-  int mk_acc;                   // 1: y is the gradient buffer of x, updated as y += gamma * rstd * dpre (dpre itself is not stored)
+  int mk_acc;                   // y is the gradient buffer of x: 1: y += gamma * rstd * dpre, 2: y = gamma * rstd * dpre (sole consumer); 0: y = dpre
   // in-kernel finalize by the last workgroup (kernels that set FdConvInfo.fused_finalize)
   float *fin_mean, *fin_var;
   unsigned* fin_counter;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
         xv[i] = gv[i] = u32x4{0u, 0u, 0u, 0u};
         if (ok) {
           xv[i] = *reinterpret_cast<const u32x4*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)(ox0 + q) * a.mk_sw + cg);
-          if (a.mk_acc) gv[i] = *reinterpret_cast<const u32x4*>(ybase + offs[i]);
+          if (a.mk_acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(ybase + offs[i]);
         }
       }
 #pragma unroll
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
           const float v = (cg + e < a.Cout) ? da[e] * (pre > 0.f ? 1.f : a.mk_slope) : 0.f;
           s1[e] += v;
           s2[e] += v * fx[e];
-          o[e] = a.mk_acc ? fmaf(sc8[e], v, o[e]) : v;
+          o[e] = a.mk_acc ? fmaf(sc8[e], v, o[e]) : v;   // o = 0 unless accumulating
         }
         *reinterpret_cast<u32x4*>(ybase + offs[i]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
       }

@@ -187,6 +187,7 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
                                      int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, const FdConvDesc* d,
                                      FdStream stream) {
   FD_REQUIRE(w_packed_flipped && d && dpre && fwd_x, "conv2d_bwd_data: NULL argument");
+  FD_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv2d_bwd_data: accumulate %d", accumulate);
   FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv2d_bwd_data: packed weights must be 16-byte aligned");
   FD_REQUIRE(d->stride == 1 && !d->upsample2 && d->epilogue_act == FD_ACT_NONE && d->w_layout == FD_WLAYOUT_CHUNK32,
              "conv2d_bwd_data: stride-1 conv with the chunk32 filter image, no epilogue");
@@ -225,7 +226,7 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
   const int act = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
   FD_REQUIRE(act == FD_ACT_NONE || act == FD_ACT_RELU || act == FD_ACT_LEAKY02, "conv2d_bwd_data: prologue activation %d", act);
   a.mk_mode = norm ? 2 : 1;
-  a.mk_acc = accumulate ? 1 : 0;
+  a.mk_acc = accumulate;
   a.mk_slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   a.mk_x = static_cast<const unsigned short*>(fwd_x->ptr);
   a.mk_sn = fwd_x->stride[0], a.mk_sh = (int)fwd_x->stride[1], a.mk_sw = (int)fwd_x->stride[2];

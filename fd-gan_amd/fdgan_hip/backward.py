@@ -156,6 +156,33 @@ class PlanBackward:
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
+        # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
+        # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
+        # stores need no zeroing, neither at the start of a walk nor between the versions they hold.
+        self.nozero = set()
+        if self.fuse_mask and self.defer_affine and os.environ.get("FDGAN_NO_DX_STORE") is None:
+            def reads(rk):
+                return _region(rk["x"]) if rk["kind"] == "conv" else _region(rk["src"])
+
+            def writes(rk):
+                out = rk.get("y") if rk["kind"] == "conv" else rk.get("dst")
+                return _region(out) if out is not None else None
+            per_gbuf = {}
+            for i, r in enumerate(self.recs):
+                sole = False
+                if r["kind"] == "conv":
+                    rx = _region(r["x"])
+                    prod = next((j for j in range(i - 1, -1, -1) if writes(self.recs[j]) is not None and _overlap(writes(self.recs[j]), rx)), None)
+                    nxt = next((k for k in range(i + 1, len(self.recs)) if writes(self.recs[k]) is not None and _overlap(writes(self.recs[k]), rx)),
+                               len(self.recs))
+                    meta = r["pro"]._meta if r.get("pro") is not None else dict(pool=False)
+                    sole = (prod is not None and r["stride"] == 1 and not meta["pool"] and r["x"].c0 % 8 == 0 and
+                            not any(t != i and _overlap(reads(self.recs[t]), rx) for t in range(prod + 1, nxt)))
+                    per_gbuf.setdefault(id(self.gbuf[rx[0]]), []).append(sole)
+                else:
+                    per_gbuf.setdefault(id(self.gbuf[reads(r)[0]]), []).append(False)
+                r["_sole"] = sole
+            self.nozero = {g for g, flags in per_gbuf.items() if all(flags)}
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
 
     def record_params(self, i):
@@ -175,8 +202,10 @@ class PlanBackward:
         return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
 
     def zero_(self):
+        skip = self.nozero if self.checks is None else ()
         for g in {id(g): g for g in self.gbuf.values()}.values():      # aliased gradient buffers once
-            g.zero_()
+            if id(g) not in skip:
+                g.zero_()
         for d in self.deferred.values():                                # nothing pending from an interrupted walk
             if d["dirty"]:
                 d["coef"].zero_()
@@ -244,8 +273,9 @@ class PlanBackward:
             # coefficient pair until the gradient of those channels is read (flush) -- shared by every layer that normalises
             # them (dense blocks).  dpre is never stored.
             gx = self.G(x)
+            store = r.get("_sole", False) and self.checks is None and id(self.gbuf[x.buf.data_ptr()]) in self.nozero
             rows, cpad = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
-                                         accumulate=True)
+                                         accumulate=2 if store else 1)
             if bn is not None:
                 dg = torch.empty(cin, dtype=torch.float32, device=p.device)
                 dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
@@ -374,8 +404,8 @@ class PlanBackward:
             elif r["e_act"] != L.ACT_NONE:
                 raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
             self.conv_backward(r, dyv, grads, need_dx=(id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of))
-            if y.buf.data_ptr() in self.multi_version:
-                self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer writes a fresh gradient here
+            if y.buf.data_ptr() in self.multi_version and (self.checks is not None or id(self.gbuf[y.buf.data_ptr()]) not in self.nozero):
+                self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer accumulates a fresh gradient here
             if PROGRESS_HOOK is not None:
                 PROGRESS_HOOK(self, i)
         self.flush_all()      # plan inputs: their gradients are read by the caller

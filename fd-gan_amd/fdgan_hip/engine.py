@@ -307,11 +307,12 @@ def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta,
 
 def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None, accumulate=False):
     """dpre <- conv^T(dy, W) * act'(bn(fwd_x)) (stride-1 convs); with a norm in fwd_pro fills `ws` and returns
-    (rows, cpad) for bn_bwd_finalize_raw.  accumulate: dpre_fd is the gradient buffer of fwd_x, += gamma * rstd * dpre."""
+    (rows, cpad) for bn_bwd_finalize_raw.  accumulate: dpre_fd is the gradient buffer of fwd_x; 1 / True: += gamma * rstd *
+    dpre, 2: = gamma * rstd * dpre (sole consumer)."""
     rows, cpad = C.c_int64(0), C.c_int64(0)
     L.check(L.load().fdgan_conv2d_bwd_data(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
                                            C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd),
-                                           int(bool(accumulate)), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                           int(accumulate), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
                                            C.byref(rows), C.byref(cpad), C.byref(desc), stream_ptr()), "conv2d_bwd_data")
     return rows.value, cpad.value
 

@@ -258,7 +258,8 @@ int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, 
  * (rows / cpad returned) for fdgan_bn_bwd_finalize_raw; fdgan_bn_bwd_apply completes dx.  Replaces
  * fdgan_conv2d_fwd + fdgan_bn_act_bwd: one pass less over the gradient tensor.
  * accumulate = 1: `dpre` is the GRADIENT BUFFER of fwd_x instead and receives dx += gamma * rstd * dpre (dx += dpre
- * without a norm); dpre itself is never stored.  The rest of BatchNorm's backward, B * x + C per channel, is linear in x:
+ * without a norm); dpre itself is never stored.  accumulate = 2: the same value is STORED (dx = ...): for an input with
+ * this conv as its only consumer, whose gradient buffer then needs neither zeroing nor reading.  The rest of BatchNorm's backward, B * x + C per channel, is linear in x:
  * fdgan_bn_bwd_coef adds a layer's (B, C) into a coefficient pair shared by every layer that normalises those channels
  * (the layers of a dense block) and one fdgan_affine_accumulate pass, dx += Bsum * x + Csum, serves them all. */
 int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
