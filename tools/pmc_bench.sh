@@ -23,6 +23,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
 # BatchNorm-backward pass on the training step (both run in the default bench.py)
 names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
          "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256"),
+         "conv1x1_bwd_kernel": ("conv1x1_bwd_stream", "train_B16_256"),
          "conv_igemm_kernel<1, 1, 0, 4, 8, 4, 1, 1, 1>": ("conv1x1_bn128_bwd", "train_B16_256"),
          "conv_igemm_kernel<3, 1, 0, 4, 8, 4, 1, 1, 1>": ("conv3x3_bn128_bwd", "train_B16_256")}
 res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (training step + netG forward leg, B=16 @256^2); KiB; "
