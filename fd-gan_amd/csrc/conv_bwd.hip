@@ -554,18 +554,35 @@ struct SumFinArgs {
   // raw moments: the second sum is sum(dpre * x), turned into sum(dpre * xhat) = rstd * (S2 - mean * S1) here
   const float *raw_mean, *raw_var;
   float raw_eps;
+  // two-level reduction of many partial rows (a few thousand pixel tiles x 4 workgroups would take 60 us): with
+  // `level1` set, workgroup (x, y) sums the y-th of gridDim.y row slices and writes ONE row of fp32 sums to level1
+  float* level1;
 };
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
   __shared__ double sh[2][32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const long long c = (long long)blockIdx.x * 32 + cl;
+  const long long per = (a.rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per, r1 = r0 + per < a.rows ? r0 + per : a.rows;
   double t1 = 0.0, t2 = 0.0;
-  if (c < a.channels)
-    for (long long r = rg; r < a.rows; r += 32) {
+  if (c < a.channels) {
+    long long r = r0 + rg;
+    for (; r + 96 < r1; r += 128) {   // four rows in flight
+      const float2 v0 = *reinterpret_cast<const float2*>(a.partial + (r * a.cpad + c) * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(a.partial + ((r + 32) * a.cpad + c) * 2);
+      const float2 v2 = *reinterpret_cast<const float2*>(a.partial + ((r + 64) * a.cpad + c) * 2);
+      const float2 v3 = *reinterpret_cast<const float2*>(a.partial + ((r + 96) * a.cpad + c) * 2);
+      t1 += (double)v0.x, t2 += (double)v0.y;
+      t1 += (double)v1.x, t2 += (double)v1.y;
+      t1 += (double)v2.x, t2 += (double)v2.y;
+      t1 += (double)v3.x, t2 += (double)v3.y;
+    }
+    for (; r < r1; r += 32) {
       const float2 v = *reinterpret_cast<const float2*>(a.partial + (r * a.cpad + c) * 2);
       t1 += v.x;
       t2 += v.y;
     }
+  }
   sh[0][rg][cl] = t1;
   sh[1][rg][cl] = t2;
   __syncthreads();
@@ -574,6 +591,11 @@ __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
     for (int g = 0; g < 32; ++g) {
       t1 += sh[0][g][cl];
       t2 += sh[1][g][cl];
+    }
+    if (a.level1 != nullptr) {
+      a.level1[((long long)blockIdx.y * a.cpad + c) * 2] = (float)t1;
+      a.level1[((long long)blockIdx.y * a.cpad + c) * 2 + 1] = (float)t2;
+      return;
     }
     if (a.raw_mean != nullptr) t2 = (t2 - (double)a.raw_mean[c] * t1) / sqrt((double)a.raw_var[c] + (double)a.raw_eps);
     if (a.accumulate) {
@@ -1018,21 +1040,33 @@ extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t
   return fdgan_bn_bwd_finalize_sink(partial, rows, cpad, channels, dgamma, dbeta, accumulate, nullptr, nullptr, stream);
 }
 
+static int launch_sum_finalize(SumFinArgs a, float* scratch, int64_t scratch_floats, FdStream stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 cgrid((unsigned)((a.channels + 31) / 32));
+  constexpr int SLICES = 32;
+  if (scratch != nullptr && a.rows > 256 && (int64_t)SLICES * a.cpad * 2 <= scratch_floats) {
+    SumFinArgs l1 = a;
+    l1.level1 = scratch;
+    if (int rc = fd_launch(&sum_finalize_kernel, "bn_bwd_finalize_l1", dim3(cgrid.x, SLICES), dim3(1024), 0, l1, st)) return rc;
+    a.partial = scratch, a.rows = SLICES;
+  }
+  a.level1 = nullptr;
+  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", cgrid, dim3(1024), 0, a, st);
+}
+
 extern "C" int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                           float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma, nullptr, nullptr, 0.f};
-  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
-                   static_cast<hipStream_t>(stream));
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma, nullptr, nullptr, 0.f, nullptr};
+  return launch_sum_finalize(a, nullptr, 0, stream);
 }
 
 extern "C" int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const float* mean,
                                          const float* var, float eps, float* dgamma, float* dbeta, float* sink_dgamma,
-                                         float* sink_dbeta, FdStream stream) {
+                                         float* sink_dbeta, float* scratch, int64_t scratch_floats, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && mean && var && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize_raw: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, 0, sink_dbeta, sink_dgamma, mean, var, eps};
-  return fd_launch(&sum_finalize_kernel, "bn_bwd_finalize", dim3((unsigned)((channels + 31) / 32)), dim3(1024), 0, a,
-                   static_cast<hipStream_t>(stream));
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, 0, sink_dbeta, sink_dgamma, mean, var, eps, nullptr};
+  return launch_sum_finalize(a, scratch, scratch_floats, stream);
 }
 
 // ---- deferred affine part of BatchNorm's backward ---------------------------------------------------------------

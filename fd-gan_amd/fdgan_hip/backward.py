@@ -153,6 +153,7 @@ class PlanBackward:
         dev = plan.device
         self.ws = torch.empty(1 << 25, dtype=torch.float32, device=dev)      # split-K partials (128 MiB)
         self.ws_bn = torch.empty(1 << 24, dtype=torch.float32, device=dev)   # BatchNorm-backward partial sums (64 MiB)
+        self.ws_fin = torch.empty(64 * 4096, dtype=torch.float32, device=dev)  # second level of the BatchNorm-sum reduction
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
@@ -282,7 +283,7 @@ class PlanBackward:
                 train_bn = bn.weight is not None and bn.weight.requires_grad
                 E.bn_bwd_finalize_raw(self.ws_bn, rows, cpad, cin, meta["mean"], meta["var"], meta["eps"], dg, dbt,
                                       sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
-                                      sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+                                      sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
                 d = self._deferred(x)
                 E.bn_bwd_coef(dg, dbt, act_pro, cin, n * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
                 d["dirty"].update(range(x.c0, x.c0 + cin))
@@ -359,7 +360,8 @@ class PlanBackward:
             sinks = dict(sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                          sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
             if masked is not None:
-                E.bn_bwd_finalize_raw(self.ws_bn, masked[0], masked[1], cin, meta["mean"], meta["var"], meta["eps"], dg, dbt, **sinks)
+                E.bn_bwd_finalize_raw(self.ws_bn, masked[0], masked[1], cin, meta["mean"], meta["var"], meta["eps"], dg, dbt,
+                                      scratch=self.ws_fin, **sinks)
             else:
                 rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
                 E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, **sinks)

@@ -296,12 +296,15 @@ def bn_bwd_finalize(ws, rows, cpad, channels, dgamma, dbeta, accumulate=False, s
             "bn_bwd_finalize")
 
 
-def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta, sink_dgamma=None, sink_dbeta=None):
-    """(dgamma, dbeta) from the (sum dpre, sum dpre * x) partials of conv_bwd_data."""
+def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta, sink_dgamma=None, sink_dbeta=None, scratch=None):
+    """(dgamma, dbeta) from the (sum dpre, sum dpre * x) partials of conv_bwd_data.  scratch: fp32 tensor of at least
+    64 * cpad elements enabling the two-level reduction of many rows."""
     L.check(L.load().fdgan_bn_bwd_finalize_raw(ws.data_ptr(), rows, cpad, channels, mean.data_ptr(), var.data_ptr(), eps,
                                                dgamma.data_ptr(), dbeta.data_ptr(),
                                                sink_dgamma.data_ptr() if sink_dgamma is not None else None,
-                                               sink_dbeta.data_ptr() if sink_dbeta is not None else None, stream_ptr()),
+                                               sink_dbeta.data_ptr() if sink_dbeta is not None else None,
+                                               scratch.data_ptr() if scratch is not None else None,
+                                               scratch.numel() if scratch is not None else 0, stream_ptr()),
             "bn_bwd_finalize_raw")
 
 

@@ -245,10 +245,11 @@ int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int6
 int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream);
 /* (dgamma, dbeta) from RAW moments: partial rows of (sum dpre, sum dpre * x) as fdgan_conv2d_bwd_data writes them;
- * dgamma = (S2 - mean * S1) / sqrt(var + eps), dbeta = S1.  sink_*: as above. */
+ * dgamma = (S2 - mean * S1) / sqrt(var + eps), dbeta = S1.  sink_*: as above.  scratch (optional, >= 64 * cpad floats):
+ * lets more than 256 rows be reduced in two levels (32 row slices in parallel, then one row per slice). */
 int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const float* mean,
                               const float* var, float eps, float* dgamma, float* dbeta, float* sink_dgamma,
-                              float* sink_dbeta, FdStream stream);
+                              float* sink_dbeta, float* scratch, int64_t scratch_floats, FdStream stream);
 /* Data gradient of a stride-1 conv (reference: autograd of nn.Conv2d as composed in models/dehaze1113.py:188-230,
  * :703-801) fused with the first backward pass of the conv's input-side prologue: runs the FORWARD kernel on dy with
  * the flipped filter (fdgan_pack_conv_weight(..., flip = 1), d->pad = k - 1 - pad) and stores

@@ -165,7 +165,7 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     (3, 1, 16, 40, "relu", (2, 13, 19)),
     # N*H*W a multiple of 64 and at most 128 forward filters: the streaming 1x1 kernel (conv1x1_bwd.hip)
     (1, 0, 96, 128, "relu", (2, 16, 24)), (1, 0, 224, 128, "relu", (1, 8, 64)), (1, 0, 40, 64, "leaky", (2, 8, 8)),
-    (1, 0, 992, 128, "relu", (1, 8, 8))])
+    (1, 0, 992, 128, "relu", (1, 8, 8)), (3, 1, 128, 32, "relu", (3, 80, 96))])
 def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     """fdgan_conv2d_bwd_data: conv^T(dy, W) * act'(bn(x)) stored by the data-gradient kernel itself, with the raw
     moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
@@ -212,7 +212,8 @@ def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     rows2, cpad2 = E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro, E.View(G, 0, cin).fd,
                                    E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32), ws, accumulate=True)
     dg2, db2 = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
-    E.bn_bwd_finalize_raw(ws, rows2, cpad2, cin, keep[0], keep[1], 1e-5, dg2, db2)
+    scratch = torch.zeros(64 * cpad2, dtype=torch.float32, device=DEV)    # two-level reduction when there are > 256 rows
+    E.bn_bwd_finalize_raw(ws, rows2, cpad2, cin, keep[0], keep[1], 1e-5, dg2, db2, scratch=scratch)
     torch.cuda.synchronize()
     A = (p["gamma"].double() * rstd).view(1, -1, 1, 1)
     want = g0.double() + A * dpre_ref
