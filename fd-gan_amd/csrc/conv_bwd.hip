@@ -961,6 +961,19 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
       return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 63) / 64)), dim3(256), 0, r3, st3);
     }
   }
+  // the dense-layer bottleneck (1x1, 128 filters): transpose-read kernel (conv_wgrad1x1_tr.hip)
+  if (workspace != nullptr && conv_wgrad1x1_tr_fits(x, dy, cout, d->ksize, d->stride, pool, dbias != nullptr)) {
+    long long ns = 0;
+    hipStream_t st1 = static_cast<hipStream_t>(stream);
+    const int rc1 = conv_wgrad1x1_tr_launch(x, dy, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta, workspace,
+                                            workspace_floats, &ns, st1);
+    if (rc1 < 0) return rc1;
+    if (rc1 == FD_OK) {
+      const long long numel1 = 128LL * a.Cin;
+      WredArgs r1{workspace, dw, numel1, (int)ns, accumulate};
+      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel1 + 63) / 64)), dim3(256), 0, r1, st1);
+    }
+  }
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
   // workgroup tile: 64 x 64 with 4 waves, or 128 x 128 with 8 waves (half the L2 -> LDS traffic per flop: the 64-tile
   // kernel runs at the ~5 TB/s its operand re-reads can be served at) when both channel counts fill it

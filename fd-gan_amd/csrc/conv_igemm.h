@@ -819,6 +819,11 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
 int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
                        int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
                        hipStream_t stream);
+// 1x1 weight gradient with transpose reads (conv_wgrad1x1_tr.hip)
+bool conv_wgrad1x1_tr_fits(const FdTensor* x, const FdTensor* dy, int cout, int ksize, int stride, bool pool, bool has_bias);
+int conv_wgrad1x1_tr_launch(const FdTensor* x, const FdTensor* dy, int pro_mode, float p_slope, float eps, const float* mean,
+                            const float* var, const float* gamma, const float* beta, float* workspace, long long workspace_floats,
+                            long long* nsplit_out, hipStream_t stream);
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
                          float* dbias, int accumulate, hipStream_t stream);

@@ -260,6 +260,34 @@ def test_weight_gradient_split_k_pool_and_accumulate(E):
         assert torch.equal(dw2, dw3)                                               # deterministic reduction
 
 
+@pytest.mark.parametrize("n,cin,h,w,pitch", [(2, 224, 16, 24, 256), (1, 992, 8, 8, 1024), (1, 72, 8, 16, 72), (3, 160, 16, 16, 160)])
+def test_weight_gradient_1x1_transpose_read_kernel(E, n, cin, h, w, pitch):
+    """conv_wgrad1x1_tr (the dense-layer bottleneck: 1x1, 128 filters, BatchNorm + ReLU prologue, N*H*W a multiple of 64):
+    Cin not a multiple of 128, channel slices of a wider buffer, several pixel splits; against torch on identical bf16
+    operands."""
+    from fdgan_hip import lib as L
+    cout = 128
+    x = bf16_round(seeded((n, cin, h, w), 81, -1.5, 1.5))
+    dy = bf16_round(seeded((n, cout, h, w), 82, -1.0, 1.0))
+    p = _bn_params(cin, 83)
+    keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
+    sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+    sh = (p["beta"] - p["mean"] * sc).float()
+    a = bf16_round(torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).double()
+    wref = torch.zeros(cout, cin, 1, 1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a, wref).backward(dy.double())
+    pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
+    xb, dyb = _nhwc(x, pitch=pitch), _nhwc(dy)
+    if pitch > cin:
+        xb[..., cin:] = float("nan")                       # neighbouring channels of the buffer must not leak in
+    ws = torch.zeros(1 << 22, dtype=torch.float32, device=DEV)
+    dw = torch.full((cout, cin, 1, 1), 0.25, dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(1, 1, 0, cout=cout), dw, None, ws, True)
+    torch.cuda.synchronize()
+    assert rel_rms(dw.cpu().double() - 0.25, wref.grad) < 5e-3
+    assert bool(torch.isfinite(dw).all())
+
+
 def test_gradient_plumbing_kernels(E):
     from fdgan_hip import lib as L
     n, c, h, w = 2, 40, 6, 10
