@@ -7,16 +7,17 @@
 // The generic implicit-GEMM kernel (conv_igemm.h, MK = 1) moves 2.7-2.9 TB/s on these shapes: a 128-pixel x 128-channel
 // tile per workgroup with four K steps is all prologue and epilogue, and every channel tile re-reads dy.  Here the
 // work is organised around the data that is big -- x and G, 3 C values per pixel against Cy of dy:
-//   * persistent workgroups (2 per CU, 4 waves) walk 64-pixel tiles of the flattened N*H*W axis; a tile's dy rows
-//     (64 x Cy) are staged once in LDS and serve every channel tile;
-//   * per 128-channel tile the filter fragments (32 KB, L2-resident) are staged through registers; the x and G rows
-//     of a (pixel tile, channel tile) pair are requested one whole pair AHEAD (two register sets used alternately), so
-//     HBM reads are in flight while the previous pair's epilogue computes and stores -- with the requests issued in the
-//     same iteration every phase serialised (570 us for a 256x256 layer; each phase alone ran at HBM speed);
+//   * a workgroup (4 waves, 2 per CU) owns ONE 128-channel tile for its whole life -- filter fragments (32 KB) staged
+//     once, the lane's 8 channels' coefficients and BatchNorm sums in registers -- and walks 64-pixel tiles of the
+//     flattened N*H*W axis; the channel tiles of the same pixels run back to back on one XCD, so dy (small next to x and
+//     G) comes out of that L2 for all but the first;
+//   * the dy, x and G rows of a pixel tile are requested one whole tile AHEAD (two register sets used alternately), so
+//     HBM reads are in flight while the previous tile's epilogue computes and stores.  (First version: pixel tile outer,
+//     channel tiles inner, requests in the same iteration: every phase serialised, 570 us for a 256x256 layer while each
+//     phase alone ran at HBM speed; restaging the filter per pair and the per-pair sums cost another 1.2 us of 7.8.)
 //   * the epilogue is the row phase of the MK kernels: the accumulator tile goes through a wave-private LDS
 //     transposition, every lane owns 8 channels of 4 pixels, whole 16-byte pieces of pixel rows in and out;
-//   * BatchNorm's two sums stay in LDS across the workgroup's tiles (fixed summation order) and leave as ONE partial
-//     row per workgroup.
+//   * BatchNorm's two sums leave as one partial row per (pixel slot, channel tile), summed in a fixed order.
 // Reference: autograd of conv1 / norm1 / relu1 of torchvision's _DenseLayer as used by
 // /root/reference/models/dehaze1113.py:713-724.
 #include <stdlib.h>
@@ -48,7 +49,7 @@ struct Bwd1Args {
   int mode, acc;              // 1 activation only, 2 BatchNorm + activation; acc 1: G += gamma*rstd*v, 2: G = gamma*rstd*v, 0: G = v
   float slope, eps;
   const float *mean, *var, *gamma, *beta;
-  float* partial;             // [gridDim.x][nct * 128][2] or NULL
+  float* partial;             // [pixel slots][nct * 128][2] or NULL
   int dbg;                    // FDGAN_DEBUG_PHASES (results wrong): 1 no filter loads, 2 no MFMAs, 4 no row phase, 8 no x / G loads, 16 no dy tile
 };
 
@@ -56,108 +57,86 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
   extern __shared__ __attribute__((aligned(16))) char b1_lds[];
   const int kch = a.Cy / 32;                                  // k chunks (<= 4)
   char* dyt = b1_lds;                                         // [64 px][Cy * 2 B], 16-byte columns XOR-swizzled by the pixel
-  char* wt = dyt + B1_PX * a.Cy * 2;                          // [kch][8 tiles][1 KB] A fragments of the channel tile
+  char* wt = dyt + B1_PX * a.Cy * 2;                          // [kch][8 tiles][1 KB] A fragments of THIS workgroup's channel tile
   char* tb0 = wt + kch * 8 * 1024;                            // 4 x transposition areas
-  float* red = reinterpret_cast<float*>(tb0 + 4 * B1_TB);     // [4 waves][128][2]
-  float* stats = red + 4 * 128 * 2;                           // [nct * 128][2] running sums of this workgroup
-  // scale / shift of every channel, computed once (up to 5 channel tiles: two workgroups still fit a CU), else of the
-  // current channel tile only
-  const bool sc_once = a.nct <= 5;
-  float* scall = stats + a.nct * 256;                         // [cpad] scale, [cpad] shift  |  [128] scale, [128] shift
+  float* red = reinterpret_cast<float*>(tb0);                 // [4 waves][128][2]: aliases the transposition areas, used once at the end
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, kgl = lane >> 4;
   char* tb = tb0 + wave * B1_TB;
-  const int cpad = a.nct * B1_CT;
-  for (int i = tid; i < a.nct * 256; i += 256) stats[i] = 0.f;
-  for (int c = tid; sc_once && c < cpad; c += 256) {
-    float sc = 1.f, sh = 0.f;
-    if (a.mode == 2 && c < a.C) {
-      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-      sc = gm / sqrtf(a.var[c] + a.eps);
-      sh = bt - a.mean[c] * sc;
-    }
-    scall[c] = sc;
-    scall[cpad + c] = sh;
+  // work item: (channel tile, pixel slot).  The channel tiles of one slot read the same dy pixels: XCD-aware numbering
+  // keeps them on one XCD, back to back, so that dy comes out of that L2 for all but the first.
+  int item = blockIdx.x;
+  {
+    const int per_xcd = gridDim.x >> 3;
+    if (item < per_xcd * 8) item = (item & 7) * per_xcd + (item >> 3);
   }
+  const int ct = item % a.nct, slot = item / a.nct, nslots = (int)gridDim.x / a.nct;
+  const int c0 = ct * B1_CT;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int dyrow = a.Cy * 2;                                 // bytes per staged dy pixel
   const int dcols = a.Cy / 8;                                 // 16-byte columns per dy pixel: 4, 8 or 16
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
   typedef __attribute__((ext_vector_type(4))) float f4_t;
-  // row phase: lanes of a quad own the same 8-channel piece of 4 consecutive pixels, so the per-channel sums reduce
-  // with two DPP quad swaps
+  // row phase: lanes of a quad own the same 8-channel piece of 4 consecutive pixels -- the same 8 channels for the
+  // whole kernel: their coefficients and BatchNorm sums live in registers
   const int piece = lane >> 2, q0 = lane & 3;
-  const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int n_it = my_tiles * a.nct;                          // (tile, channel tile) pairs of this workgroup, in order
+  const int cg = c0 + piece * 8;
+  const bool ch_ok = cg < a.C;
+  float sc8[8], sh8[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg + e;
+    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
+    if (a.mode == 2 && c < a.C) {
+      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
+      sh8[e] = bt - a.mean[c] * sc8[e];
+    }
+  }
+  // ---- this channel tile's filter fragments: once
+  if (!(a.dbg & 1))
+    for (int f = tid; f < kch * 512; f += 256) {              // 16-byte unit of the [kch][8][64 lanes] fragment block
+      const int kc = f >> 9, t8 = (f >> 6) & 7, ln = f & 63;
+      const int tile16 = ct * 8 + t8;
+      lds_write16(wt + f * 16, tile16 < a.ntile_total ? *reinterpret_cast<const u32x4*>(a.w + ((long long)kc * a.ntile_total + tile16) * 512 + ln * 8) : zero4);
+    }
+  const int my_tiles = slot < a.ntiles ? (a.ntiles - slot + nslots - 1) / nslots : 0;
 
-  // x / G rows of one (tile, channel tile) pair: requested one whole iteration ahead, so that HBM reads are in flight
-  // while the previous pair's row phase computes and stores (two register sets, used alternately)
-  auto request = [&](int it, u32x4 (&xv)[4], u32x4 (&gv)[4]) __attribute__((always_inline)) {
-    const int tl = it / a.nct, ct = it - tl * a.nct;
-    const long long p0 = (long long)((int)blockIdx.x + tl * (int)gridDim.x) * B1_PX;
-    const int cg = ct * B1_CT + piece * 8;
+  // dy rows, x / G rows of one pixel tile: requested one whole tile ahead (two register sets, used alternately)
+  u32x4 dyr[4];   // one set: a tile's dy rows are written to LDS at the start of its step, the next request reuses the registers
+  auto request_dy = [&](int tl) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + i * 256;
+      dyr[i] = zero4;
+      if (tl < my_tiles && u < B1_PX * dcols && !(a.dbg & 16)) dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + u / dcols) * a.dy_pitch + (u % dcols) * 8);
+    }
+  };
+  auto request = [&](int tl, u32x4 (&xv)[4], u32x4 (&gv)[4]) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    const bool live = tl < my_tiles;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long p = p0 + wave * 16 + i * 4 + q0;
       xv[i] = gv[i] = zero4;
-      if (it < n_it && cg < a.C && !(a.dbg & 8)) {
+      if (live && ch_ok && !(a.dbg & 8)) {
         xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg);
         if (a.acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg);
       }
     }
   };
-  auto step = [&](int it, u32x4 (&xv)[4], u32x4 (&gv)[4], u32x4 (&xn)[4], u32x4 (&gn)[4]) __attribute__((always_inline)) {
-    const int tl = it / a.nct, ct = it - tl * a.nct;
-    const long long p0 = (long long)((int)blockIdx.x + tl * (int)gridDim.x) * B1_PX;
-    const int c0 = ct * B1_CT;
-    // ---- filter fragments of this channel tile -> registers
-    u32x4 wr[8];
+  auto step = [&](int tl, u32x4 (&xv)[4], u32x4 (&gv)[4], u32x4 (&xn)[4], u32x4 (&gn)[4]) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    B1_BARRIER();                                             // previous tile's dy fragments read by every wave
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = tid + i * 256;                            // 16-byte unit of the [kch][8][64 lanes] fragment block
-      const int kc = f >> 9, t8 = (f >> 6) & 7, ln = f & 63;
-      const int tile16 = ct * 8 + t8;
-      wr[i] = zero4;
-      if (kc < kch && tile16 < a.ntile_total && !(a.dbg & 1)) wr[i] = *reinterpret_cast<const u32x4*>(a.w + ((long long)kc * a.ntile_total + tile16) * 512 + ln * 8);
+    for (int i = 0; i < 4; ++i) {   // column c16 of pixel q lands at column c16 ^ (q mod columns): conflict-free B-fragment reads
+      const int u = tid + i * 256, q = u / dcols, c16 = u % dcols;
+      if (u < B1_PX * dcols) lds_write16(dyt + q * dyrow + ((c16 ^ (q & (dcols - 1))) << 4), dyr[i]);
     }
-    u32x4 dyr[4];                                             // this tile's dy rows (first channel tile only)
-    if (ct == 0 && !(a.dbg & 16))
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = tid + i * 256;
-        dyr[i] = zero4;
-        if (u < B1_PX * dcols) dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + u / dcols) * a.dy_pitch + (u % dcols) * 8);
-      }
-    float sc_t = 1.f, sh_t = 0.f;                             // per-tile mode: this channel tile's coefficients (threads 0-127)
-    if (!sc_once && tid < 128 && a.mode == 2 && c0 + tid < a.C) {
-      const int c = c0 + tid;
-      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-      sc_t = gm / sqrtf(a.var[c] + a.eps);
-      sh_t = bt - a.mean[c] * sc_t;
-    }
-    B1_BARRIER();                                             // previous pair: fragments read, red written, coefficients used
-    if (!sc_once && tid < 128) {
-      scall[tid] = sc_t;
-      scall[128 + tid] = sh_t;
-    }
-    if (it > 0 && a.partial != nullptr) {                     // previous pair's sums: fixed order over the four waves
-      const int pc0 = ((it - 1) % a.nct) * B1_CT, c = tid >> 1, which = tid & 1;
-      const float t = (red[(0 * 128 + c) * 2 + which] + red[(1 * 128 + c) * 2 + which]) +
-                      (red[(2 * 128 + c) * 2 + which] + red[(3 * 128 + c) * 2 + which]);
-      stats[(pc0 + c) * 2 + which] += t;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = tid + i * 256;
-      if ((f >> 9) < kch) lds_write16(wt + f * 16, wr[i]);
-    }
-    if (ct == 0 && !(a.dbg & 16))   // column c16 of pixel q lands at column c16 ^ (q mod columns): conflict-free B-fragment reads
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = tid + i * 256, q = u / dcols, c16 = u % dcols;
-        if (u < B1_PX * dcols) lds_write16(dyt + q * dyrow + ((c16 ^ (q & (dcols - 1))) << 4), dyr[i]);
-      }
     B1_BARRIER();
+    request_dy(tl + 1);                                       // next tile: in flight during this tile's MFMAs and row phase
+    request(tl + 1, xn, gn);
     // ---- MFMA: wave = 16 pixels x 128 channels
     f32x4 acc[8];
 #pragma unroll
@@ -173,8 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[j], 0, 0, 0);
         }
       }
-    request(it + 1, xn, gn);                                  // next pair's rows: in flight during this row phase
-    // ---- row phase: transpose through the wave's staging area, mask, sums, G += gamma*rstd*v (or store v)
+    // ---- row phase: transpose through the wave's staging area, mask, sums, G (+)= gamma*rstd*v (or store v)
     if (a.dbg & 4) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
@@ -183,15 +161,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
       *reinterpret_cast<u32x2*>(tb + m * B1_TBP + j * 32 + kgl * 8) = bits;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int cg = c0 + piece * 8;
-    const bool ch_ok = cg < a.C;
-    float sc8[8], sh8[8], s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sc8[e] = sc_once ? scall[cg + e] : scall[piece * 8 + e];
-      sh8[e] = sc_once ? scall[cpad + cg + e] : scall[128 + piece * 8 + e];
-      s1[e] = s2[e] = 0.f;
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ql = i * 4 + q0;
@@ -209,41 +178,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
       if (ch_ok) *reinterpret_cast<u32x4*>(a.g + (p0 + wave * 16 + ql) * a.g_pitch + cg) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (a.partial != nullptr) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s1[e] += __shfl_xor(s1[e], 1, 64);
-        s2[e] += __shfl_xor(s2[e], 1, 64);
-        s1[e] += __shfl_xor(s1[e], 2, 64);
-        s2[e] += __shfl_xor(s2[e], 2, 64);
-      }
-      if (q0 == 0)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          red[(wave * 128 + piece * 8 + e) * 2] = s1[e];
-          red[(wave * 128 + piece * 8 + e) * 2 + 1] = s2[e];
-        }
-    }
   };
 
   u32x4 xa[4], ga[4], xb[4], gb[4];
-  B1_BARRIER();                                               // scall / stats initialised
+  request_dy(0);
   request(0, xa, ga);
-  for (int it = 0; it < n_it; it += 2) {
-    step(it, xa, ga, xb, gb);
-    if (it + 1 < n_it) step(it + 1, xb, gb, xa, ga);
+  for (int tl = 0; tl < my_tiles; tl += 2) {
+    step(tl, xa, ga, xb, gb);
+    if (tl + 1 < my_tiles) step(tl + 1, xb, gb, xa, ga);
   }
-  if (a.partial != nullptr) {
-    B1_BARRIER();
-    if (n_it > 0) {
-      const int pc0 = ((n_it - 1) % a.nct) * B1_CT, c = tid >> 1, which = tid & 1;
-      const float t = (red[(0 * 128 + c) * 2 + which] + red[(1 * 128 + c) * 2 + which]) +
-                      (red[(2 * 128 + c) * 2 + which] + red[(3 * 128 + c) * 2 + which]);
-      stats[(pc0 + c) * 2 + which] += t;
+  if (a.partial != nullptr) {   // quad -> lane 0 of the quad, then the four waves in a fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += __shfl_xor(s1[e], 1, 64);
+      s2[e] += __shfl_xor(s2[e], 1, 64);
+      s1[e] += __shfl_xor(s1[e], 2, 64);
+      s2[e] += __shfl_xor(s2[e], 2, 64);
     }
+    B1_BARRIER();                                             // every wave is through its last row phase (red aliases tb)
+    if (q0 == 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 128 + piece * 8 + e) * 2] = s1[e];
+        red[(wave * 128 + piece * 8 + e) * 2 + 1] = s2[e];
+      }
     B1_BARRIER();
-    float* dst = a.partial + (long long)blockIdx.x * a.nct * 256;
-    for (int i = tid; i < a.nct * 256; i += 256) dst[i] = stats[i];
+    const int c = tid >> 1, which = tid & 1;
+    const float t = (red[(0 * 128 + c) * 2 + which] + red[(1 * 128 + c) * 2 + which]) +
+                    (red[(2 * 128 + c) * 2 + which] + red[(3 * 128 + c) * 2 + which]);
+    a.partial[((long long)slot * a.nct * B1_CT + c0 + c) * 2 + which] = t;
   }
 }
 
@@ -276,15 +239,17 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   a.mode = norm ? 2 : 1, a.acc = accumulate;
   a.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
-  long long grid = a.ntiles < 512 ? a.ntiles : 512;            // two resident workgroups per CU
+  long long nslots = 512 / a.nct;                              // two resident workgroups per CU in all
+  if (nslots < 1) nslots = 1;
+  if (nslots > a.ntiles) nslots = a.ntiles;
+  const long long grid = nslots * a.nct;
   a.partial = norm ? partial : nullptr;
-  if (norm) FD_REQUIRE(partial && grid * a.nct * 256 <= capacity_floats, "conv2d_bwd_data: workspace too small (%lld floats needed)", grid * a.nct * 256);
+  if (norm) FD_REQUIRE(partial && nslots * a.nct * 256 <= capacity_floats, "conv2d_bwd_data: workspace too small (%lld floats needed)", nslots * a.nct * 256);
   static const char* ph = getenv("FDGAN_DEBUG_PHASES");
   a.dbg = ph ? atoi(ph) : 0;
-  if (rows_out) *rows_out = grid;
+  if (rows_out) *rows_out = nslots;
   if (cpad_out) *cpad_out = a.nct * 128;
-  const unsigned lds = (unsigned)(B1_PX * a.Cy * 2 + (a.Cy / 32) * 8 * 1024 + 4 * B1_TB + 4 * 128 * 2 * 4 + a.nct * 256 * 4 +
-                                  (a.nct <= 5 ? a.nct : 1) * 256 * 4);
+  const unsigned lds = (unsigned)(B1_PX * a.Cy * 2 + (a.Cy / 32) * 8 * 1024 + 4 * B1_TB);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
