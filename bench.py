@@ -153,6 +153,8 @@ def _model_conv_bwd_data(args, kw):
     name = "conv%dx%d_bn%d_bwd" % (desc.ksize, desc.ksize, 32 if dpre_fd.c <= 32 else 128)
     if desc.ksize == 1 and dy_fd.c in (32, 64, 128) and px % 64 == 0 and dpre_fd.c <= 1024:
         name = "conv1x1_bwd_stream"                       # conv1x1_bwd_fits (whole-buffer views in the training step)
+    if desc.ksize == 3 and desc.pad == 1 and dy_fd.c == 32 and dpre_fd.c == 128:
+        name = "conv3x3_bwd_stream"                       # conv3x3_bwd_fits
     return name, byts, flops
 
 
@@ -161,6 +163,7 @@ for _k in (1, 3, 4):
     for _w in (32, 128):
         MODELS["conv%dx%d_bn%d_bwd" % (_k, _k, _w)] = ("conv_bwd_data", _model_conv_bwd_data)
 MODELS["conv1x1_bwd_stream"] = ("conv_bwd_data", _model_conv_bwd_data)
+MODELS["conv3x3_bwd_stream"] = ("conv_bwd_data", _model_conv_bwd_data)
 
 
 def train_bench(a, dp, dev, B, S):

@@ -1,0 +1,243 @@
+// conv3x3_bwd.hip -- data gradient of the dense-layer growth conv (3x3, pad 1, 128 -> 32 forward, so 32 -> 128 here)
+// fused with the backward of its BatchNorm + ReLU prologue, as a row-streaming kernel.
+//
+//   da[y][x][c] = sum_{ky,kx,k} dy[y + ky - 1][x + kx - 1][k] * Wf[ky][kx][k][c]     (Wf: the flipped filter image)
+//   v = da * act'(bn(xb[y][x][c]));  sums (v, v * xb) per channel;  G = / += gamma*rstd * v   (or dpre = v)
+//
+// The generic implicit-GEMM instantiation moves 2.6 TB/s on this shape.  Same recipe as conv1x1_bwd.hip, organised around
+// the big operands (the 128-channel xb and G rows; dy has 32 channels):
+//   * a workgroup (8 waves, one per CU: the filter alone is 72 KB of LDS) owns (image, 64-pixel column block, row
+//     segment) with ALL 128 output channels: the nine taps' filter fragments are staged once;
+//   * dy rows live in a 4-slot LDS ring (66 pixels x 64 B): one new row per output row, requested a row ahead, ONE
+//     barrier per row; a tap is a (row slot, pixel offset) pair of the same ring;
+//   * wave (w & 3, w >> 2) owns 16 pixels x 64 channels: 9 B-fragment reads + 36 A-fragment reads per 36 MFMAs;
+//   * row phase as in the MK kernels (accumulator tile transposed through a wave-private LDS area, whole 16-byte pieces
+//     of pixel rows in and out) with the xb / G rows of the NEXT output row already requested (two register sets);
+//     a lane owns the same 8 channels for the whole kernel: coefficients and BatchNorm sums in registers.
+// Reference: autograd of conv2 / norm2 / relu2 of torchvision's _DenseLayer as used by
+// /root/reference/models/dehaze1113.py:713-724.
+#include <stdlib.h>
+
+#include "conv_igemm.h"
+
+namespace {
+
+constexpr int B3_PB = 64;                        // output pixels per row step
+constexpr int B3_DPIX = B3_PB + 2;               // staged dy pixels per row
+constexpr int B3_DROW = B3_DPIX * 64;            // 32 channels x 2 B per pixel
+constexpr int B3_W = 9 * 8 * 1024;               // filter fragments [tap][cout tile][lane x 16 B]
+constexpr int B3_TBP = 128 + 16;                 // transposition pitch of one pixel (64 channels)
+constexpr int B3_TB = 16 * B3_TBP;
+constexpr int B3_LDS = B3_W + 4 * B3_DROW + 8 * B3_TB;
+#define B3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct Bwd3Args {
+  const unsigned short* dy;   // [N][H][W][32]
+  long long dy_sn;
+  int dy_sh, dy_sw;
+  const unsigned short* w;    // chunk32 image of the flipped filter: [tap][8 tiles][64 lanes][8]
+  const unsigned short* x;    // forward input of the conv (the bottleneck), 128 channels
+  long long x_sn;
+  int x_sh, x_sw;
+  unsigned short* g;          // gradient buffer of x, or dpre
+  long long g_sn;
+  int g_sh, g_sw;
+  int H, W;
+  int xblocks, seg_rows, segs;
+  int mode, acc;              // 1 activation only, 2 BatchNorm + activation; acc 1: G += gamma*rstd*v, 2: G = gamma*rstd*v, 0: G = v
+  float slope, eps;
+  const float *mean, *var, *gamma, *beta;
+  float* partial;             // [items][128][2] or NULL
+};
+
+__global__ __launch_bounds__(512) void conv3x3_bwd_kernel(Bwd3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char b3_lds[];
+  char* wt = b3_lds;
+  char* ring = b3_lds + B3_W;
+  char* tb0 = ring + 4 * B3_DROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kgl = lane >> 4;
+  const int pxq = wave & 3, chh = wave >> 2;                  // 16-pixel quarter, 64-channel half
+  char* tb = tb0 + wave * B3_TB;
+  const int item = blockIdx.x;
+  const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
+  const int y_begin = seg * a.seg_rows, y_end = min(a.H, y_begin + a.seg_rows);
+  const int xbase = xb * B3_PB;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  // ---- filter fragments: once
+  for (int f = tid; f < 9 * 8 * 64; f += 512) lds_write16(wt + f * 16, *reinterpret_cast<const u32x4*>(a.w + (long long)f * 8));
+  // ---- row phase ownership: 8 channels of 8 pixels per instruction, two instructions per 16-pixel tile
+  const int piece = lane & 7, ql = lane >> 3;
+  const int cg = chh * 64 + piece * 8;
+  float sc8[8], sh8[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg + e;
+    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
+    if (a.mode == 2) {
+      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
+      sh8[e] = bt - a.mean[c] * sc8[e];
+    }
+  }
+  // ---- dy row staging: thread -> (pixel tid / 4, 16-byte piece tid % 4) of the 66-pixel row
+  const int dpix = tid >> 2, dpiece = tid & 3;
+  const bool d_thr = dpix < B3_DPIX;
+  const int dpx = xbase - 1 + dpix;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + dpiece * 8;
+  u32x4 dyr = zero4;
+  auto request_dy = [&](int row) __attribute__((always_inline)) {
+    dyr = zero4;
+    if (d_thr && row >= 0 && row < a.H && dpx >= 0 && dpx < a.W) dyr = *reinterpret_cast<const u32x4*>(dimg + (long long)row * a.dy_sh + (long long)dpx * a.dy_sw);
+  };
+  auto store_dy = [&](int row) __attribute__((always_inline)) {
+    if (d_thr) lds_write16(ring + ((row + 1) & 3) * B3_DROW + dpix * 64 + dpiece * 16, dyr);
+  };
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn + cg;
+  unsigned short* gimg = a.g + (long long)n * a.g_sn + cg;
+  auto request_rows = [&](int row, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int px = xbase + pxq * 16 + i * 8 + ql;
+      xv[i] = gv[i] = zero4;
+      if (row < y_end && px < a.W) {
+        xv[i] = *reinterpret_cast<const u32x4*>(ximg + (long long)row * a.x_sh + (long long)px * a.x_sw);
+        if (a.acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(gimg + (long long)row * a.g_sh + (long long)px * a.g_sw);
+      }
+    }
+  };
+  auto step = [&](int y, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2]) __attribute__((always_inline)) {
+    store_dy(y + 1);                                          // requested during the previous step; its slot held row y - 3
+    B3_BARRIER();                                             // row y + 1 visible; every wave is past the MFMAs of row y - 1
+    request_dy(y + 2);
+    request_rows(y + 1, xn, gn);
+    // ---- MFMA: 16 pixels x 64 channels, nine taps
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const char* rowp = ring + ((y + ky) & 3) * B3_DROW;      // dy row y + ky - 1
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(rowp + (pxq * 16 + m + kx) * 64 + kgl * 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 afr = __builtin_bit_cast(bf16x8, lds_read16(wt + (((ky * 3 + kx) * 8 + chh * 4 + j) * 64 + lane) * 16));
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- row phase
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){acc[j][0], acc[j][1], acc[j][2], acc[j][3]}, bf16x4_t));
+      *reinterpret_cast<u32x2*>(tb + m * B3_TBP + j * 32 + kgl * 8) = bits;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pl = i * 8 + ql, px = xbase + pxq * 16 + pl;
+      const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, lds_read16(tb + pl * B3_TBP + piece * 16)), f32x8);
+      const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+      f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
+      const bool ok = px < a.W;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pre = fmaf(fx[e], sc8[e], sh8[e]);
+        const float v = ok ? da[e] * (pre > 0.f ? 1.f : a.slope) : 0.f;
+        s1[e] += v;
+        s2[e] += v * fx[e];
+        o[e] = a.acc ? fmaf(sc8[e], v, o[e]) : v;
+      }
+      if (ok) *reinterpret_cast<u32x4*>(gimg + (long long)y * a.g_sh + (long long)px * a.g_sw) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // rows y_begin - 1 and y_begin, then row y_begin + 1 in flight
+  request_dy(y_begin - 1);
+  store_dy(y_begin - 1);
+  request_dy(y_begin);
+  store_dy(y_begin);
+  request_dy(y_begin + 1);
+  u32x4 xa[2], ga[2], xb_[2], gb[2];
+  request_rows(y_begin, xa, ga);
+  for (int y = y_begin; y < y_end; y += 2) {
+    step(y, xa, ga, xb_, gb);
+    if (y + 1 < y_end) step(y + 1, xb_, gb, xa, ga);
+  }
+  if (a.partial != nullptr) {   // lanes 8 apart own the same channels; then the four pixel quarters in a fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int d = 8; d < 64; d <<= 1) {
+        s1[e] += __shfl_xor(s1[e], d, 64);
+        s2[e] += __shfl_xor(s2[e], d, 64);
+      }
+    B3_BARRIER();                                             // every wave is through its last row phase (red aliases tb)
+    float* red = reinterpret_cast<float*>(tb0);               // [8 waves][64][2]
+    if (ql == 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 64 + piece * 8 + e) * 2] = s1[e];
+        red[(wave * 64 + piece * 8 + e) * 2 + 1] = s2[e];
+      }
+    B3_BARRIER();
+    if (tid < 256) {
+      const int c = tid >> 1, which = tid & 1, h = c >> 6, cl = c & 63;   // channel half h: waves 4 h .. 4 h + 3
+      const float t = (red[((4 * h + 0) * 64 + cl) * 2 + which] + red[((4 * h + 1) * 64 + cl) * 2 + which]) +
+                      (red[((4 * h + 2) * 64 + cl) * 2 + which] + red[((4 * h + 3) * 64 + cl) * 2 + which]);
+      a.partial[((long long)item * 128 + c) * 2 + which] = t;
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre, const FdConvDesc* d) {
+  auto rows16 = [](const FdTensor* t) {
+    return t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0 &&
+           t->stride[1] < (1ll << 31) && t->stride[2] < (1ll << 31);
+  };
+  return d->ksize == 3 && d->stride == 1 && d->pad == 1 && dy->c == 32 && dpre->c == 128 && fwd_x->c >= 128 && dy->h == dpre->h &&
+         dy->w == dpre->w && dy->n == dpre->n && rows16(dy) && rows16(fwd_x) && rows16(dpre) && getenv("FDGAN_DEBUG_NO_BWD3X3S") == nullptr;
+}
+
+int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
+                       int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
+                       hipStream_t stream) {
+  Bwd3Args a{};
+  a.dy = static_cast<const unsigned short*>(dy->ptr), a.dy_sn = dy->stride[0], a.dy_sh = (int)dy->stride[1], a.dy_sw = (int)dy->stride[2];
+  a.w = static_cast<const unsigned short*>(w_packed);
+  a.x = static_cast<const unsigned short*>(fwd_x->ptr), a.x_sn = fwd_x->stride[0], a.x_sh = (int)fwd_x->stride[1], a.x_sw = (int)fwd_x->stride[2];
+  a.g = static_cast<unsigned short*>(dpre->ptr), a.g_sn = dpre->stride[0], a.g_sh = (int)dpre->stride[1], a.g_sw = (int)dpre->stride[2];
+  a.H = (int)dpre->h, a.W = (int)dpre->w;
+  const bool norm = pro && pro->mean;
+  const int act = pro ? pro->act : FD_ACT_NONE;
+  a.mode = norm ? 2 : 1, a.acc = accumulate;
+  a.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
+  if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
+  a.xblocks = (a.W + B3_PB - 1) / B3_PB;
+  const long long strips = dpre->n * a.xblocks;
+  long long segs = 256 / strips;                               // one resident workgroup per CU
+  if (segs < 1) segs = 1;
+  if (segs > (a.H + 3) / 4) segs = (a.H + 3) / 4;              // at least 4 rows per item (2 halo rows re-staged per item)
+  a.seg_rows = (int)((a.H + segs - 1) / segs);
+  a.segs = (a.H + a.seg_rows - 1) / a.seg_rows;
+  const long long items = strips * a.segs;
+  a.partial = norm ? partial : nullptr;
+  if (norm) FD_REQUIRE(partial && items * 256 <= capacity_floats, "conv2d_bwd_data: workspace too small (%lld floats needed)", items * 256);
+  if (rows_out) *rows_out = items;
+  if (cpad_out) *cpad_out = 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv3x3_bwd): %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  return fd_launch(&conv3x3_bwd_kernel, "conv3x3_bwd_stream", dim3((unsigned)items), dim3(512), B3_LDS, a, stream);
+}

@@ -819,6 +819,11 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
 int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
                        int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
                        hipStream_t stream);
+// row-streaming 3x3 data gradient of the growth conv + prologue backward (conv3x3_bwd.hip)
+bool conv3x3_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre, const FdConvDesc* d);
+int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
+                       int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
+                       hipStream_t stream);
 // 1x1 weight gradient with transpose reads (conv_wgrad1x1_tr.hip)
 bool conv_wgrad1x1_tr_fits(const FdTensor* x, const FdTensor* dy, int cout, int ksize, int stride, bool pool, bool has_bias);
 int conv_wgrad1x1_tr_launch(const FdTensor* x, const FdTensor* dy, int pro_mode, float p_slope, float eps, const float* mean,

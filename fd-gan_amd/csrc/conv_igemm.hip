@@ -212,6 +212,15 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
     if (cpad_out) *cpad_out = cpad;
     return rc;
   }
+  if (dy->dtype == FD_BF16 && (d->cout <= 0 || d->cout == dpre->c) && conv3x3_bwd_fits(dy, fwd_x, dpre, d)) {
+    FD_REQUIRE(!(fwd_pro && fwd_pro->mean) || (fwd_pro->var && partial), "conv2d_bwd_data: a BatchNorm prologue needs var and the partial-sum workspace");
+    long long rows = 0, cpad = 0;
+    const int rc = conv3x3_bwd_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, partial, capacity_floats, &rows, &cpad,
+                                      static_cast<hipStream_t>(stream));
+    if (rows_out) *rows_out = rows;
+    if (cpad_out) *cpad_out = cpad;
+    return rc;
+  }
   ConvArgs a;
   long long nimg;
   bool pool;

@@ -165,7 +165,9 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     (3, 1, 16, 40, "relu", (2, 13, 19)),
     # N*H*W a multiple of 64 and at most 128 forward filters: the streaming 1x1 kernel (conv1x1_bwd.hip)
     (1, 0, 96, 128, "relu", (2, 16, 24)), (1, 0, 224, 128, "relu", (1, 8, 64)), (1, 0, 40, 64, "leaky", (2, 8, 8)),
-    (1, 0, 992, 128, "relu", (1, 8, 8)), (3, 1, 128, 32, "relu", (3, 80, 96))])
+    (1, 0, 992, 128, "relu", (1, 8, 8)), (3, 1, 128, 32, "relu", (3, 80, 96)),
+    # the growth conv's data gradient (32 -> 128): row-streaming kernel (conv3x3_bwd.hip); ragged width, short images
+    (3, 1, 128, 32, "relu", (2, 5, 70)), (3, 1, 128, 32, "leaky", (1, 33, 64))])
 def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     """fdgan_conv2d_bwd_data: conv^T(dy, W) * act'(bn(x)) stored by the data-gradient kernel itself, with the raw
     moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
