@@ -796,6 +796,48 @@ def test_overlapped_allreduce_on_rccl_one_rank_group():
         dist.destroy_process_group()
 
 
+def test_backward_variants_agree(monkeypatch):
+    """The fast backward (stored sole-consumer gradients without zeroing, BatchNorm's linear remainder deferred, streaming
+    bottleneck kernels) against the plain one (everything accumulated into zeroed buffers, per-layer apply pass, generic
+    kernels), selected by the tuning switches at PlanBackward construction: same weights, same input.
+    Stored vs accumulated-into-zero is the same arithmetic (bitwise equal gradients); the other switches reorder
+    bf16 roundings."""
+    import copy
+    import models.dehaze1113 as net
+    torch.manual_seed(21)
+    g_fast = net.FDGAN().to(DEV)
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    tgt = torch.rand(2, 3, 64, 64, device=DEV) * 2 - 1
+
+    def grads_of(switches):
+        for k in ("FDGAN_NO_DX_STORE", "FDGAN_NO_DEFERRED_AFFINE", "FDGAN_DEBUG_NO_BWD1X1S", "FDGAN_DEBUG_NO_BWD3X3S",
+                  "FDGAN_DEBUG_NO_WGRAD1X1_TR", "FDGAN_DEBUG_NO_WGRAD_TR"):
+            monkeypatch.delenv(k, raising=False)
+        for k in switches:
+            monkeypatch.setenv(k, "1")
+        g = copy.deepcopy(g_fast)
+        ((g(x) - tgt) ** 2).mean().backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
+
+    fast = grads_of(())
+    no_store = grads_of(("FDGAN_NO_DX_STORE",))
+    assert fast.keys() == no_store.keys() and len(fast) == 282
+    for k in fast:
+        assert torch.equal(fast[k], no_store[k]), k
+    plain = grads_of(("FDGAN_NO_DX_STORE", "FDGAN_NO_DEFERRED_AFFINE"))
+    # the dense blocks' gradients are chaotic at this size (ReLU masks flip under any rounding change: the two CPU oracles
+    # of test_fdgan_backward differ by 35-75 % there); judge the worst case on the parameters downstream of them
+    stable = [k for k in fast if not k.startswith(("dense_block1", "dense_block2", "dense_block3", "conv_refine4", "trans_block1",
+                                                   "conv_refin1", "conv_refin2"))]
+    worst = max(rel_rms(fast[k], plain[k]) for k in stable)
+    med = float(np.median([rel_rms(fast[k], plain[k]) for k in fast]))
+    # NOTE: the getenv-cached kernel switches (FDGAN_DEBUG_NO_*) are read once per process, so they are exercised by the
+    # unit tests of test_hip_bwd.py rather than here
+    _report("backward_variants", {"deferred_vs_per_layer_apply": {"worst": worst, "median": med}})
+    assert med < 0.03 and worst < 0.1 and len(stable) >= 10, (med, worst, len(stable))
+
+
 def test_flat_gradient_sink_equals_autograd_accumulation():
     """With FlatAdam the backward walk adds weight / bias / BatchNorm gradients straight into the flat gradient views
     (no autograd accumulation): two backward passes (the real and the fake half of a discriminator step) must leave
