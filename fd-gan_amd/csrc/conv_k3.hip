@@ -12,10 +12,13 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
     return conv_dispatch_k3_rs(a, nimg, cout_total, info, stats_cap, dry, stream);
   if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && getenv("FDGAN_DEBUG_NO_PW") == nullptr)
     return conv_dispatch_k3_pw(a, nimg, cout_total, info, stats_cap, dry, stream);
+  const bool mid = cout_total <= 64;   // 64 output channels per workgroup: the 128-wide tile would idle half its MFMAs (VGG16 conv1_2: 197 us)
   if (a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
     if (narrow) FD_CONV_DISPATCH_X(3, 1, 0, 4, 2, 4, 1, 9, 1, "conv3x3_bn32_bwd");
+    if (mid) FD_CONV_DISPATCH_X(3, 1, 0, 4, 4, 4, 1, 1, 1, "conv3x3_bn64_bwd");
     FD_CONV_DISPATCH_X(3, 1, 0, 4, 8, 4, 1, 1, 1, "conv3x3_bn128_bwd");
   }
   if (narrow) FD_CONV_DISPATCH(3, 1, 0, 4, 2, 4, 1, 9, "conv3x3_bn32");
+  if (mid) FD_CONV_DISPATCH(3, 1, 0, 4, 4, 4, 1, 1, "conv3x3_bn64");
   FD_CONV_DISPATCH(3, 1, 0, 4, 8, 4, 1, 1, "conv3x3_bn128");
 }
