@@ -151,7 +151,7 @@ class PlanBackward:
                     self.multi_version.add(rx[0])
                     break
         dev = plan.device
-        self.ws = torch.empty(1 << 25, dtype=torch.float32, device=dev)      # split-K partials (128 MiB)
+        self.ws = torch.empty(1 << 26, dtype=torch.float32, device=dev)      # split-K partials (256 MiB)
         self.ws_bn = torch.empty(1 << 24, dtype=torch.float32, device=dev)   # BatchNorm-backward partial sums (64 MiB)
         self.ws_fin = torch.empty(64 * 4096, dtype=torch.float32, device=dev)  # second level of the BatchNorm-sum reduction
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
