@@ -179,10 +179,10 @@ def train_bench(a, dp, dev, B, S):
         ts.step(haze, gt)
     torch.cuda.synchronize()
     # ---- one instrumented step (every launch bracketed) -> GPU time per launcher name
-    E.kernel_timer_arm(None, 1, 16384)
+    E.kernel_timer_arm(None, 1, 4096)
     ts.step(haze, gt)
     torch.cuda.synchronize()
-    samples, n_launch = E.kernel_timer_read(16384)
+    samples, n_launch = E.kernel_timer_read(4096)
     by_name = {}
     for _, ms, name in samples:
         d = by_name.setdefault(name, [0, 0.0])
