@@ -15,6 +15,17 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// ---- tuning switches ------------------------------------------------------------
+// Kernel-selection / phase-skipping switches used by tools/ while tuning.  They exist only in builds made with
+// -DFDGAN_TUNING (FDGAN_TUNING=1 python __graft_entry__.py); in the shipped library the macro is a constant NULL, the
+// branches fold away and the switch names do not appear in the binary (tests/test_capi_cpu.py checks).
+#ifdef FDGAN_TUNING
+#include <stdlib.h>
+#define FD_TUNE_GETENV(name) getenv(name)
+#else
+#define FD_TUNE_GETENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 // ---- errors ---------------------------------------------------------------
 void fd_set_error(const char* fmt, ...);
 #define FD_FAIL(code, ...)      \

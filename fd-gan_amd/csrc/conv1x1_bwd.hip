@@ -220,7 +220,7 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
   const long long P = dpre->n * dpre->h * dpre->w;
   return (dy->c == 32 || dy->c == 64 || dy->c == 128) && dense(dy) && dense(fwd_x) && dense(dpre) && P % B1_PX == 0 &&
          dpre->c <= 1024 && dpre->stride[2] >= (dpre->c + 7) / 8 * 8 && fwd_x->stride[2] >= (dpre->c + 7) / 8 * 8 &&
-         P * fwd_x->stride[2] < (1ll << 40) && getenv("FDGAN_DEBUG_NO_BWD1X1S") == nullptr;
+         P * fwd_x->stride[2] < (1ll << 40) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_BWD1X1S") == nullptr;
 }
 
 /* rows_out / cpad_out: shape of the partial-sum block written when `partial` is given. */
@@ -245,7 +245,7 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   const long long grid = nslots * a.nct;
   a.partial = norm ? partial : nullptr;
   if (norm) FD_REQUIRE(partial && nslots * a.nct * 256 <= capacity_floats, "conv2d_bwd_data: workspace too small (%lld floats needed)", nslots * a.nct * 256);
-  static const char* ph = getenv("FDGAN_DEBUG_PHASES");
+  static const char* ph = FD_TUNE_GETENV("FDGAN_DEBUG_PHASES");
   a.dbg = ph ? atoi(ph) : 0;
   if (rows_out) *rows_out = nslots;
   if (cpad_out) *cpad_out = a.nct * 128;

@@ -376,7 +376,7 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
               a.y_sn == (long long)a.Ho * a.y_sh;
   if (!conv1x1_xs_fits(cout_total, a.Cin)) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_xs: filter does not fit LDS");
   // the bottleneck shape (-> 128 channels, dense tensors, plain epilogue) streams through LDS-DMA
-  if (conv1x1_ds_fits(a, cout_total, pool, FD_WLAYOUT_X64) && getenv("FDGAN_DEBUG_NO_DS") == nullptr)
+  if (conv1x1_ds_fits(a, cout_total, pool, FD_WLAYOUT_X64) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_DS") == nullptr)
     return conv_dispatch_k1_ds(a, info, stats_cap, dry, stream);
   const int nks = a.nks;
   const long long big_tiles = (a.P + 511) / 512;

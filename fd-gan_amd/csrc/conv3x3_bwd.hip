@@ -204,7 +204,7 @@ bool conv3x3_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
            t->stride[1] < (1ll << 31) && t->stride[2] < (1ll << 31);
   };
   return d->ksize == 3 && d->stride == 1 && d->pad == 1 && dy->c == 32 && dpre->c == 128 && fwd_x->c >= 128 && dy->h == dpre->h &&
-         dy->w == dpre->w && dy->n == dpre->n && rows16(dy) && rows16(fwd_x) && rows16(dpre) && getenv("FDGAN_DEBUG_NO_BWD3X3S") == nullptr;
+         dy->w == dpre->w && dy->n == dpre->n && rows16(dy) && rows16(fwd_x) && rows16(dpre) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_BWD3X3S") == nullptr;
 }
 
 int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,

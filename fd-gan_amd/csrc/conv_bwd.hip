@@ -928,7 +928,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   }
   // the dense-layer growth conv: all nine taps in one workgroup
   if (workspace != nullptr && dbias == nullptr && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !pool && cout <= 32 &&
-      a.Cin % 32 == 0 && a.Ws % 4 == 0 && getenv("FDGAN_DEBUG_NO_WGRAD3") == nullptr) {
+      a.Cin % 32 == 0 && a.Ws % 4 == 0 && FD_TUNE_GETENV("FDGAN_DEBUG_NO_WGRAD3") == nullptr) {
     Wgrad3Args w{};
     w.x = a.x, w.x_sn = a.x_sn, w.x_sh = a.x_sh, w.x_sw = a.x_sw;
     w.dy = a.dy, w.dy_sn = a.dy_sn, w.dy_sh = a.dy_sh, w.dy_sw = a.dy_sw;
@@ -977,7 +977,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
   // workgroup tile: 64 x 64 with 4 waves, or 128 x 128 with 8 waves (half the L2 -> LDS traffic per flop: the 64-tile
   // kernel runs at the ~5 TB/s its operand re-reads can be served at) when both channel counts fill it
-  static const char* tsel = getenv("FDGAN_DEBUG_WGRAD_T");   // tuning aid: force 64 / 128
+  static const char* tsel = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_T");   // tuning aid: force 64 / 128
   const bool fits128 = cout >= 96 && a.Cin >= 96 && (cout % 128 == 0 || cout % 128 > 64) && (a.Cin % 128 == 0 || a.Cin % 128 > 32);
   const int T = tsel ? atoi(tsel) : (fits128 ? 128 : 64);
   const long long base = (long long)((a.Cin + T - 1) / T) * ((cout + T - 1) / T) * d->ksize * d->ksize;
@@ -994,7 +994,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   FD_REQUIRE(workspace != nullptr || !accumulate, "conv2d_bwd_weight: accumulate needs a workspace");
   const bool direct = workspace == nullptr;
   FD_REQUIRE(direct || numel + (dbias ? cout : 0) <= workspace_floats, "conv2d_bwd_weight: workspace too small (%lld floats)", numel + cout);
-  static const char* ph = getenv("FDGAN_DEBUG_PHASES");
+  static const char* ph = FD_TUNE_GETENV("FDGAN_DEBUG_PHASES");
   a.dbg_skip = ph ? atoi(ph) : 0;
   a.nsplit = (int)nsplit;
   a.split_px = ((a.P + nsplit - 1) / nsplit + WG_KPX - 1) / WG_KPX * WG_KPX;
@@ -1036,7 +1036,7 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
   fill_pro(pro, a.pro_mode, a.slope, a.eps, a.mean, a.var, a.gamma, a.beta);
   a.cpad = a.C8 * 8;
   long long rows = (a.P + 31) / 32;
-  static const char* cap_env = getenv("FDGAN_DEBUG_BN_ROWS");   // experiment aid
+  static const char* cap_env = FD_TUNE_GETENV("FDGAN_DEBUG_BN_ROWS");   // experiment aid
   const long long chunks = (a.C8 + 7) / 8;                      // 64-channel chunks -> gridDim.y
   long long cap = (cap_env ? atoll(cap_env) : 512) / chunks;    // ~2 workgroups per CU in total measured best
   if (cap < 16) cap = 16;
@@ -1204,7 +1204,7 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.dbeta = dbeta, a.dgamma = dgamma;
   a.accumulate = accumulate;
   long long rows = (a.P + 31) / 32;
-  static const char* cap_env = getenv("FDGAN_DEBUG_BN_ROWS");   // experiment aid
+  static const char* cap_env = FD_TUNE_GETENV("FDGAN_DEBUG_BN_ROWS");   // experiment aid
   const long long chunks = (a.C8 + 7) / 8;
   long long cap = (cap_env ? atoll(cap_env) : 512) / chunks;
   if (cap < 16) cap = 16;
@@ -1227,7 +1227,7 @@ extern "C" int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, 
   a.N = (int)n, a.Cin = cin, a.H = (int)h, a.W = (int)wd, a.ks = d->ksize, a.stride = d->stride, a.pad = d->pad;
   const unsigned lds_px = (unsigned)(d->ksize * d->ksize * cin * ((cout + 7) / 8 * 8) * 4);
   if ((cin == 3 || cin == 9 || cin == 16) && lds_px <= 60 * 1024 && (cout + 7) / 8 * 8 <= dy->stride[2] &&
-      getenv("FDGAN_DEBUG_NO_DGRAD_PX") == nullptr) {
+      FD_TUNE_GETENV("FDGAN_DEBUG_NO_DGRAD_PX") == nullptr) {
     const dim3 grid((unsigned)((n * h * wd + 255) / 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cin == 3) return fd_launch(&dgrad_direct_px_kernel<3>, "dgrad_direct_px3", grid, dim3(256), lds_px, a, st);

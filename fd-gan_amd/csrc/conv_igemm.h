@@ -363,7 +363,7 @@ __device__ __forceinline__ void fd_store_row16_ptr(unsigned short* yrow, int y_s
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS>
+template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS, int WD = 0>
 struct ConvCfg {
   static constexpr int NT = 64 * WM * WN;
   static constexpr int TH = WM * PT, TW = 16;
@@ -376,7 +376,7 @@ struct ConvCfg {
   static constexpr int BN = CTB * 16;
   static constexpr int KK = KS * KS;
   static constexpr int NSPC = KK / TPS;  // steps per chunk
-  static constexpr int W_BYTES = TPS * CTB * 1024;
+  static constexpr int W_BYTES = WD ? 0 : TPS * CTB * 1024;   // WD: filter fragments go global -> registers per wave
   static constexpr int IN_UNITS = 4 * NPIXR;
   static constexpr int IN_UPT = (IN_UNITS + NT - 1) / NT;
   static constexpr int W_UNITS = TPS * CTB * 64;
@@ -389,9 +389,14 @@ struct ConvCfg {
 
 // MK = 1: the backward-data instantiation (masked epilogue, ConvArgs.mk_*); kept out of the forward kernels, whose
 // register budget it would double
-template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS, int MK = 0>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a) {
-  using C = ConvCfg<KS, STRIDE, POOL, PT, CT, WM, WN, TPS>;
+// WD = 1: "filter direct" main loop for the MFMA-bound shapes (wide 3x3 / 4x4: VGG16, D, refine convs).  The waves of a
+// workgroup split the OUTPUT CHANNELS (WN groups of CT*16) and share the pixel tile, so a wave's filter fragments are
+// private to it: they go global -> VGPR in fragment order (16 B per lane, lane-linear: the packed image IS the register
+// image), one tap ahead, and never touch LDS.  LDS holds only the input halo tile of a 32-channel chunk, which all KS*KS
+// taps re-read: ONE barrier per chunk (9 / 16 taps x PT*CT MFMAs per wave) instead of one per tap.
+template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS, int MK = 0, int WD = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void conv_igemm_kernel(ConvArgs a) {
+  using C = ConvCfg<KS, STRIDE, POOL, PT, CT, WM, WN, TPS, WD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* in_lds = smem;                      // [2][IN_BYTES]
   char* w_lds = smem + 2 * C::IN_BYTES;     // [2][W_BYTES]
@@ -508,6 +513,66 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // fragment base addresses
+  const char* xfrag0 = in_lds + kgl * C::PLANE_B + ((wm * PT * STRIDE) * C::IW + m * STRIDE) * 16;
+  if constexpr (WD) {
+    __syncthreads();  // scale/shift visible
+    load_in(0);
+    store_in(in_lds, 0);
+    // this wave's CT filter fragments of step s = chunk * KK + tap: 1 KiB each, lane-linear.  Wave-uniform base pointer
+    // (scalar arithmetic, saddr-form loads) + the lane's 16 bytes.  Output-channel tiles past the filter's last one
+    // re-read a valid tile instead of being zeroed: their accumulators are never stored (the epilogue masks by Cout).
+    const int wnu = __builtin_amdgcn_readfirstlane(wn);
+    int cofs[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const int tile16 = by * C::CTB + wnu * CT + c;
+      cofs[c] = (tile16 < a.ntile_total ? tile16 : 0) * 512;
+    }
+    const unsigned short* wtile = a.w;
+    const long long wstep = (long long)a.ntile_total * 512;
+    const int nsteps = a.nchunk * C::KK;
+    // fragments are requested TWO taps ahead (an L2 round trip under load is longer than one tap's MFMAs); the
+    // sched_barrier keeps the compiler from sinking the request down to its first use
+    u32x4 wcur[CT], wnx1[CT], wnx2[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wcur[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
+    wtile += (1 < nsteps) ? wstep : 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wnx1[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
+    __syncthreads();
+    int s = 1;
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      const bool has_next = (chunk + 1) < a.nchunk;
+      if (has_next) load_in(chunk + 1);
+      const char* xb = xfrag0 + (chunk & 1) * C::IN_BYTES;
+#pragma unroll
+      for (int t = 0; t < C::KK; ++t) {
+        ++s;
+        wtile += (s < nsteps) ? wstep : 0;   // past the end: re-read the last step's fragments
+#pragma unroll
+        for (int c = 0; c < CT; ++c) wnx2[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        const int dy = t / KS, dx = t % KS;
+        bf16x8 xf[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+          xf[p] = __builtin_bit_cast(bf16x8, lds_read16(xb + ((p * STRIDE + dy) * C::IW + dx) * 16));
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[c]), xf[p], acc[p][c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          wcur[c] = wnx1[c];
+          wnx1[c] = wnx2[c];
+        }
+      }
+      if (has_next) store_in(in_lds + ((chunk + 1) & 1) * C::IN_BYTES, chunk + 1);
+      __syncthreads();
+    }
+  } else {
   const int nsteps = a.nchunk * C::NSPC;
   __syncthreads();  // scale/shift visible
   load_in(0);
@@ -516,8 +581,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
   store_w(w_lds);
   __syncthreads();
 
-  // fragment base addresses
-  const char* xfrag0 = in_lds + kgl * C::PLANE_B + ((wm * PT * STRIDE) * C::IW + m * STRIDE) * 16;
   const char* wfrag0 = w_lds + ((wn * CT) * 64 + lane) * 16;
 
   for (int s = 0; s < nsteps; ++s) {
@@ -558,6 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
     if (has_next) store_w(w_lds + ((s + 1) & 1) * C::W_BYTES);
     if (new_chunk) store_in(in_lds + (chunk1 & 1) * C::IN_BYTES, chunk1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue: bias, activation, store, batch statistics
@@ -754,9 +818,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
 //   wide  : BN = 128 (PT=4, CT=8, 4x1 waves, one tap per stage for 3x3 / 4x4)
 //   pool  : BN = 128, TH = 8 (PT=2): 4 source pixels per staged unit
 #define FD_CONV_DISPATCH(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, NAME_) FD_CONV_DISPATCH_X(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, 0, NAME_)
-#define FD_CONV_DISPATCH_X(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, NAME_)                                \
+#define FD_CONV_DISPATCH_X(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, NAME_) FD_CONV_DISPATCH_W(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, 0, NAME_)
+#define FD_CONV_DISPATCH_W(KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, WD_, NAME_)                          \
   do {                                                                                                          \
-    using C = ConvCfg<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_>;                                                \
+    using C = ConvCfg<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, WD_>;                                                \
     a.tiles_x = (a.Wo + C::TW - 1) / C::TW;                                                                     \
     a.tiles_y = (a.Ho + C::TH - 1) / C::TH;                                                                     \
     dim3 grid((unsigned)(nimg * a.tiles_x * a.tiles_y), (unsigned)((cout_total + C::BN - 1) / C::BN), 1);      \
@@ -771,7 +836,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(ConvArgs a)
       info->lds_bytes = lds;                                                                                    \
     }                                                                                                           \
     if (dry) return FD_OK;                                                                                      \
-    auto kfn = &conv_igemm_kernel<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_>;                              \
+    auto kfn = &conv_igemm_kernel<KS_, ST_, POOL_, PT_, CT_, WM_, WN_, TPS_, MK_, WD_>;                              \
     static bool attr_done = false;                                                                              \
     if (!attr_done) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                    \

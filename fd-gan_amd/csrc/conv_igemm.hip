@@ -139,11 +139,11 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
   }
   a.dbg = g_fd_debug_timing;
   {  // measurement aid (tools only): FDGAN_DEBUG_NOSTORE=1 drops every output store
-    static const bool nostore = getenv("FDGAN_DEBUG_NOSTORE") != nullptr;
+    static const bool nostore = FD_TUNE_GETENV("FDGAN_DEBUG_NOSTORE") != nullptr;
     if (nostore) a.Cout = 0;
-    static const char* co = getenv("FDGAN_DEBUG_COALESCE");
+    static const char* co = FD_TUNE_GETENV("FDGAN_DEBUG_COALESCE");
     if (co && d->ksize == 1) a.pad = atoi(co);
-    static const char* ph = getenv("FDGAN_DEBUG_PHASES");   // bit mask of kernel phases to skip (results wrong)
+    static const char* ph = FD_TUNE_GETENV("FDGAN_DEBUG_PHASES");   // bit mask of kernel phases to skip (results wrong)
     a.dbg_skip = ph ? atoi(ph) : 0;
   }
   nimg = x->n;

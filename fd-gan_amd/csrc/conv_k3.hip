@@ -8,10 +8,24 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
   const bool narrow = cout_total <= 32;
   if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
   if (stride != 1) FD_FAIL(FD_EUNSUPPORTED, "3x3 conv with stride %d", stride);
-  if (a.mk_mode == 0 && conv3x3_rs_fits(a, cout_total) && getenv("FDGAN_DEBUG_NO_RS") == nullptr)
+  if (a.mk_mode == 0 && conv3x3_rs_fits(a, cout_total) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_RS") == nullptr)
     return conv_dispatch_k3_rs(a, nimg, cout_total, info, stats_cap, dry, stream);
-  if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && getenv("FDGAN_DEBUG_NO_PW") == nullptr)
+  if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_PW") == nullptr)
     return conv_dispatch_k3_pw(a, nimg, cout_total, info, stats_cap, dry, stream);
+  // MFMA-bound shapes (VGG16, D, the refine convs, the dy blocks' 3x3): filter-direct kernels (conv_igemm.h, WD = 1).
+  {
+    const char* sel = FD_TUNE_GETENV("FDGAN_DEBUG_WD");   // tuning aid: 0 forces the LDS-staged-filter kernels, A..D a variant
+    const char v = sel ? sel[0] : 'x';
+    if (v != '0' && !narrow && a.Cin >= 64 && a.mk_mode == 0) {
+      if (v == 'A') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 1, 4, 9, 0, 1, "conv3x3_wdA");
+      if (v == 'B') FD_CONV_DISPATCH_W(3, 1, 0, 8, 4, 2, 2, 9, 0, 1, "conv3x3_wdB");
+      if (v == 'C') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 4, 9, 0, 1, "conv3x3_wdC");
+      if (v == 'D') FD_CONV_DISPATCH_W(3, 1, 0, 4, 8, 4, 1, 9, 0, 1, "conv3x3_wdD");
+      if (v == 'E') FD_CONV_DISPATCH_W(3, 1, 0, 16, 2, 1, 4, 9, 0, 1, "conv3x3_wdE");
+      if (v == 'G') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 2, 9, 0, 1, "conv3x3_wdG");
+      if (v == 'H') FD_CONV_DISPATCH_W(3, 1, 0, 8, 3, 1, 3, 9, 0, 1, "conv3x3_wdH");
+    }
+  }
   const bool mid = cout_total <= 64;   // 64 output channels per workgroup: the 128-wide tile would idle half its MFMAs (VGG16 conv1_2: 197 us)
   if (a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
     if (narrow) FD_CONV_DISPATCH_X(3, 1, 0, 4, 2, 4, 1, 9, 1, "conv3x3_bn32_bwd");

@@ -177,7 +177,7 @@ bool conv_wgrad1x1_tr_fits(const FdTensor* x, const FdTensor* dy, int cout, int 
   };
   const long long P = x->n * x->h * x->w;
   return ksize == 1 && stride == 1 && !pool && !has_bias && cout == 128 && dy->c == 128 && x->c >= 64 && dense(x) && dense(dy) &&
-         P % W1_PX == 0 && x->stride[2] >= (x->c + 7) / 8 * 8 && getenv("FDGAN_DEBUG_NO_WGRAD1X1_TR") == nullptr;
+         P % W1_PX == 0 && x->stride[2] >= (x->c + 7) / 8 * 8 && FD_TUNE_GETENV("FDGAN_DEBUG_NO_WGRAD1X1_TR") == nullptr;
 }
 
 /* Partials [nsplit][128][Cin] into `workspace`; returns nsplit through *nsplit_out (the caller runs wgrad_reduce). */

@@ -312,7 +312,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   const long long ctiles = (a.Cout + 31) / 32;
   const long long item_stride = ci_tiles * zt * NW * C::TAPS * 512, item_floats = item_stride + (dbias ? ctiles * 32 : 0);
   if (strips * item_floats > workspace_floats || strips >= 65536) return 1;   // caller falls back to the per-tap kernel
-  static const char* wgs_env = getenv("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
+  static const char* wgs_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
   long long segs = (wgs_env ? atoll(wgs_env) : 256) / (strips * ci_tiles * zt);   // one resident workgroup per CU
   if (segs < 1) segs = 1;
   if (segs > (a.Ho + 1) / 2) segs = (a.Ho + 1) / 2;             // at least 2 rows per item (KYN - 1 halo rows re-staged per item)
@@ -327,7 +327,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(%s): %s", name, hipGetErrorString(e));
     attr_done = true;
   }
-  static const char* ph = getenv("FDGAN_DEBUG_PHASES");
+  static const char* ph = FD_TUNE_GETENV("FDGAN_DEBUG_PHASES");
   a.dbg_skip = ph ? atoi(ph) : 0;
   const long long items = strips * a.segs;
   a.bias_part = dbias ? workspace + items * item_stride : nullptr;
@@ -348,7 +348,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
 // 72 -> 144); 4x4: 9 cin tiles, two filter rows per workgroup (the Fusion-discriminator's 144 -> 288 and 288 -> 1,
 // /root/reference/models/dehaze1113.py:200-207).
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool) {
-  if (stride != 1 || pool || cin < 32 || getenv("FDGAN_DEBUG_NO_WGRAD_TR") != nullptr) return 0;
+  if (stride != 1 || pool || cin < 32 || FD_TUNE_GETENV("FDGAN_DEBUG_NO_WGRAD_TR") != nullptr) return 0;
   if (ksize == 3 && pad == 1) {
     int best = 0;
     long long best_pad = 0;

@@ -7,15 +7,18 @@ CHW via swapaxes(0,2), swapaxes(1,2) (== transpose(2,0,1)); `len` is the number 
 `<root>/*h5`; `transform` is accepted and ignored (reference :80-92 is commented out); `seed` only
 seeds numpy (:49-50).
 
-h5py is an optional dependency (absent from the build image): without it, `<index>.npz` files with
-the same two keys are read instead -- same indexing rule, `len` = number of `*.npz` -- and asking
-for an existing `.h5` raises an error that says so.
+h5py is an optional dependency (absent from the build and GPU images): without it the files go through
+`datasets/h5lite.py`, a self-contained reader / writer of exactly the HDF5 subset h5py's defaults produce for these
+files (contiguous float32 datasets in the root group).  `<index>.npz` files with the same two keys are still
+accepted when no `.h5` exists (older fixtures) -- same indexing rule, `len` = number of `*.npz`.
 """
 import glob
 import os
 
 import numpy as np
 import torch.utils.data as data
+
+from . import h5lite
 
 try:  # pragma: no cover - depends on the host image
     import h5py
@@ -26,10 +29,7 @@ except ImportError:  # the build / GPU images ship no h5py
 def _read_pair(root, index):
     stem = root + '/' + str(index)
     if os.path.exists(stem + '.h5'):
-        if h5py is None:
-            raise ImportError("%s.h5 exists but h5py is not installed; convert it to %s.npz (keys 'haze', 'gt') "
-                              "or install h5py" % (stem, stem))
-        with h5py.File(stem + '.h5', 'r') as f:
+        with (h5py if h5py is not None else h5lite).File(stem + '.h5', 'r') as f:
             return f['haze'][:], f['gt'][:]
     if os.path.exists(stem + '.npz'):
         with np.load(stem + '.npz') as f:
@@ -39,8 +39,8 @@ def _read_pair(root, index):
 
 
 def write_pair(root, index, haze, gt):
-    """Writer with generate_testsample.py:31-38 semantics (float32 HWC in [0,1]); .h5 when h5py is
-    available, else .npz."""
+    """Writer with generate_testsample.py:31-38 semantics (float32 HWC in [0,1]): `<index>.h5` with datasets
+    'gt' and 'haze', through h5py when it is installed, else through h5lite (same file structure)."""
     os.makedirs(root, exist_ok=True)
     haze, gt = np.float32(haze), np.float32(gt)
     stem = os.path.join(root, str(index))
@@ -49,8 +49,7 @@ def write_pair(root, index, haze, gt):
             f.create_dataset('gt', data=gt)
             f.create_dataset('haze', data=haze)
         return stem + '.h5'
-    np.savez(stem + '.npz', gt=gt, haze=haze)
-    return stem + '.npz'
+    return h5lite.write(stem + '.h5', {'gt': gt, 'haze': haze})
 
 
 class pix2pix(data.Dataset):

@@ -21,13 +21,14 @@ from fdgan_hip import lib as L  # noqa: E402
 
 
 def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pitch_in=None, pitch_out=None,
-        bias=False, layout=None, reps=20, upsample=False):
+        bias=False, layout=None, reps=20, upsample=False, lrelu=False, e_relu=False, keep_out=False):
     dev = torch.device("cuda:0")
     pad = k // 2 if k == 3 else (1 if k == 4 else 0)
     pitch_in = pitch_in or (cin + 7) // 8 * 8
     ho, wo = (h // 2, w // 2) if pool else (h + 2 * pad - k + 1, w + 2 * pad - k + 1)
     up = 2 if upsample else 1
     pitch_out = pitch_out or (cout + 7) // 8 * 8
+    torch.manual_seed(1234)
     x = (torch.randn(n, h, w, pitch_in, device=dev) * 0.7).to(torch.bfloat16)
     y = torch.empty(n, ho * up, wo * up, pitch_out, dtype=torch.bfloat16, device=dev)
     wt = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
@@ -36,8 +37,8 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
     b = torch.randn(cout, device=dev) if bias else None
     pro = None
     keep = []
-    if bn or relu or pool:
-        kw = dict(act=L.ACT_RELU if (relu or bn) else L.ACT_NONE, pool=pool)
+    if bn or relu or pool or lrelu:
+        kw = dict(act=L.ACT_LEAKY02 if lrelu else (L.ACT_RELU if (relu or bn) else L.ACT_NONE), pool=pool)
         if bn:
             mean, var = torch.randn(cin, device=dev) * 0.1, torch.rand(cin, device=dev) + 0.5
             g, bt = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
@@ -45,7 +46,7 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
             kw.update(mean=mean, var=var, gamma=g, beta=bt)
         pro = E.make_prologue(**kw)
     ws = torch.empty(1 << 23, dtype=torch.float32, device=dev) if stats else None
-    desc = E.conv_desc(k, 1, pad, L.ACT_NONE, upsample, cout=cout, w_layout=pw.layout)
+    desc = E.conv_desc(k, 1, pad, L.ACT_RELU if e_relu else L.ACT_NONE, upsample, cout=cout, w_layout=pw.layout)
     xv, yv = E.View(x, 0, cin), E.View(y, 0, (cout + 3) // 4 * 4 if (cout + 3) // 4 * 4 <= pitch_out else cout)
     plan = E.Plan()
     with plan.record():
@@ -67,9 +68,52 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
     t = sum(ms) / len(ms) * 1e-3
     byt = n * h * w * cin * 2 + n * ho * up * wo * up * cout * 2
     fl = 2.0 * n * ho * wo * (4 if pool else 1) * cout * cin * k * k
-    return {"kernel": plan.kernel_names()[0], "shape": "%d->%d k%d @%dx%d n%d" % (cin, cout, k, h, w, n),
-            "us": round(t * 1e6, 2), "GB/s": round(byt / t / 1e9, 1), "TFLOP/s": round(fl / t / 1e12, 1),
-            "MB": round(byt / 1e6, 1)}
+    res = {"kernel": plan.kernel_names()[0], "shape": "%d->%d k%d @%dx%d n%d" % (cin, cout, k, h, w, n),
+           "us": round(t * 1e6, 2), "GB/s": round(byt / t / 1e9, 1), "TFLOP/s": round(fl / t / 1e12, 1),
+           "MB": round(byt / 1e6, 1)}
+    if keep_out:
+        res["_y"] = y
+        res["_stats"] = ws[:4096].clone() if ws is not None else None
+    return res
+
+
+# MFMA-bound shapes of the training step (VGG16, Fusion-D, the generator's wide 3x3 convs), batch 16
+MFMA_SHAPES = [
+    dict(k=3, cin=160, cout=128, n=16, h=128, w=128, bias=True, stats=True, pitch_out=512),     # conv_refine4
+    dict(k=3, cin=640, cout=512, n=16, h=32, w=32, bias=True, pitch_out=768),                   # conv_refin6
+    dict(k=3, cin=1024, cout=256, n=16, h=32, w=32, relu=True, pitch_out=768),                  # dense_block4.conv2
+    dict(k=3, cin=512, cout=128, n=16, h=64, w=64, relu=True, pitch_out=512),                   # dense_block5.conv2
+    dict(k=3, cin=64, cout=64, n=16, h=256, w=256, bias=True, e_relu=True),                     # VGG conv1_2
+    dict(k=3, cin=64, cout=128, n=16, h=128, w=128, bias=True, e_relu=True),                    # VGG conv2_1
+    dict(k=3, cin=128, cout=128, n=16, h=128, w=128, bias=True, e_relu=True),                   # VGG conv2_2
+    dict(k=3, cin=128, cout=256, n=16, h=64, w=64, bias=True, e_relu=True),                     # VGG conv3_1
+    dict(k=3, cin=256, cout=256, n=16, h=64, w=64, bias=True, e_relu=True),                     # VGG conv3_2/3
+    dict(k=3, cin=256, cout=512, n=16, h=32, w=32, bias=True, e_relu=True),                     # VGG conv4_1
+    dict(k=3, cin=512, cout=512, n=16, h=32, w=32, bias=True, e_relu=True),                     # VGG conv4_2/3
+    dict(k=3, cin=72, cout=144, n=16, h=128, w=128, bn=True, lrelu=True, stats=True),           # D layer3
+    dict(k=4, cin=144, cout=288, n=16, h=128, w=128, bn=True, lrelu=True),                      # D layer4
+]
+
+
+def ab_suite(shapes, var="FDGAN_DEBUG_WD", variants=("",)):
+    """A/B of a tuning switch (needs a FDGAN_TUNING=1 build): per shape old (switch = 0) vs each variant, outputs compared."""
+    for cfg in shapes:
+        os.environ[var] = "0"
+        r0 = run(keep_out=True, **cfg)
+        y0 = r0.pop("_y").float()
+        cmax = cfg["cout"]
+        row = {"shape": r0["shape"], "old": r0["kernel"], "old_us": r0["us"], "old_TF": r0["TFLOP/s"]}
+        for v in variants:
+            if v:
+                os.environ[var] = v
+            else:
+                del os.environ[var]
+            r1 = run(keep_out=True, **cfg)
+            y1 = r1.pop("_y").float()
+            rel = float((y0[..., :cmax] - y1[..., :cmax]).norm() / (y0[..., :cmax].norm() + 1e-30))
+            row[v or "new"] = "%s %.1fus %.0fTF x%.2f d%.1e" % (r1["kernel"], r1["us"], r1["TFLOP/s"], r0["us"] / r1["us"], rel)
+        os.environ.pop(var, None)
+        print(json.dumps(row), flush=True)
 
 
 SUITES = {
@@ -98,8 +142,12 @@ def main():
     for nm in ("bn", "relu", "stats", "pool", "bias"):
         ap.add_argument("--" + nm, action="store_true")
     ap.add_argument("--layout", type=int, default=None)
+    ap.add_argument("--variants", default="")
     a = ap.parse_args()
     L.load()
+    if a.suite == "mfma_ab":
+        ab_suite([c for c in MFMA_SHAPES if c["k"] == 3], variants=tuple(a.variants.split(",")))
+        return
     if a.suite:
         for cfg in SUITES[a.suite]:
             print(json.dumps(run(**cfg)), flush=True)
