@@ -300,7 +300,9 @@ struct RowStore {
   static constexpr int PITCH = RB + 16;
   static constexpr int BYTES = 16 * PITCH;       // staging bytes per wave
   static constexpr int LPP = RB / 16;            // lanes per pixel on the way out
-  static constexpr int PPI = 64 / LPP;           // pixels per store instruction
+  static constexpr int PPI = 64 / LPP;           // pixels per store instruction (CT = 3: 10, lanes 60..63 idle)
+  static constexpr int NIT = (16 + PPI - 1) / PPI;   // store instructions per 16-pixel tile
+  static constexpr bool POW2 = (LPP & (LPP - 1)) == 0;
 };
 template <int CT, bool ACC = false, typename F>
 __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, const float (&v)[CT][4], int lane,
@@ -319,10 +321,11 @@ __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, cons
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int piece = lane % R::LPP, q0 = lane / R::LPP;
 #pragma unroll
-  for (int i = 0; i < 16 / R::PPI; ++i) {
+  for (int i = 0; i < R::NIT; ++i) {
     const int q = i * R::PPI + q0;
-    u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
-    const long long off = pixoff(q);
+    const bool qok = R::POW2 || (q0 < R::PPI && q < 16);
+    u32x4 row = *reinterpret_cast<const u32x4*>(tb + (qok ? q : 0) * R::PITCH + piece * 16);
+    const long long off = qok ? pixoff(q) : -1;
     if (off >= 0) {
       u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8);
       if constexpr (ACC) {   // y += row (the gradient buffer of the forward input), whole 16-byte pieces of a pixel row
@@ -355,10 +358,11 @@ __device__ __forceinline__ void fd_store_row16_ptr(unsigned short* yrow, int y_s
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int piece = lane % R::LPP, q0 = lane / R::LPP;
 #pragma unroll
-  for (int i = 0; i < 16 / R::PPI; ++i) {
+  for (int i = 0; i < R::NIT; ++i) {
     const int q = i * R::PPI + q0;
-    const u32x4 row = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
-    if (q < npix) *reinterpret_cast<u32x4*>(yrow + (unsigned)(q * y_sw + piece * 8)) = row;
+    const bool qok = R::POW2 || (q0 < R::PPI && q < 16);
+    const u32x4 row = *reinterpret_cast<const u32x4*>(tb + (qok ? q : 0) * R::PITCH + piece * 16);
+    if (qok && q < npix) *reinterpret_cast<u32x4*>(yrow + (unsigned)(q * y_sw + piece * 8)) = row;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -529,47 +533,65 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       const int tile16 = by * C::CTB + wnu * CT + c;
       cofs[c] = (tile16 < a.ntile_total ? tile16 : 0) * 512;
     }
-    const unsigned short* wtile = a.w;
-    const long long wstep = (long long)a.ntile_total * 512;
-    const int nsteps = a.nchunk * C::KK;
-    // fragments are requested TWO taps ahead (an L2 round trip under load is longer than one tap's MFMAs); the
-    // sched_barrier keeps the compiler from sinking the request down to its first use
+    // Tap order is COLUMN-major (dx outer, dy inner): for one dx the PT + KS - 1 input-row fragments are read from LDS
+    // once and serve all KS row taps (output row p at tap dy reads input row p + dy) -- 30 fragment reads per chunk
+    // instead of 72 for a 3x3 on 8 rows.  Filter fragments are requested TWO taps ahead in that order (an L2 round trip
+    // under load is longer than one tap's MFMAs); the sched_barrier keeps the compiler from sinking the request down to
+    // its first use.
+    static_assert(STRIDE == 1 && !POOL, "filter-direct kernels are stride-1, unpooled");
+    const long long wstep = (long long)a.ntile_total * 512;             // elements per (chunk, tap)
+    const unsigned short* wch = a.w + lane * 8;                          // this chunk's taps; the lane's 16 bytes
+    auto wload = [&](u32x4 (&dst)[CT], const unsigned short* base, int e) {   // e: position in execution order
+      const int tap = (e % KS) * KS + (e / KS);                          // e = dx * KS + dy  ->  tap = dy * KS + dx
+#pragma unroll
+      for (int c = 0; c < CT; ++c) dst[c] = *reinterpret_cast<const u32x4*>(base + tap * wstep + cofs[c]);
+    };
     u32x4 wcur[CT], wnx1[CT], wnx2[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) wcur[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
-    wtile += (1 < nsteps) ? wstep : 0;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) wnx1[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
+    wload(wcur, wch, 0);
+    wload(wnx1, wch, 1);
     __syncthreads();
-    int s = 1;
+    // s_setprio around the MFMA blocks: +3..9 % (the co-resident wave's loads / LDS reads yield to the MFMA issue);
+    // VAR bit 0 (tuning): store the next chunk's input tile early instead of before the barrier (mixed: off)
+    constexpr int VAR = (WD >> 1) ^ 2;
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
       const bool has_next = (chunk + 1) < a.nchunk;
       if (has_next) load_in(chunk + 1);
+      const unsigned short* wnext = wch + (has_next ? (long long)C::KK * wstep : 0);   // past the end: re-read (unused)
       const char* xb = xfrag0 + (chunk & 1) * C::IN_BYTES;
 #pragma unroll
-      for (int t = 0; t < C::KK; ++t) {
-        ++s;
-        wtile += (s < nsteps) ? wstep : 0;   // past the end: re-read the last step's fragments
+      for (int dx = 0; dx < KS; ++dx) {
+        bf16x8 xr[PT + KS - 1];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) wnx2[c] = *reinterpret_cast<const u32x4*>(wtile + cofs[c] + lane * 8);
-        __builtin_amdgcn_sched_barrier(0);
-        const int dy = t / KS, dx = t % KS;
-        bf16x8 xf[PT];
+        for (int r = 0; r < PT + KS - 1; ++r) xr[r] = __builtin_bit_cast(bf16x8, lds_read16(xb + (r * C::IW + dx) * 16));
 #pragma unroll
-        for (int p = 0; p < PT; ++p)
-          xf[p] = __builtin_bit_cast(bf16x8, lds_read16(xb + ((p * STRIDE + dy) * C::IW + dx) * 16));
+        for (int dy = 0; dy < KS; ++dy) {
+          const int e = dx * KS + dy;
+          if (e + 2 < C::KK) wload(wnx2, wch, e + 2);
+          else wload(wnx2, wnext, e + 2 - C::KK);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int p = 0; p < PT; ++p)
+          for (int p = 0; p < PT; ++p)
 #pragma unroll
-          for (int c = 0; c < CT; ++c)
-            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[c]), xf[p], acc[p][c], 0, 0, 0);
+            for (int c = 0; c < CT; ++c)
+              acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[c]), xr[p + dy], acc[p][c], 0, 0, 0);
+          if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          wcur[c] = wnx1[c];
-          wnx1[c] = wnx2[c];
+          for (int c = 0; c < CT; ++c) {
+            wcur[c] = wnx1[c];
+            wnx1[c] = wnx2[c];
+          }
+        }
+        // the other input buffer is free for the whole chunk (every wave left it at the previous barrier): fill it while
+        // the MFMA pipe is busy with the remaining taps instead of in the bubble before the barrier
+        if constexpr (VAR & 1) {
+          if (dx == KS - 2 && has_next) store_in(in_lds + ((chunk + 1) & 1) * C::IN_BYTES, chunk + 1);
         }
       }
-      if (has_next) store_in(in_lds + ((chunk + 1) & 1) * C::IN_BYTES, chunk + 1);
+      wch = wnext;
+      if constexpr (!(VAR & 1)) {
+        if (has_next) store_in(in_lds + ((chunk + 1) & 1) * C::IN_BYTES, chunk + 1);
+      }
       __syncthreads();
     }
   } else {
@@ -686,14 +708,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
         *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + kgl * 8) = bits;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      u32x4 dav[16 / R::PPI], xv[16 / R::PPI], gv[16 / R::PPI];
-      long long offs[16 / R::PPI];
+      u32x4 dav[R::NIT], xv[R::NIT], gv[R::NIT];
+      long long offs[R::NIT];
 #pragma unroll
-      for (int i = 0; i < 16 / R::PPI; ++i) {
+      for (int i = 0; i < R::NIT; ++i) {
         const int q = i * R::PPI + q0;
-        const bool ok = ch_ok && row < a.Ho && ox0 + q < a.Wo;
+        const bool qok = R::POW2 || (q0 < R::PPI && q < 16);
+        const bool ok = qok && ch_ok && row < a.Ho && ox0 + q < a.Wo;
         offs[i] = ok ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw + cg : -1;
-        dav[i] = *reinterpret_cast<const u32x4*>(tb + q * R::PITCH + piece * 16);
+        dav[i] = *reinterpret_cast<const u32x4*>(tb + (qok ? q : 0) * R::PITCH + piece * 16);
         xv[i] = gv[i] = u32x4{0u, 0u, 0u, 0u};
         if (ok) {
           xv[i] = *reinterpret_cast<const u32x4*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)(ox0 + q) * a.mk_sw + cg);
@@ -701,7 +724,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
         }
       }
 #pragma unroll
-      for (int i = 0; i < 16 / R::PPI; ++i) {
+      for (int i = 0; i < R::NIT; ++i) {
         if (offs[i] < 0) continue;
         const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dav[i]), f32x8);
         const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
@@ -719,21 +742,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (a.stats != nullptr) {   // lanes LPP apart own the same channels
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int dlt = R::LPP; dlt < 64; dlt <<= 1) {
-          s1[e] += __shfl_xor(s1[e], dlt, 64);
-          s2[e] += __shfl_xor(s2[e], dlt, 64);
-        }
-      }
-      if (q0 == 0)
+      if constexpr (R::POW2) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int idx = (wave * CT * 16 + piece * 8 + e) * 2;
-          red[idx] = s1[e];
-          red[idx + 1] = s2[e];
+#pragma unroll
+          for (int dlt = R::LPP; dlt < 64; dlt <<= 1) {
+            s1[e] += __shfl_xor(s1[e], dlt, 64);
+            s2[e] += __shfl_xor(s2[e], dlt, 64);
+          }
         }
+        if (q0 == 0)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int idx = (wave * CT * 16 + piece * 8 + e) * 2;
+            red[idx] = s1[e];
+            red[idx + 1] = s2[e];
+          }
+      } else {   // 6 lanes per pixel: the PPI lanes of a channel group are not a butterfly; wave-private LDS adds, once per kernel
+        for (int i = lane; i < CT * 16 * 2; i += 64) red[wave * CT * 16 * 2 + i] = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (q0 < R::PPI)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int idx = (wave * CT * 16 + piece * 8 + e) * 2;
+            atomicAdd(&red[idx], s1[e]);
+            atomicAdd(&red[idx + 1], s2[e]);
+          }
+      }
     }
   } else {
 #pragma unroll

@@ -12,18 +12,26 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
     return conv_dispatch_k3_rs(a, nimg, cout_total, info, stats_cap, dry, stream);
   if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_PW") == nullptr)
     return conv_dispatch_k3_pw(a, nimg, cout_total, info, stats_cap, dry, stream);
-  // MFMA-bound shapes (VGG16, D, the refine convs, the dy blocks' 3x3): filter-direct kernels (conv_igemm.h, WD = 1).
+  // MFMA-bound shapes (VGG16, D, the refine convs, the dy blocks' 3x3) and their data gradients: filter-direct kernels
+  // (conv_igemm.h, WD = 1), 8 x 16 output pixels per wave, 2-3 workgroups per CU:
+  //   wdA: 128 output channels per workgroup (4 waves x 32), wdG: 64 (2 x 2 waves, 16 x 16 pixels),
+  //   wdH: 144 (3 waves x 48): D's 72 -> 144 -> 288 widths without padding waste.
   {
-    const char* sel = FD_TUNE_GETENV("FDGAN_DEBUG_WD");   // tuning aid: 0 forces the LDS-staged-filter kernels, A..D a variant
-    const char v = sel ? sel[0] : 'x';
-    if (v != '0' && !narrow && a.Cin >= 64 && a.mk_mode == 0) {
-      if (v == 'A') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 1, 4, 9, 0, 1, "conv3x3_wdA");
-      if (v == 'B') FD_CONV_DISPATCH_W(3, 1, 0, 8, 4, 2, 2, 9, 0, 1, "conv3x3_wdB");
-      if (v == 'C') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 4, 9, 0, 1, "conv3x3_wdC");
-      if (v == 'D') FD_CONV_DISPATCH_W(3, 1, 0, 4, 8, 4, 1, 9, 0, 1, "conv3x3_wdD");
-      if (v == 'E') FD_CONV_DISPATCH_W(3, 1, 0, 16, 2, 1, 4, 9, 0, 1, "conv3x3_wdE");
-      if (v == 'G') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 2, 9, 0, 1, "conv3x3_wdG");
-      if (v == 'H') FD_CONV_DISPATCH_W(3, 1, 0, 8, 3, 1, 3, 9, 0, 1, "conv3x3_wdH");
+    const char* sel = FD_TUNE_GETENV("FDGAN_DEBUG_WD");   // tuning aid: 0 forces the LDS-staged-filter kernels, A/G/H a variant
+    char v = sel ? sel[0] : 'x';
+    if (v != '0' && !narrow && a.Cin >= 32) {
+      if (v == 'x') {
+        const int waste128 = (cout_total + 127) / 128 * 128 - cout_total, waste144 = (cout_total + 143) / 144 * 144 - cout_total;
+        v = cout_total <= 64 ? 'G' : (waste144 < waste128 ? 'H' : 'A');
+      }
+      if (a.mk_mode != 0) {
+        if (v == 'G') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 2, 9, 1, 1, "conv3x3_wd64_bwd");
+        if (v == 'H') FD_CONV_DISPATCH_W(3, 1, 0, 8, 3, 1, 3, 9, 1, 1, "conv3x3_wd144_bwd");
+        FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 1, 4, 9, 1, 1, "conv3x3_wd128_bwd");
+      }
+      if (v == 'G') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 2, 9, 0, 1, "conv3x3_wd64");
+      if (v == 'H') FD_CONV_DISPATCH_W(3, 1, 0, 8, 3, 1, 3, 9, 0, 1, "conv3x3_wd144");
+      FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 1, 4, 9, 0, 1, "conv3x3_wd128");
     }
   }
   const bool mid = cout_total <= 64;   // 64 output channels per workgroup: the 128-wide tile would idle half its MFMAs (VGG16 conv1_2: 197 us)

@@ -5,6 +5,24 @@ int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bo
                      long long stats_cap, bool dry, hipStream_t stream) {
   const bool narrow = cout_total <= 32, mid = cout_total <= 64;   // 32 / 64 / 128 output channels per workgroup
   if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
+  if (stride == 1) {   // filter-direct kernels (conv_k3.hip): D's 144 -> 288 @127x127 and its data gradient
+    const char* sel = FD_TUNE_GETENV("FDGAN_DEBUG_WD");
+    char v = sel ? sel[0] : 'x';
+    if (v != '0' && !narrow && a.Cin >= 32) {
+      if (v == 'x') {
+        const int waste128 = (cout_total + 127) / 128 * 128 - cout_total, waste144 = (cout_total + 143) / 144 * 144 - cout_total;
+        v = cout_total <= 64 ? 'G' : (waste144 < waste128 ? 'H' : 'A');
+      }
+      if (a.mk_mode != 0) {
+        if (v == 'G') FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 2, 2, 16, 1, 1, "conv4x4_wd64_bwd");
+        if (v == 'H') FD_CONV_DISPATCH_W(4, 1, 0, 8, 3, 1, 3, 16, 1, 1, "conv4x4_wd144_bwd");
+        FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 1, 4, 16, 1, 1, "conv4x4_wd128_bwd");
+      }
+      if (v == 'G') FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 2, 2, 16, 0, 1, "conv4x4_wd64");
+      if (v == 'H') FD_CONV_DISPATCH_W(4, 1, 0, 8, 3, 1, 3, 16, 0, 1, "conv4x4_wd144");
+      FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 1, 4, 16, 0, 1, "conv4x4_wd128");
+    }
+  }
   if (stride == 1 && a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
     if (narrow) FD_CONV_DISPATCH_X(4, 1, 0, 4, 2, 4, 1, 4, 1, "conv4x4_bn32_bwd");
     if (mid) FD_CONV_DISPATCH_X(4, 1, 0, 4, 4, 4, 1, 1, 1, "conv4x4_bn64_bwd");

@@ -87,6 +87,75 @@ extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksi
   return fd_launch(&pack_weight_kernel, "pack_weight", dim3(nb), dim3(256), 0, a, static_cast<hipStream_t>(stream));
 }
 
+// Batched form: every filter of a network (both orientations) in ONE launch.  The job table lives in device memory; a unit
+// (16 bytes of packed output) finds its job by bisection over the jobs' first units.
+struct PackJobsArgs {
+  const FdPackJob* jobs;
+  int njobs;
+  long long nunits;
+};
+
+__global__ void pack_weights_kernel(PackJobsArgs b) {
+  const long long gu = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gu >= b.nunits) return;
+  int lo = 0, hi = b.njobs - 1;
+  while (lo < hi) {   // last job with first_unit <= gu
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.jobs[mid].first_unit <= gu) lo = mid;
+    else hi = mid - 1;
+  }
+  const FdPackJob j = b.jobs[lo];
+  const long long u = gu - j.first_unit;
+  const int kk = j.ksize * j.ksize, ntile = (j.cout + 15) / 16;
+  const int lane = (int)(u & 63);
+  long long r = u >> 6;
+  const int tile = (int)(r % ntile);
+  r /= ntile;
+  const int co = tile * 16 + (lane & 15);
+  int tap, ci0;
+  if (j.layout == FD_WLAYOUT_X64) {
+    tap = 0;
+    ci0 = (int)(r >> 1) * 64 + (lane >> 4) * 16 + (int)(r & 1) * 8;
+  } else {
+    tap = (int)(r % kk);
+    ci0 = (int)(r / kk) * 32 + (lane >> 4) * 8;
+  }
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ci0 + e;
+    float x = 0.f;
+    if (co < j.cout && ci < j.cin) {
+      int o = co, i = ci, t = tap;
+      if (j.flip) {
+        o = ci;
+        i = co;
+        t = kk - 1 - tap;
+      }
+      const int d0 = j.flip ? j.cin : j.cout, d1 = j.flip ? j.cout : j.cin;
+      const long long idx = j.transposed ? ((long long)i * d0 + o) * kk + t : ((long long)o * d1 + i) * kk + t;
+      x = j.w[idx];
+    }
+    v[e] = x;
+  }
+  *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(j.packed) + u * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+}
+
+extern "C" int64_t fdgan_pack_units(int cout, int cin, int ksize, int layout) {
+  if (cout <= 0 || cin <= 0 || ksize <= 0) return 0;
+  const long long ntile = (cout + 15) / 16;
+  return layout == FD_WLAYOUT_X64 ? (long long)((cin + 63) / 64) * 2 * ntile * 64
+                                  : (long long)((cin + 31) / 32) * ksize * ksize * ntile * 64;
+}
+
+extern "C" int fdgan_pack_conv_weights(const FdPackJob* jobs_device, int64_t njobs, int64_t total_units, FdStream stream) {
+  FD_REQUIRE(jobs_device && njobs > 0 && njobs < (1 << 20) && total_units > 0, "pack_conv_weights: empty job table");
+  FD_REQUIRE(total_units < (1ll << 31) * 256, "pack_conv_weights: too many units");
+  PackJobsArgs b{jobs_device, (int)njobs, (long long)total_units};
+  const unsigned nb = (unsigned)((total_units + 255) / 256);
+  return fd_launch(&pack_weights_kernel, "pack_weights", dim3(nb), dim3(256), 0, b, static_cast<hipStream_t>(stream));
+}
+
 // ---------------------------------------------------------------------------------
 // BatchNorm statistics: partial[rows][cpad][2] -> mean, biased var
 // (nn.BatchNorm2d train mode).  One workgroup per 32 channels;

@@ -255,11 +255,7 @@ class PlanBackward:
             return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
         hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
         # the forward filter tensor in OIHW terms: ConvTranspose2d stores (cin, cout): already the transposed one
-        if w.transposed:
-            pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=False, layout=L.WLAYOUT_CHUNK32)
-        else:
-            pw = E.PackedWeight(p.detach(), cin, w.cout, k, transposed=False, flip=True, layout=L.WLAYOUT_CHUNK32)
-        pw.pack()
+        pw = self.plan.flipped_weight(w)      # packed with the forward images, once per parameter update
         ddesc = E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32)
         fusable = not meta["pool"] and x.c0 % 8 == 0 and self.fuse_mask
         bn = meta.get("bn")

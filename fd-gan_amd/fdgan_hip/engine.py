@@ -86,6 +86,32 @@ class PackedWeight:
                 "pack_conv_weight")
 
 
+class PackTable:
+    """Every PackedWeight of a network packed by ONE launch (fdgan_pack_conv_weights): the job table is uploaded once
+    and stays valid while the parameters and the packed buffers keep their addresses."""
+
+    def __init__(self, weights):
+        lib = L.load()
+        self.weights = list(weights)
+        jobs = (L.FdPackJob * len(self.weights))()
+        first = 0
+        for j, w in zip(jobs, self.weights):
+            p = w.param.detach()
+            assert p.dtype == torch.float32 and p.is_contiguous()
+            j.w, j.packed = p.data_ptr(), w.buf.data_ptr()
+            j.cout, j.cin, j.ksize, j.transposed, j.flip, j.layout = w.cout, w.cin, w.k, w.transposed, w.flip, w.layout
+            j.first_unit = first
+            first += lib.fdgan_pack_units(w.cout, w.cin, w.k, w.layout)
+        self.total_units = first
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        self.table = raw.to(self.weights[0].param.device)
+        self.ptrs = tuple(w.param.data_ptr() for w in self.weights)
+
+    def launch(self):
+        L.check(L.load().fdgan_pack_conv_weights(self.table.data_ptr(), len(self.weights), self.total_units, stream_ptr()),
+                "pack_conv_weights")
+
+
 def make_prologue(act=L.ACT_NONE, pool=False, mean=None, var=None, gamma=None, beta=None, eps=1e-5,
                   momentum=0.1, running_mean=None, running_var=None, nbt=None, count=0):
     p = L.FdPrologue()

@@ -34,6 +34,11 @@ class FdPrologue(C.Structure):
                 ("count", C.c_int64)]
 
 
+class FdPackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
+                ("transposed", C.c_int32), ("flip", C.c_int32), ("layout", C.c_int32), ("first_unit", C.c_int64)]
+
+
 class FdConvDesc(C.Structure):
     _fields_ = [("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("epilogue_act", C.c_int32),
                 ("upsample2", C.c_int32), ("cout", C.c_int32), ("w_layout", C.c_int32)]
@@ -58,6 +63,8 @@ SIGNATURES = {
     "fdgan_conv_weight_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fdgan_pack_units": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fdgan_pack_conv_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_conv2d_fwd_info": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_int, C.POINTER(FdConvDesc),
                                         C.POINTER(FdPrologue), C.POINTER(FdConvInfo)]),
     "fdgan_conv2d_fwd": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdPrologue),

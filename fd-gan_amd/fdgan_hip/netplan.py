@@ -29,7 +29,9 @@ class ChanStats:
 class NetPlan:
     def __init__(self, device):
         self.device = device
-        self.weights = []          # PackedWeight, refreshed by pack_plan
+        self.weights = []          # PackedWeight, refreshed by ONE batched pack launch per parameter update
+        self.flipped = {}          # id(forward PackedWeight) -> its data-gradient twin (created by the first backward)
+        self._table = None
         self._ops = []             # (closure, stats_floats)
         self.ws = None             # stats partial workspace
         self.main = None
@@ -131,10 +133,6 @@ class NetPlan:
     def finish(self):
         need = max([o[1] for o in self._ops] + [2])
         self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        self.packp = E.Plan()
-        with self.packp.record():
-            for w in self.weights:
-                w.pack()
         self.main = E.Plan()
         self.meta = []             # one entry per op: launch index range + algorithmic work
         with self.main.record():
@@ -150,10 +148,26 @@ class NetPlan:
     def _versions(self):
         return tuple(w.param._version for w in self.weights)
 
+    def flipped_weight(self, w):
+        """The packed filter image the DATA gradient of conv `w` runs on: flipped taps, in/out channels swapped (a
+        ConvTranspose2d 1x1 stores (cin, cout) already).  Created on first use, packed with the forward images from then
+        on -- once per parameter update, in the same launch."""
+        t = self.flipped.get(id(w))
+        if t is None:
+            p = w.param.detach()
+            t = E.PackedWeight(p, w.cin, w.cout, w.k, transposed=False, flip=not w.transposed, layout=L.WLAYOUT_CHUNK32)
+            t.pack()
+            self.flipped[id(w)] = t
+            self.keep.append(t)
+            self._table = None
+        return t
+
     def refresh_weights(self, force=False):
         v = self._versions()
         if force or v != self._param_versions:
-            self.packp.launch()
+            if self._table is None:
+                self._table = E.PackTable(self.weights + list(self.flipped.values()))
+            self._table.launch()
             self._param_versions = v
 
     def launch(self):

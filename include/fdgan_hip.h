@@ -152,6 +152,20 @@ size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize);
 int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
                            int layout, void* packed, size_t packed_bytes, FdStream stream);
 
+/* Batched form for a whole network: `jobs` is a table in DEVICE memory (it is read by the kernel), one entry per packed
+ * image -- e.g. every filter of a generator in both orientations -- and the launch packs all of them at once (one
+ * launch per optimizer step instead of one per filter and orientation).  first_unit = running sum of
+ * fdgan_pack_units(cout, cin, ksize, layout) over the preceding jobs; total_units = that sum over all jobs.  Same
+ * semantics per job as fdgan_pack_conv_weight. */
+typedef struct FdPackJob {
+  const float* w;
+  void* packed;
+  int32_t cout, cin, ksize, transposed, flip, layout;
+  int64_t first_unit;
+} FdPackJob;
+int64_t fdgan_pack_units(int cout, int cin, int ksize, int layout);
+int fdgan_pack_conv_weights(const FdPackJob* jobs_device, int64_t njobs, int64_t total_units, FdStream stream);
+
 /* ---- convolution ---------------------------------------------------------- */
 /* Replaces nn.Conv2d / nn.ConvTranspose2d(1x1) forward and the BN/ReLU/pool/cat/
  * upsample/tanh/sigmoid modules fused around it:

@@ -90,29 +90,40 @@ MFMA_SHAPES = [
     dict(k=3, cin=256, cout=256, n=16, h=64, w=64, bias=True, e_relu=True),                     # VGG conv3_2/3
     dict(k=3, cin=256, cout=512, n=16, h=32, w=32, bias=True, e_relu=True),                     # VGG conv4_1
     dict(k=3, cin=512, cout=512, n=16, h=32, w=32, bias=True, e_relu=True),                     # VGG conv4_2/3
+    dict(k=3, cin=36, cout=72, n=16, h=128, w=128, lrelu=True, stats=True, pitch_in=40),         # D layer2
     dict(k=3, cin=72, cout=144, n=16, h=128, w=128, bn=True, lrelu=True, stats=True),           # D layer3
     dict(k=4, cin=144, cout=288, n=16, h=128, w=128, bn=True, lrelu=True),                      # D layer4
 ]
 
 
-def ab_suite(shapes, var="FDGAN_DEBUG_WD", variants=("",)):
-    """A/B of a tuning switch (needs a FDGAN_TUNING=1 build): per shape old (switch = 0) vs each variant, outputs compared."""
+def ab_suite(shapes, var="FDGAN_DEBUG_WD", variants=("",), rounds=3):
+    """A/B of a tuning switch (needs a FDGAN_TUNING=1 build): per shape old (switch = 0) vs each variant, interleaved
+    over `rounds` rounds (the clock state drifts by several % between back-to-back measurements: best-of and median are
+    reported), outputs compared."""
+    import statistics
     for cfg in shapes:
-        os.environ[var] = "0"
-        r0 = run(keep_out=True, **cfg)
-        y0 = r0.pop("_y").float()
-        cmax = cfg["cout"]
-        row = {"shape": r0["shape"], "old": r0["kernel"], "old_us": r0["us"], "old_TF": r0["TFLOP/s"]}
-        for v in variants:
-            if v:
-                os.environ[var] = v
-            else:
-                del os.environ[var]
-            r1 = run(keep_out=True, **cfg)
-            y1 = r1.pop("_y").float()
-            rel = float((y0[..., :cmax] - y1[..., :cmax]).norm() / (y0[..., :cmax].norm() + 1e-30))
-            row[v or "new"] = "%s %.1fus %.0fTF x%.2f d%.1e" % (r1["kernel"], r1["us"], r1["TFLOP/s"], r0["us"] / r1["us"], rel)
+        names, times, outs = {}, {}, {}
+        order = ["0"] + list(variants)
+        for r in range(rounds):
+            for v in order:
+                if v:
+                    os.environ[var] = v
+                else:
+                    os.environ.pop(var, None)
+                res = run(keep_out=(r == 0), **cfg)
+                if r == 0:
+                    outs[v] = res.pop("_y").float()[..., :cfg["cout"]]
+                    res.pop("_stats", None)
+                    names[v] = res["kernel"]
+                times.setdefault(v, []).append(res["us"])
+                flop_us = res["TFLOP/s"] * res["us"]
         os.environ.pop(var, None)
+        row = {"shape": res["shape"]}
+        for v in order:
+            best, med = min(times[v]), statistics.median(times[v])
+            rel = float((outs["0"] - outs[v]).norm() / (outs["0"].norm() + 1e-30))
+            row[v or "new"] = "%s best %.1fus %.0fTF med %.1fus x%.2f d%.0e" % (names[v], best, flop_us / best, med,
+                                                                               min(times["0"]) / best, rel)
         print(json.dumps(row), flush=True)
 
 
@@ -146,7 +157,7 @@ def main():
     a = ap.parse_args()
     L.load()
     if a.suite == "mfma_ab":
-        ab_suite([c for c in MFMA_SHAPES if c["k"] == 3], variants=tuple(a.variants.split(",")))
+        ab_suite(MFMA_SHAPES, variants=tuple(a.variants.split(",")))
         return
     if a.suite:
         for cfg in SUITES[a.suite]:
