@@ -93,6 +93,13 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_ssim_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_float, C.c_void_p, C.c_void_p]),
+    "fdgan_loss_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_sum_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
+    "fdgan_mse_nhwc_fwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_float, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_mse_nhwc_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p, C.c_float, C.POINTER(FdTensor),
+                                     C.c_void_p]),
     "fdgan_maxpool2_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_maxpool2_bwd_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_blur15_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,

@@ -10,22 +10,24 @@ import torch
 
 
 def create_exp_dir(exp):
-    try:
-        os.makedirs(exp)
+    """misc.py:7-13: make the experiment directory if it is not there yet; always True."""
+    if not os.path.isdir(exp):
+        os.makedirs(exp, exist_ok=True)
         print('Creating exp dir: %s' % exp)
-    except OSError:
-        pass
     return True
 
 
 def weights_init(m):
-    """misc.py:16-22: class-name substring dispatch ('Conv' also matches ConvTranspose2d)."""
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1:
-        m.weight.data.normal_(0.0, 0.02)
-    elif classname.find('BatchNorm') != -1:
-        m.weight.data.normal_(1.0, 0.02)
-        m.bias.data.fill_(0)
+    """misc.py:16-22 semantics: dispatch on a substring of the class name -- 'Conv' (which also
+    matches ConvTranspose2d) draws weight ~ N(0, 0.02) and leaves the bias alone; 'BatchNorm' draws weight ~ N(1, 0.02)
+    and zeroes the bias.  For `net.apply(weights_init)`."""
+    kind = type(m).__name__
+    with torch.no_grad():
+        if 'Conv' in kind:
+            torch.nn.init.normal_(m.weight, mean=0.0, std=0.02)
+        elif 'BatchNorm' in kind:
+            torch.nn.init.normal_(m.weight, mean=1.0, std=0.02)
+            torch.nn.init.zeros_(m.bias)
 
 
 def getLoader(datasetName, dataroot, originalSize, imageSize, batchSize=64, workers=4,
@@ -43,43 +45,54 @@ def getLoader(datasetName, dataroot, originalSize, imageSize, batchSize=64, work
 
 
 class AverageMeter(object):
-    """misc.py:121-136."""
+    """misc.py:121-136 interface: `val` (last value), `sum`, `count`, `avg` (count-weighted running mean), `reset()`,
+    `update(val, n=1)`."""
 
     def __init__(self):
-        self.reset()
+        self.val, self.sum, self.count = 0, 0, 0
 
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
+    reset = __init__
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
 
 
 class ImagePool:
-    """misc.py:140-161: history of generated images (pix2pix); uses numpy's global RNG like the reference."""
+    """misc.py:140-161 semantics (the pix2pix history buffer): the first `pool_size` queries are stored and returned
+    as they are; afterwards a fair coin decides between returning the new image untouched and swapping it with a
+    uniformly chosen stored one, which is returned instead.  `pool_size == 0` disables the pool.
 
-    def __init__(self, pool_size=50):
+    Here the history is ONE preallocated tensor on the images' device (slot copies instead of a python list of clones)
+    and the draws come from an explicit numpy Generator: pass `seed`, or let it be drawn from numpy's global RNG so that
+    `np.random.seed()` (which `datasets.pix2pix(seed=...)` calls) still makes a run reproducible."""
+
+    def __init__(self, pool_size=50, seed=None):
         self.pool_size = pool_size
-        if pool_size > 0:
-            self.num_imgs = 0
-            self.images = []
+        self.num_imgs = 0
+        self.store = None
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self.rng = np.random.default_rng(seed)
 
     def query(self, image):
         if self.pool_size == 0:
             return image
         if self.num_imgs < self.pool_size:
-            self.images.append(image.clone())
+            if self.store is None:
+                self.store = torch.empty((self.pool_size,) + tuple(image.shape), dtype=image.dtype, device=image.device)
+            self.store[self.num_imgs].copy_(image)
             self.num_imgs += 1
             return image
-        if np.random.uniform(0, 1) > 0.5:
-            random_id = np.random.randint(self.pool_size, size=1)[0]
-            tmp = self.images[random_id].clone()
-            self.images[random_id] = image.clone()
-            return tmp
-        return image
+        if self.rng.random() <= 0.5:
+            return image
+        slot = int(self.rng.integers(self.pool_size))
+        old = self.store[slot].clone()
+        self.store[slot].copy_(image)
+        return old
 
 
 def adjust_learning_rate(optimizer, init_lr, epoch, factor, every):

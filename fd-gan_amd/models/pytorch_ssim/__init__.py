@@ -34,8 +34,8 @@ class _SsimFn(torch.autograd.Function):
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
         L.check(L.load().fdgan_ssim_bwd(x.data_ptr(), y.data_ptr(), da.data_ptr(), db.data_ptr(), dc.data_ptr(), n * c, h, w,
-                                        C.c_float(float(g) / (n * c * h * w)), dx.data_ptr(), E.stream_ptr()), "ssim_bwd")
-        return dx, None
+                                        C.c_float(1.0 / (n * c * h * w)), dx.data_ptr(), E.stream_ptr()), "ssim_bwd")
+        return dx.mul_(g), None       # the upstream scalar stays on the device: no host sync inside backward()
 
 
 def ssim(img1, img2, window_size=11, size_average=True):

@@ -30,12 +30,12 @@ class Vgg16(torch.nn.Module):
         self.__dict__.pop("_plans", None)
         return super()._apply(fn, *a, **k)
 
-    def _plan_for(self, X):
+    def _plan_for(self, X, slot=0):
         E.require_gpu(X, "Vgg16.forward")
         if X.dim() != 4 or X.shape[1] != 3:
             raise ValueError("Vgg16 expects a Bx3xHxW tensor, got %s" % (tuple(X.shape),))
         cache = self.__dict__.setdefault("_plans", {})
-        key = (tuple(X.shape), X.device.index)
+        key = (tuple(X.shape), X.device.index, slot)
         P = cache.get(key)
         if P is not None and P.param_ptrs() != P._built_ptrs:
             P = None
@@ -53,6 +53,7 @@ class Vgg16(torch.nn.Module):
         P.xin = E.new_act(n, h, w, 8, dev, zero=True)
         cur, cur_c = P.xin, 3
         P.taps = []
+        P._gen = 0                 # bumped by every run: a backward checks that its activations are still the ones it saw
         for item in _CFG:
             if item == "tap":
                 P.taps.append(E.View(cur, 0, cur_c))
@@ -70,11 +71,25 @@ class Vgg16(torch.nn.Module):
                 cur, cur_c = nxt, cout
         return P.finish()
 
-    def _run(self, X):
-        P = self._plan_for(X)
+    def run_nhwc(self, X, slot=0):
+        """Runs the plan of `slot` on X and returns it: the four feature maps are the NHWC bf16 views `plan.taps`, valid
+        until the same slot runs again (fdgan_hip.losses.vgg_perceptual keeps inputs and targets in two slots)."""
+        P = self._plan_for(X, slot)
         with torch.no_grad():
             E.to_nhwc(X.detach().float().contiguous(), E.View(P.xin))
             P.launch()
+        P._gen += 1
+        return P
+
+    def plan_backward(self, P):
+        from fdgan_hip.backward import PlanBackward
+        if getattr(P, "_bwd", None) is None:
+            P._bwd = PlanBackward(P)
+        return P._bwd
+
+    def _run(self, X):
+        P = self.run_nhwc(X)
+        with torch.no_grad():
             outs = []
             for v in P.taps:
                 nn_, hh, ww, cc = v.shape
@@ -92,10 +107,7 @@ class Vgg16(torch.nn.Module):
     def _backward(self, P, douts, need_dx):
         """Perceptual-loss path: gradients of the four tapped feature maps back to the input image (and to the
         filters, if they are not frozen)."""
-        from fdgan_hip.backward import PlanBackward
-        if getattr(P, "_bwd", None) is None:
-            P._bwd = PlanBackward(P)
-        B = P._bwd
+        B = self.plan_backward(P)
         B.zero_()
         for v, d in zip(P.taps, douts):
             if d is not None:
@@ -113,10 +125,14 @@ class _VggFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, X, *params):
         P, outs = module._run(X)
-        ctx.module, ctx.plan, ctx.params, ctx.need_dx = module, P, params, X.requires_grad
+        ctx.module, ctx.plan, ctx.params, ctx.need_dx, ctx.gen = module, P, params, X.requires_grad, P._gen
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
+        if ctx.plan._gen != ctx.gen:       # another forward of the same shape overwrote the activations this backward reads
+            raise RuntimeError("Vgg16: the module ran again on an input of the same shape between this forward and its "
+                               "backward; the plan's activations were overwritten.  Compute targets first (under "
+                               "torch.no_grad()), or use fdgan_hip.losses.vgg_perceptual, which keeps them apart.")
         dx, grads = ctx.module._backward(ctx.plan, douts, ctx.need_dx)
         return (None, dx) + autograd_grads(grads, ctx.params)

@@ -10,9 +10,10 @@ those pieces -- the loss weights are not recoverable from the reference:
     G step:  L1(fake, gt) + (1 - SSIM(fake, gt)) + sum_k MSE(VGG_k(fake), VGG_k(gt)) + w_adv * BCE(D(F(fake)), 1)  -> Adam(G)
     F(img) = cat[img, Blur15(img), Laplacian3(img)]
 
-Every network forward / backward, the frequency split and SSIM run through libfdgan_hip.so; the scalar loss
-reductions (L1, MSE, BCE on already-computed tensors) are torch elementwise ops for now; Adam is one HIP kernel over
-a flat fp32 parameter buffer (fdgan_hip/optim.py), whose flat gradient is also what RCCL all-reduces.
+Every network forward / backward, the frequency split, SSIM and the scalar losses (L1, BCE, the perceptual MSE on
+Vgg16's NHWC bf16 feature maps: fdgan_hip/losses.py) run through libfdgan_hip.so; Adam is one HIP kernel over a flat
+fp32 parameter buffer (fdgan_hip/optim.py), whose flat gradient is also what RCCL all-reduces.  Nothing in a step
+synchronises with the host until its six loss values are read, once, at the end.
 Activations live in the modules' plan buffers, so each module's backward runs before its next forward (two
 backward calls for the two halves of the D loss).
 """
@@ -20,12 +21,12 @@ import argparse
 import time
 
 import torch
-import torch.nn.functional as F
 
 import misc
 import models.dehaze1113 as net
 import models.pytorch_ssim as pytorch_ssim
 from fdgan_hip.dp import DpContext
+from fdgan_hip.losses import bce_loss, l1_loss, vgg_perceptual
 from fdgan_hip.optim import FlatAdam
 from loss import fusion_input
 from myutils.vgg16 import Vgg16
@@ -51,6 +52,24 @@ class TrainStep:
         self.pool = misc.ImagePool(pool_size)
         self.w = dict(adv=w_adv, perc=w_perc, ssim=w_ssim, l1=w_l1)
         self.dp = dp
+        if dp is not None and dp.world > 1:
+            self.sync_replicas()
+
+    def sync_replicas(self):
+        """Data-parallel replicas must START identical: only gradients are exchanged afterwards.  Rank 0's parameters
+        (the optimizers' flat buffers) and BatchNorm buffers are broadcast, then every rank checks a checksum."""
+        import torch.distributed as dist
+        bufs = [self.optG.flat, self.optD.flat]
+        bufs += [b for m in (self.netG, self.netD) for b in m.buffers() if b.dtype.is_floating_point]
+        bufs += [p.data for p in self.netG.parameters() if not any(p is q for q in self.optG.params)]   # never-trained tensors
+        for b in bufs:
+            dist.broadcast(b, src=0)
+        chk = torch.stack([b.double().sum() for b in bufs[:2]])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("data-parallel replicas differ after the initial broadcast")
 
     @staticmethod
     def _params_with_grad(module, device):
@@ -70,8 +89,7 @@ class TrainStep:
             p.requires_grad_(flag)
 
     def step(self, haze, gt):
-        """haze, gt: (B,3,H,W) float in [0,1] on the device.  Returns a dict of python floats."""
-        out = {}
+        """haze, gt: (B,3,H,W) float in [0,1] on the device.  Returns a dict of python floats (ONE host sync, at the end)."""
         fake = self.netG(haze)                                                     # autograd graph of the generator
         # ---- D step: two backward calls (D's activations live in its plan buffers)
         self._set_d_grad(True)
@@ -79,32 +97,25 @@ class TrainStep:
         with torch.no_grad():
             real_in = fusion_input(gt)
             fake_in = fusion_input(self.pool.query(fake.detach()))
-        p_real = self.netD(real_in)
-        l_real = F.binary_cross_entropy(p_real, torch.ones_like(p_real))
+        l_real = bce_loss(self.netD(real_in), 1.0)
         l_real.backward()
-        p_fake = self.netD(fake_in)
-        l_fake = F.binary_cross_entropy(p_fake, torch.zeros_like(p_fake))
+        l_fake = bce_loss(self.netD(fake_in), 0.0)
         l_fake.backward()
         self.optD.allreduce_grads(self.dp)
         self.optD.step()
-        out["lossD"] = float((l_real + l_fake).detach())
         # ---- G step
         self._set_d_grad(False)                                                    # D is a fixed critic here: no dW work
         self.optG.zero_grad()
-        with torch.no_grad():
-            feats_gt = self.vgg(gt)
-        feats = self.vgg(fake)
-        l_perc = sum(F.mse_loss(a, b) for a, b in zip(feats, feats_gt))
-        l_ssim = 1.0 - pytorch_ssim.ssim(fake, gt)
-        l_l1 = (fake - gt).abs().mean()
-        p_adv = self.netD(fusion_input(fake))
-        l_adv = F.binary_cross_entropy(p_adv, torch.ones_like(p_adv))
-        lossG = self.w["l1"] * l_l1 + self.w["ssim"] * l_ssim + self.w["perc"] * l_perc + self.w["adv"] * l_adv
+        l_perc = vgg_perceptual(self.vgg, fake, gt)
+        ssim = pytorch_ssim.ssim(fake, gt)
+        l_l1 = l1_loss(fake, gt)
+        l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        lossG = self.w["l1"] * l_l1 + self.w["ssim"] * (1.0 - ssim) + self.w["perc"] * l_perc + self.w["adv"] * l_adv
         with self.optG.overlap(self.dp):            # slices of the flat gradient are all-reduced while the backward still runs
             lossG.backward()
         self.optG.step()
-        out.update({k: float(v.detach()) for k, v in dict(lossG=lossG, l1=l_l1, ssim=1.0 - l_ssim, perc=l_perc, adv=l_adv).items()})
-        return out
+        vals = torch.stack([t.detach().float() for t in (l_real + l_fake, lossG, l_l1, ssim, l_perc, l_adv)]).tolist()
+        return dict(zip(("lossD", "lossG", "l1", "ssim", "perc", "adv"), vals))
 
 
 def main():

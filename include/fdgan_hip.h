@@ -310,6 +310,28 @@ int fdgan_ssim_fwd(const float* x, const float* y, int64_t planes, int64_t h, in
 int fdgan_ssim_bwd(const float* x, const float* y, const float* da, const float* db, const float* dc, int64_t planes,
                    int64_t h, int64_t w, float weight, float* dx, FdStream stream);
 
+/* ---- scalar losses -----------------------------------------------------------------------------------
+ * Mean reductions of a training loop over the reference's networks, value AND gradient in one pass, ordered two-stage
+ * sums (bit-reproducible).  fdgan_loss_f32 on contiguous fp32 tensors of n elements:
+ *   kind 0  F.l1_loss(x, t)                  grad = sign(x - t) / n
+ *   kind 1  F.mse_loss(x, t)                 grad = 2 (x - t) / n
+ *   kind 2  F.binary_cross_entropy(x, t)     logs clamped at -100, grad = (x - t) / max(x (1 - x), 1e-12) / n  (torch's
+ *           rule) -- D's sigmoid map, dehaze1113.py:221-223, against all-ones / all-zeros
+ * t == NULL: the constant target t_const.  `partial` receives *nparts per-workgroup sums of the UNSCALED loss terms;
+ * fdgan_sum_partials(partial, nparts, 1.0 / n, out) turns them into the mean (fp64 accumulation, index order).
+ * grad (optional): d mean / d x, fp32, same shape.
+ * fdgan_mse_nhwc_fwd / _bwd: mean squared difference of two NHWC bf16 views (Vgg16's tapped feature maps,
+ * myutils/vgg16.py:27-49, read where the conv kernels left them): partial sums pre-multiplied by `scale` (1 / numel for
+ * a mean; several maps may share one partial array and one fdgan_sum_partials), and g = upstream[0] * scale * (a - b)
+ * written to the gradient view of `a` (scale = 2 / numel), `upstream` a DEVICE scalar so no host sync is needed. */
+int fdgan_loss_f32(int kind, const float* x, const float* t, float t_const, int64_t n, float* grad, float* partial,
+                   int64_t partial_floats, int64_t* nparts, FdStream stream);
+int fdgan_sum_partials(const float* partial, int64_t count, double scale, float* out, FdStream stream);
+int fdgan_mse_nhwc_fwd(const FdTensor* a, const FdTensor* b, float scale, float* partial, int64_t partial_floats,
+                       int64_t* nparts, FdStream stream);
+int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, const FdTensor* g,
+                       FdStream stream);
+
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);

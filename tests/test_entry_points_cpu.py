@@ -84,6 +84,27 @@ def test_loader_and_helpers(tmp_path):
     pool = misc.ImagePool(2)
     a, b = torch.zeros(1), torch.ones(1)
     assert pool.query(a) is a and pool.query(b) is b and pool.num_imgs == 2
+    # full pool: a fair coin between "return the new image" and "swap with a uniformly drawn slot, return the old one"
+    pool = misc.ImagePool(4, seed=11)
+    for i in range(4):
+        pool.query(torch.full((2,), float(i)))
+    kept, swapped, seen = 0, 0, set()
+    for i in range(4, 404):
+        new = torch.full((2,), float(i))
+        got = pool.query(new)
+        if got is new:
+            kept += 1
+        else:
+            swapped += 1
+            assert float(got[0]) < i and float(got[0]) not in seen          # an older image, returned once
+            seen.add(float(got[0]))
+            assert any(float(pool.store[s][0]) == i for s in range(4))      # the new one took its slot
+    assert 150 < kept < 250 and kept + swapped == 400
+    assert misc.ImagePool(0).query(a) is a
+    np.random.seed(5)
+    r1 = misc.ImagePool(3).rng.integers(1 << 30)
+    np.random.seed(5)
+    assert misc.ImagePool(3).rng.integers(1 << 30) == r1                     # np.random.seed() still pins a run
     conv, bn = torch.nn.ConvTranspose2d(4, 4, 1), torch.nn.BatchNorm2d(4)
     torch.manual_seed(0)
     misc.weights_init(conv), misc.weights_init(bn)
