@@ -124,9 +124,20 @@ def cpu_baseline_train(size, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 20:
             break
-    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full training steps (G + Fusion-D + VGG16 + SSIM, Adam), batch 1 @%dx%d, fp32 PyTorch-CPU oracle "
-                      "(oracle/train_ref.py), %.1f s" % (n, size, size, dt)}
+    res = {"value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d full training steps (G + Fusion-D + VGG16 + SSIM, Adam), batch 1 @%dx%d, fp32 PyTorch-CPU oracle "
+                     "(oracle/train_ref.py), %.1f s" % (n, size, size, dt), "host_cpus": os.cpu_count()}
+    # SURVEY 8(d) asks for batch 1 AND the benchmark's batch 16: one step of the same oracle at the same thread count (more
+    # threads are SLOWER for torch's CPU convolutions on this host: 64 threads took 52.7 s for this step, 16 take ~10 s)
+    cores16 = cores
+    gt16 = det_input((16, 3, size, size), seed=98)
+    haze16 = (gt16 * 0.6 + 0.3).clamp(0, 1)
+    t0 = time.perf_counter()
+    ts.step(haze16, gt16)
+    dt16 = time.perf_counter() - t0
+    res["batch16"] = {"value": round(16 / dt16, 3), "unit": "images/sec", "cores": cores16,
+                      "sample": "1 full training step, batch 16 @%dx%d, same oracle, %.1f s" % (size, size, dt16)}
+    return res
 
 
 # Algorithmic HBM bytes / flops of one launch of the kernels that can dominate the training step, from the arguments of
@@ -251,6 +262,32 @@ def train_bench(a, dp, dev, B, S):
                     roof["traffic"] = round(ach * traffic_mb / roof["algorithmic_mb_per_launch"], 1)
         except (OSError, ValueError):
             pass
+    # ---- whole-step roofline: counted work of the step / measured step time.  Work is counted from the plans' own op logs
+    # (NetPlan.meta: 2*MACs of every conv on the reference's formulation; bytes = every conv reads its input once and
+    # writes its output once in bf16).  Multipliers: a backward is one data-gradient + one weight-gradient
+    # pass, each with the forward's MACs and (input + output) bytes; frozen networks get the data gradient only:
+    #   G: fwd + dgrad + wgrad = 3;  D: 3 fwd + 2 x (dgrad + wgrad) [D step] + 1 x dgrad [G step] = 8;  VGG16: 2 fwd + dgrad = 3
+    step_roof = None
+    try:
+        with torch.no_grad():
+            pg = ts.netG.hip_plan(haze)
+            pd = ts.netD.hip_plan(torch.empty(B, 9, S, S, device=dev))
+            pv = ts.vgg._plan_for(haze, 0)
+        work = {}
+        for nm, pl, mult in (("netG", pg, 3), ("netD", pd, 8), ("vgg16", pv, 3)):
+            fl = sum(m["flops"] for m in pl.meta)
+            by = sum(m["bytes"] for m in pl.meta)
+            work[nm] = {"fwd_gflop": round(fl / 1e9, 1), "fwd_algorithmic_gb": round(by / 1e9, 3), "passes": mult}
+        gflop = sum(w["fwd_gflop"] * w["passes"] for w in work.values())
+        gb = sum(w["fwd_algorithmic_gb"] * w["passes"] for w in work.values())
+        ms_step = 1e3 * dt / a.steps
+        step_roof = {"gflop_per_step": round(gflop, 1), "algorithmic_gb_per_step": round(gb, 2),
+                     "tflops": round(gflop / ms_step, 1), "frac_mfma": round(gflop / ms_step / MFMA_PEAK_TFLOPS, 4),
+                     "GB/s": round(gb / ms_step * 1e3, 1), "frac_hbm": round(gb / ms_step * 1e3 / HBM_PEAK_GBS, 4),
+                     "arithmetic_intensity": round(gflop / gb, 1), "ridge": round(RIDGE, 1), "networks": work,
+                     "tflop_per_image": round(gflop / 1e3 / B, 3)}
+    except Exception as e:      # measurement aid only: never fail the benchmark line
+        step_roof = {"error": str(e)[:200]}
     res = None
     if rank == 0:
         res = {"metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
@@ -264,10 +301,38 @@ def train_bench(a, dp, dev, B, S):
                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
                           "library_launches_per_step": n_launch, "library_gpu_ms_per_step_instrumented": round(lib_ms, 2),
                           "last_losses": {k: round(v, 4) for k, v in last.items()}},
-               "roofline": roof, "cpu_baseline": None}
+               "roofline": roof, "step_roofline": step_roof, "cpu_baseline": None}
     del ts
     torch.cuda.empty_cache()
     return res
+
+
+def forward_1024(g, dev, batch=4, size=1024, warm=2, steps=5):
+    """BASELINE.json configs[4]: netG inference at batch 4 @ 1024x1024 (the reference's demo.py defaults imageSize to 1024),
+    train-mode BatchNorm as the reference runs it.  Attached to the default line so the driver times it too."""
+    import numpy as np
+    import torch
+    x = torch.from_numpy(np.random.default_rng(4321).random((batch, 3, size, size), dtype=np.float32)).to(dev)
+    with torch.no_grad():
+        for _ in range(warm):
+            y = g(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = g(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        plan = g.hip_plan(x)
+    fl, by = sum(m["flops"] for m in plan.meta), sum(m["bytes"] for m in plan.meta)
+    ok = bool(torch.isfinite(y).all())
+    del y
+    torch.cuda.empty_cache()
+    return {"value": round(batch / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "workload": "netG (FDGAN) forward-only, batch %d @ %dx%d, bf16 storage / fp32 accumulate, train-mode BatchNorm "
+                        "(BASELINE.json configs[4])" % (batch, size, size),
+            "gflop_per_step": round(fl / 1e9, 1), "algorithmic_gb_per_step": round(by / 1e9, 2),
+            "tflops": round(fl / dt / 1e12, 1), "frac_mfma": round(fl / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "GB/s": round(by / dt / 1e9, 1), "frac_hbm": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "finite": ok}
 
 
 def main():
@@ -449,6 +514,7 @@ def main():
         if train_res is not None:       # default line: the training step, with the forward-only measurement attached
             train_res["forward_only"] = {"value": res["value"], "unit": "images/sec", "ms_per_step": res["ms_per_step"],
                                          "workload": res["config"]["workload"], "roofline": res["roofline"]}
+            train_res["forward_1024"] = forward_1024(g, dev)
             if world == 1 and not a.no_cpu_baseline:
                 train_res["cpu_baseline"] = cpu_baseline_train(S, a.cpu_seconds)
             print(json.dumps(train_res), flush=True)

@@ -91,6 +91,43 @@ def main():
         **{"tapstat__" + k: np.array([v.mean().item(), v.std().item()]) for k, v in taps.items()},
         **{"grad__" + n.replace(".", "__"): rp[n].grad.numpy() for n in gnames}, **bn)
 
+    # ---------------- FDGAN backward, well-conditioned: batch 8 @ 64x64, BatchNorm biases + 3 ----------------
+    # (oracle/detweights.shift_bn_bias: ReLU mask flips under bf16 rounding become rare, so ALL 282 parameter
+    # gradients are comparable.)  Stored: per parameter 64 signed strided sums + the norm of the REFERENCE's gradient,
+    # and the oracle-vs-bf16-emulating-oracle disagreement of that parameter (the noise floor a bf16 path can reach).
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hiputil import emulate_bf16_operands, rel_rms
+    from oracle.detweights import grad_projection, shift_bn_bias
+    ogw, rgw, oew = o1113.FDGAN(), r1113.FDGAN(), o1113.FDGAN()
+    fill_state_dict(ogw, seed=0)
+    shift_bn_bias(ogw, 3.0)
+    _copy_weights(rgw, ogw)
+    oew.load_state_dict(ogw.state_dict())
+    emulate_bf16_operands(oew)
+    xw = det_input((8, 3, 64, 64), seed=1234)
+    tw = det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
+    yrw = rgw(xw.clone())
+    ((yrw - tw) ** 2).mean().backward()
+    ((ogw(xw.clone()) - tw) ** 2).mean().backward()
+    ((oew(xw.clone()) - tw) ** 2).mean().backward()
+    rpw, opw, epw = dict(rgw.named_parameters()), dict(ogw.named_parameters()), dict(oew.named_parameters())
+    wc, o2o = {}, {}
+    for n, p in rpw.items():
+        if p.grad is None:
+            continue
+        proj, norm = grad_projection(n, p.grad.numpy())
+        key = n.replace(".", "__")
+        o2o[n] = rel_rms(epw[n].grad, opw[n].grad)
+        wc["proj__" + key], wc["norm__" + key], wc["o2o__" + key] = proj, np.float64(norm), np.float64(o2o[n])
+    man["ref_vs_oracle_maxabs"]["fdgan_wellcond_dparams"] = max(float((rpw[n].grad - opw[n].grad).abs().max()) for n in o2o)
+    man["ref_vs_oracle_maxabs"]["fdgan_wellcond_fwd"] = float((yrw - ogw(xw.clone())).abs().max())
+    vals_o2o = np.array(list(o2o.values()))
+    man["fdgan_wellcond"] = {"params": len(o2o), "bn_bias_shift": 3.0, "batch": 8, "size": 64,
+                             "oracle_vs_emulated_median": float(np.median(vals_o2o)),
+                             "oracle_vs_emulated_p90": float(np.percentile(vals_o2o, 90)),
+                             "oracle_vs_emulated_worst": sorted(((float(v), k) for k, v in o2o.items()), reverse=True)[:5]}
+    np.savez_compressed(os.path.join(OUT, "fdgan_8x64_wellcond.npz"), y=yrw.detach().numpy()[:, :, ::4, ::4], **wc)
+
     # eval-mode forward (running statistics) on the same weights, fresh modules
     og2, rg2 = o1113.FDGAN().eval(), r1113.FDGAN().eval()
     fill_state_dict(og2, seed=0)

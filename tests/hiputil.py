@@ -66,7 +66,7 @@ def seeded(shape, seed, lo=-1.0, hi=1.0):
     return torch.from_numpy(a.astype(np.float32))
 
 
-def emulate_bf16_operands(module):
+def emulate_bf16_operands(module, round_grads=False):
     """Turns an fp32 oracle network into a statement of what the HIP path computes: every conv sees its
     filter, its (activated) input and its stored output rounded to bf16 -- straight-through for autograd -- and in-place
     activations are made out-of-place so conv outputs can be inspected.  Accumulation stays fp32/fp64.
@@ -75,6 +75,15 @@ def emulate_bf16_operands(module):
     alone is a 5-10 % rms difference in every upstream gradient."""
     import torch.nn as nn
     st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+    if round_grads:
+        # round_grads: the gradient arriving at every conv input is rounded to bf16 as well -- the HIP path keeps activation
+        # GRADIENTS in NHWC bf16 buffers like the activations.  This matters for cancellation-dominated reductions (a
+        # BatchNorm bias gradient whose terms sum to ~0 analytically): their noise floor is set by that storage.
+        def st(t):          # noqa: F811
+            r = t + (t.to(torch.bfloat16).float() - t).detach()
+            if r.requires_grad:
+                r.register_hook(lambda g: g.to(torch.bfloat16).float())
+            return r
     with torch.no_grad():
         for m in module.modules():
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):

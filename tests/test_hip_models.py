@@ -23,6 +23,14 @@ def _report(name, d):
         pass
 
 
+# Input-gradient contribution of ONE fused op vs torch autograd of that op on the same device tensors: bf16 rounding of
+# the stored gradient (2^-9) plus the rare activation-mask flip at pre-activations within one ulp of zero.  Fixed: round 1
+# let the bound grow with 1 / (contribution size) because the contribution was read as the difference of two bf16
+# accumulator states -- the 0.132 it once let pass (1x1 64->32 @32x32, pooled) was that subtraction's rounding, not the op;
+# measured in isolation the same op is at 4e-3.
+DX_TOL = 2e-2
+
+
 @pytest.fixture(scope="module")
 def nets():
     import models.dehaze1113 as net
@@ -226,7 +234,8 @@ def test_vgg16_matches_golden(golden_dir):
         assert a.shape == b.shape and rel_rms(a.cpu(), b) < 2e-2
 
 
-def test_demo_end_to_end_png_parity(nets, tmp_path):
+@pytest.mark.parametrize("hw", [(96, 128), (256, 256)])
+def test_demo_end_to_end_png_parity(nets, tmp_path, hw):
     """demo.py's whole pipeline (dataset -> `module.`-prefixed checkpoint -> train-mode generator on
     the HIP path -> min-max normalised PNG) against the oracle pushed through the same writer:
     SURVEY 8c's acceptance is PSNR within 0.02 dB and SSIM within 1e-3 of the reference's score."""
@@ -244,10 +253,11 @@ def test_demo_end_to_end_png_parity(nets, tmp_path):
     root, res, oref, gtd = (str(tmp_path / d) for d in ("ds", "res", "oref", "gt"))
     for d in (res, oref, gtd):
         os.makedirs(d)
-    hz = det_input((2, 3, 96, 128), seed=77, lo=0.0, hi=1.0)
-    gt = det_input((2, 3, 96, 128), seed=78, lo=0.0, hi=1.0)
+    hz = det_input((2, 3) + hw, seed=77, lo=0.0, hi=1.0)
+    gt = det_input((2, 3) + hw, seed=78, lo=0.0, hi=1.0)
     for i in range(2):
-        write_pair(root, i, hz[i].permute(1, 2, 0).numpy(), gt[i].permute(1, 2, 0).numpy())
+        path = write_pair(root, i, hz[i].permute(1, 2, 0).numpy(), gt[i].permute(1, 2, 0).numpy())
+        assert path.endswith(".h5")                                  # the reference's file format, via datasets/h5lite.py
         Image.fromarray(misc.to_uint8_image(gt[i], normalize=False)).save(os.path.join(gtd, "%d.png" % i))
     opt = demo.build_parser().parse_args(["--valDataroot", root, "--netG", ck, "--outDir", res, "--workers", "0"])
     written = demo.run(opt)
@@ -261,7 +271,7 @@ def test_demo_end_to_end_png_parity(nets, tmp_path):
     rp, rs = ps.score_dirs(gtd, oref, verbose=False)
     rep = {"png_psnr_hip_vs_oracle": direct_p, "png_ssim_hip_vs_oracle": direct_s, "psnr_vs_gt": [hp, rp],
            "ssim_vs_gt": [hs, rs]}
-    _report("demo_png", rep)
+    _report("demo_png_%dx%d" % hw, rep)
     assert min(direct_p) > 35.0 and min(direct_s) > 0.98, rep
     assert abs(np.mean(hp) - np.mean(rp)) < 0.02 and abs(np.mean(hs) - np.mean(rs)) < 1e-3, rep
 
@@ -335,6 +345,129 @@ def test_fdgan_full_size_properties(nets):
     rep = {"psnr_eval_256": psnr(y16[:1].cpu(), y_ref)}
     _report("fdgan_full_size", rep)
     assert rep["psnr_eval_256"] > 38.0, rep
+
+
+def test_fdgan_high_res_1024(nets):
+    """BASELINE configs[4]: netG inference at 4 x 3 x 1024 x 1024 (demo.py:35-38 defaults imageSize to 1024: the
+    reference's real inference size).  Eval-mode image 0 against the CPU oracle (per-image independent in eval mode),
+    bitwise determinism, eval-mode batch independence, train mode (the reference's demo mode) finite and bounded."""
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    x = det_input((4, 3, 1024, 1024), seed=2024).to(DEV)
+    with torch.no_grad():
+        g.eval()
+        y4 = g(x).clone()
+        y4b = g(x).clone()
+        y1 = g(x[:1].contiguous()).clone()
+        g.train()
+        t4 = g(x).clone()
+    torch.cuda.synchronize()
+    assert y4.shape == (4, 3, 1024, 1024) and bool(torch.isfinite(y4).all()) and float(y4.abs().max()) <= 1.0
+    assert torch.equal(y4, y4b) and torch.equal(y4[:1], y1)
+    assert bool(torch.isfinite(t4).all()) and float(t4.abs().max()) <= 1.0 and not torch.equal(t4, y4)
+    og.eval()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        y_ref = og(x[:1].cpu())
+    rep = {"psnr_eval_1024": psnr(y4[:1].cpu(), y_ref), "max_abs": float((y4[:1].cpu() - y_ref).abs().max())}
+    _report("fdgan_1024", rep)
+    assert rep["psnr_eval_1024"] > 38.0, rep
+
+
+def test_frequency_split_1024():
+    """configs[4]: Blur / Laplacian / the fused D input at 4 x 3 x 1024 x 1024 vs oracle/freqsplit_ref.py."""
+    import loss as hl
+    from fdgan_hip import engine as E
+    from oracle import freqsplit_ref as fr
+    from oracle.detweights import det_input
+    x = det_input((4, 3, 1024, 1024), seed=99, lo=0.0, hi=1.0)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        lf, hf = hl.blur(xd).cpu(), hl.laplace_filter(xd).cpu()
+        fused = E.new_act(4, 1024, 1024, 16, DEV, zero=True)
+        E.fusion_input_nhwc(xd, E.View(fused, 0, 9))
+        lf_ref, hf_ref = fr.blur(x), fr.laplacian(x)
+    assert (lf - lf_ref).abs().max() < 2e-5 and (hf - hf_ref).abs().max() < 2e-5
+    cat = torch.cat([x, lf_ref, hf_ref], 1)
+    got = fused[..., :9].float().cpu().permute(0, 3, 1, 2)
+    assert rel_rms(got, cat) < 4e-3 and (got - cat).abs().max() < 2e-2 * float(cat.abs().max())     # bf16 storage
+    assert float(fused[..., 9:].abs().max()) == 0.0
+
+
+def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
+    """Generator gradient parity for ALL 282 trained parameters against gradients of the REAL reference
+    (tests/golden/fdgan_8x64_wellcond.npz, written by oracle/make_golden.py from /root/reference).
+
+    Conditioning: batch 8 @ 64x64 with every BatchNorm bias shifted by +3 (oracle/detweights.shift_bn_bias), which
+    takes almost all pre-activations off the ReLU kink; two CPU statements of the network (fp32 oracle vs the
+    bf16-operand-emulating oracle) then agree to 3 % in the median (MANIFEST: oracle_vs_emulated_median) instead of 54 %
+    with the plain weights.  Bound per parameter: 2 x max(that parameter's own oracle-vs-emulated disagreement, the
+    median) -- a bf16 path cannot be expected closer to the fp32 reference than a bf16-emulating CPU statement is.
+    The fixture holds 64 signed strided sums + the norm per parameter (oracle/detweights.grad_projection).
+
+    BatchNorm biases are measured on the scale of their (weight, bias) PAIR: d beta = sum dpre and d gamma = sum dpre * xhat
+    are sums of the same terms, so their absolute noise floors are equal, but with the +3 shift the ReLU passes almost
+    everything and sum dpre of a layer whose consumer is itself BatchNorm'd is ANALYTICALLY ~0 (BatchNorm's backward
+    output sums to zero): |d beta| is 1.4 % of |d gamma| for dense_block1.denselayer1.norm1, a pure cancellation
+    residue.  Activation gradients are stored in bf16 on the HIP path (as the activations are), which puts its floor for
+    such a residue at ~1 % of the pair's scale -- 80 % of the residue itself.  Relative to the pair the same error is
+    0.012."""
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict, grad_projection, shift_bn_bias
+    gold = np.load(os.path.join(golden_dir, "fdgan_8x64_wellcond.npz"))
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["fdgan_wellcond"]
+    assert man["oracle_vs_emulated_median"] < 0.05 and man["params"] == 282
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    shift_bn_bias(og, man["bn_bias_shift"])
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    x = det_input((8, 3, 64, 64), seed=1234).to(DEV)
+    tgt = det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0).to(DEV)
+    y = g(x)
+    ((y - tgt) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    assert psnr(y.detach().cpu()[:, :, ::4, ::4], torch.from_numpy(gold["y"])) > 38.0
+    rep, bad, zero_grad = {}, [], []
+    for name, p in g.named_parameters():
+        key = name.replace(".", "__")
+        if "proj__" + key not in gold.files:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        proj, norm = grad_projection(name, p.grad.cpu().numpy())
+        gp, gn, o2o = gold["proj__" + key], float(gold["norm__" + key]), float(gold["o2o__" + key])
+        if o2o > 0.5:          # analytically zero gradient (a bias in front of BatchNorm): pure rounding noise in every statement
+            zero_grad.append((name, norm, gn))
+            continue
+        scale = np.sqrt((gp ** 2).sum())
+        nscale = gn
+        partner = key[:-len("bias")] + "weight"
+        if name.endswith(".bias") and ("norm" in name) and "norm__" + partner in gold.files:
+            pscale = float(gold["norm__" + partner])
+            if pscale > gn:                               # BatchNorm bias: the (weight, bias) pair's scale (docstring)
+                scale, nscale = scale * pscale / gn, pscale
+        rel = float(np.sqrt(((proj - gp) ** 2).sum()) / scale)
+        tol = 2.0 * max(o2o, man["oracle_vs_emulated_median"])
+        rep[name] = [rel, tol, abs(norm - gn) / nscale]
+        if rel > tol or abs(norm - gn) / nscale > tol:
+            bad.append((name, rel, tol, norm / gn))
+    vals = np.array([v[0] for v in rep.values()])
+    summary = {"n": len(rep), "median": float(np.median(vals)), "p90": float(np.percentile(vals, 90)), "max": float(vals.max()),
+               "oracle_vs_emulated_median": man["oracle_vs_emulated_median"], "zero_gradient_params": zero_grad,
+               "worst": sorted(((v[0], k) for k, v in rep.items()), reverse=True)[:8]}
+    _report("fdgan_backward_all_params", summary)
+    assert len(rep) + len(zero_grad) == 282 and [z[0] for z in zero_grad] == ["conv_refine4.bias"], summary
+    w = dict(g.named_parameters())["conv_refine4.weight"].grad
+    assert zero_grad[0][1] < 1e-3 * float(w.norm()), zero_grad      # conv_refine4.bias feeds BatchNorm only: d/db == 0
+    assert not bad, (bad[:10], summary)
+    assert summary["median"] < 2.0 * man["oracle_vs_emulated_median"], summary
 
 
 def test_fusion_d_backward_matches_oracle_and_golden(nets, golden_dir):
@@ -491,7 +624,7 @@ def test_dense_block_backward_small(nets):
     rep["dx"] = rel_rms(dx.cpu(), xo.grad)
     _report("dense_block_backward", rep)
     for o in B.checks:                                   # every op vs torch autograd on identical tensors
-        assert o["dw"] < 5e-3 and o.get("dx", 0.0) < 2e-2 + 6e-3 / max(o.get("dx_scale", 1.0), 1e-3), o
+        assert o["dw"] < 5e-3 and o.get("dx", 0.0) < DX_TOL, o
     # network level: the oracle's BatchNorm sees the bf16-rounded tensors, the HIP path's statistics come from
     # the fp32 accumulators -> ~1e-3 relative differences in mean / var -> ~0.1 % of the ReLU masks differ per
     # layer; six BN+ReLU layers deep that is 6-14 % on the dense-layer parameters (0.5-4 % on the transition)
@@ -553,8 +686,8 @@ def test_fdgan_backward_matches_oracle_and_golden(nets, golden_dir):
     assert params["conv0.weight"].grad is None and params["dense_block4.bn1.weight"].grad is None
     assert rep["n_params_with_grad"] == 282 and rep["ops_checked"] >= 100, rep
     assert rep["op_dw_worst"] < 5e-3, rep
-    for o in checks:   # the contribution is measured as G_after - G_before in a bf16 accumulator: small ones are rounded
-        assert o.get("dx", 0.0) < 2e-2 + 6e-3 / max(o.get("dx_scale", 1.0), 1e-3), o
+    for o in checks:   # every op's input-gradient contribution, measured in isolation (PlanBackward._finish_check)
+        assert o.get("dx", 0.0) < DX_TOL, o
     assert rep["stable_params_worst_vs_emulated"] < 0.12, rep
     assert rep["all_params_median_vs_emulated"] < 1.5 * rep["oracle_vs_oracle_median"] + 0.05, rep
 

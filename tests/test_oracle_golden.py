@@ -154,3 +154,31 @@ def test_dehaze22_d_matches_golden(golden_dir, manifest):
         y = d(x)
     assert y.shape == (2, 1, 6, 6)
     np.testing.assert_allclose(y.numpy(), _load(golden_dir, "d22_2x64.npz")["y"], **TOL)
+
+
+def test_oracle_reproduces_wellconditioned_reference_gradients(golden_dir):
+    """The 282-parameter gradient fixture (reference run of oracle/make_golden.py, batch 8 @ 64x64, BatchNorm biases + 3):
+    the oracle restatement reproduces every stored projection (same torch CPU ops: exact up to reduction order)."""
+    import json
+    from oracle import dehaze1113_ref as ref
+    from oracle.detweights import det_input, fill_state_dict, grad_projection, shift_bn_bias
+    gold = _load(golden_dir, "fdgan_8x64_wellcond.npz")
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["fdgan_wellcond"]
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    shift_bn_bias(og, man["bn_bias_shift"])
+    x, tgt = det_input((8, 3, 64, 64), seed=1234), det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
+    y = og(x)
+    ((y - tgt) ** 2).mean().backward()
+    np.testing.assert_allclose(y.detach().numpy()[:, :, ::4, ::4], gold["y"], **TOL)
+    n = 0
+    for name, p in og.named_parameters():
+        key = "proj__" + name.replace(".", "__")
+        if key not in gold.files:
+            assert p.grad is None
+            continue
+        proj, norm = grad_projection(name, p.grad.numpy())
+        scale = float(np.abs(gold[key]).max()) + 1e-12
+        assert np.abs(proj - gold[key]).max() < 1e-4 * scale + 1e-9, name
+        n += 1
+    assert n == 282
