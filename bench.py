@@ -201,6 +201,12 @@ def train_bench(a, dp, dev, B, S):
         d[1] += ms
     lib_ms = sum(v[1] for v in by_name.values())
     ranking = sorted(by_name.items(), key=lambda kv: -kv[1][1])
+    if a.breakdown and rank == 0:       # every launcher of the instrumented step: launches, GPU ms (hipEvent pairs on the launch stream)
+        os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
+        with open(a.breakdown, "w") as f:
+            json.dump({"library_gpu_ms_per_step": lib_ms, "launches_per_step": n_launch,
+                       "rows": [{"launcher": n, "launches": v[0], "ms": round(v[1], 4), "share": round(v[1] / lib_ms, 4)}
+                                for n, v in ranking]}, f, indent=1)
     dom_name = next((n for n, _ in ranking if n in MODELS), None)   # the top kernel with a byte model (see `roofline.ranking`)
     # ---- per-call algorithmic bytes of the dominant kernel, recorded by wrapping its engine entry point
     per_call = []

@@ -557,6 +557,10 @@ struct SumFinArgs {
   // two-level reduction of many partial rows (a few thousand pixel tiles x 4 workgroups would take 60 us): with
   // `level1` set, workgroup (x, y) sums the y-th of gridDim.y row slices and writes ONE row of fp32 sums to level1
   float* level1;
+  // fused fdgan_bn_bwd_coef (fdgan_bn_bwd_finalize_coef): bsum += B, csum += C of dx = A dpre + B x + C; dbeta / dgamma may be NULL
+  const float* coef_gamma;
+  float coef_inv_m;
+  float *bsum, *csum;
 };
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
   __shared__ double sh[2][32][33];
@@ -598,15 +602,23 @@ __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
       return;
     }
     if (a.raw_mean != nullptr) t2 = (t2 - (double)a.raw_mean[c] * t1) / sqrt((double)a.raw_var[c] + (double)a.raw_eps);
-    if (a.accumulate) {
-      a.dbeta[c] += (float)t1;
-      a.dgamma[c] += (float)t2;
-    } else {
-      a.dbeta[c] = (float)t1;
-      a.dgamma[c] = (float)t2;
+    if (a.dbeta != nullptr) {
+      if (a.accumulate) {
+        a.dbeta[c] += (float)t1;
+        a.dgamma[c] += (float)t2;
+      } else {
+        a.dbeta[c] = (float)t1;
+        a.dgamma[c] = (float)t2;
+      }
     }
     if (a.sink_dbeta != nullptr) a.sink_dbeta[c] += (float)t1;
     if (a.sink_dgamma != nullptr) a.sink_dgamma[c] += (float)t2;
+    if (a.bsum != nullptr) {   // same arithmetic as bn_bwd_coef_kernel, on the fp32-rounded sums it would have read
+      const float rs = 1.f / sqrtf(a.raw_var[c] + a.raw_eps), gmm = a.coef_gamma ? a.coef_gamma[c] : 1.f;
+      const float A = gmm * rs, B = -gmm * rs * rs * (float)t2 * a.coef_inv_m;
+      a.bsum[c] += B;
+      a.csum[c] += -A * (float)t1 * a.coef_inv_m - B * a.raw_mean[c];
+    }
   }
 }
 
@@ -1070,7 +1082,8 @@ static int launch_sum_finalize(SumFinArgs a, float* scratch, int64_t scratch_flo
 extern "C" int fdgan_bn_bwd_finalize_sink(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                                           float* dbeta, int accumulate, float* sink_dgamma, float* sink_dbeta, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma, nullptr, nullptr, 0.f, nullptr};
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, accumulate, sink_dbeta, sink_dgamma, nullptr, nullptr, 0.f, nullptr,
+               nullptr, 0.f, nullptr, nullptr};
   return launch_sum_finalize(a, nullptr, 0, stream);
 }
 
@@ -1078,7 +1091,20 @@ extern "C" int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int
                                          const float* var, float eps, float* dgamma, float* dbeta, float* sink_dgamma,
                                          float* sink_dbeta, float* scratch, int64_t scratch_floats, FdStream stream) {
   FD_REQUIRE(partial && dgamma && dbeta && mean && var && rows > 0 && channels > 0 && cpad >= channels, "bn_bwd_finalize_raw: bad arguments");
-  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, 0, sink_dbeta, sink_dgamma, mean, var, eps, nullptr};
+  SumFinArgs a{partial, rows, cpad, channels, dbeta, dgamma, 0, sink_dbeta, sink_dgamma, mean, var, eps, nullptr,
+               nullptr, 0.f, nullptr, nullptr};
+  return launch_sum_finalize(a, scratch, scratch_floats, stream);
+}
+
+/* fdgan_bn_bwd_finalize_raw + fdgan_bn_bwd_coef in one launch: the reduced (dbeta, dgamma) go to the parameters' gradient
+ * sinks (optional) and straight into the buffer's deferred coefficient pair; they are not stored anywhere else. */
+extern "C" int fdgan_bn_bwd_finalize_coef(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const FdPrologue* pro,
+                                          int64_t count, float* sink_dgamma, float* sink_dbeta, float* bsum, float* csum,
+                                          float* scratch, int64_t scratch_floats, FdStream stream) {
+  FD_REQUIRE(partial && pro && pro->mean && pro->var && bsum && csum && rows > 0 && channels > 0 && cpad >= channels && count > 0,
+             "bn_bwd_finalize_coef: bad arguments");
+  SumFinArgs a{partial, rows, cpad, channels, nullptr, nullptr, 0, sink_dbeta, sink_dgamma, pro->mean, pro->var, pro->eps, nullptr,
+               pro->gamma, 1.f / (float)count, bsum, csum};
   return launch_sum_finalize(a, scratch, scratch_floats, stream);
 }
 

@@ -282,14 +282,12 @@ class PlanBackward:
             rows, cpad = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
                                          accumulate=2 if store else 1)
             if bn is not None:
-                dg = torch.empty(cin, dtype=torch.float32, device=p.device)
-                dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
                 train_bn = bn.weight is not None and bn.weight.requires_grad
-                E.bn_bwd_finalize_raw(self.ws_bn, rows, cpad, cin, meta["mean"], meta["var"], meta["eps"], dg, dbt,
-                                      sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
-                                      sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
                 d = self._deferred(x)
-                E.bn_bwd_coef(dg, dbt, act_pro, cin, n * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
+                E.bn_bwd_finalize_coef(self.ws_bn, rows, cpad, cin, act_pro, n * hin * win, d["coef"][0, x.c0:x.c0 + cin],
+                                       d["coef"][1, x.c0:x.c0 + cin],
+                                       sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                                       sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
                 d["dirty"].update(range(x.c0, x.c0 + cin))
             if check:
                 self.flush(x)

@@ -334,6 +334,17 @@ def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta,
             "bn_bwd_finalize_raw")
 
 
+def bn_bwd_finalize_coef(ws, rows, cpad, channels, pro, count, bsum, csum, sink_dgamma=None, sink_dbeta=None, scratch=None):
+    """bn_bwd_finalize_raw + bn_bwd_coef in one launch (no dgamma / dbeta temporaries)."""
+    L.check(L.load().fdgan_bn_bwd_finalize_coef(ws.data_ptr(), rows, cpad, channels, C.byref(pro), count,
+                                                sink_dgamma.data_ptr() if sink_dgamma is not None else None,
+                                                sink_dbeta.data_ptr() if sink_dbeta is not None else None,
+                                                bsum.data_ptr(), csum.data_ptr(),
+                                                scratch.data_ptr() if scratch is not None else None,
+                                                scratch.numel() if scratch is not None else 0, stream_ptr()),
+            "bn_bwd_finalize_coef")
+
+
 def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None, accumulate=False):
     """dpre <- conv^T(dy, W) * act'(bn(fwd_x)) (stride-1 convs); with a norm in fwd_pro fills `ws` and returns
     (rows, cpad) for bn_bwd_finalize_raw.  accumulate: dpre_fd is the gradient buffer of fwd_x; 1 / True: += gamma * rstd *
