@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver; before the HIP runtime starts
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "fd-gan_amd")):
     if p not in sys.path:
@@ -227,6 +229,23 @@ def train_bench(a, dp, dev, B, S):
         while math.gcd(stride, cnt) != 1:                           # ... walking through every position of the step over the run
             stride += 1
         E.kernel_timer_arm(dom_name, stride, min(65536, 16 * a.steps + 16))
+    comm = None
+    if world > 1:
+        # the gradient exchange on its own (nothing to hide behind): both flat buffers, same slicing as the step uses
+        import torch.distributed as dist
+        dp.barrier()
+        iso = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ts.optD.allreduce_grads(dp)
+            ts.optG.allreduce_grads(dp)
+            e1.record()
+            torch.cuda.synchronize()
+            iso.append(e0.elapsed_time(e1))
+        ts.optG.comm_events, ts.optD.comm_events = [], []
+        comm = {"rccl_ranks": world, "backend": dist.get_backend(), "bytes_per_step": 4 * (ts.optG.grad.numel() + ts.optD.grad.numel()),
+                "isolated_ms_per_step": round(min(iso), 3)}
     dp.barrier()                                   # torch.cuda.synchronize() + a collective barrier when world > 1
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -234,6 +253,11 @@ def train_bench(a, dp, dev, B, S):
     dp.barrier()
     dt = dp.max_over_ranks(time.perf_counter() - t0)
     images = dp.sum_over_ranks(B * a.steps)
+    if comm is not None:
+        exposed = sum(e0.elapsed_time(e1) for e0, e1 in ts.optG.comm_events + ts.optD.comm_events) / a.steps
+        comm["exposed_ms_per_step"] = round(exposed, 3)       # compute stream stalled on the collectives (G: after its backward; D: all of it)
+        comm["hidden_fraction"] = round(max(0.0, 1.0 - exposed / max(comm["isolated_ms_per_step"], 1e-9)), 3)
+        ts.optG.comm_events = ts.optD.comm_events = None
     roof = None
     if dom_name is not None:
         timed, seen = E.kernel_timer_read(65536)
@@ -306,6 +330,7 @@ def train_bench(a, dp, dev, B, S):
                                       % (2 if world == 1 else 3, B, S, S),
                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
                           "library_launches_per_step": n_launch, "library_gpu_ms_per_step_instrumented": round(lib_ms, 2),
+                          "gradient_exchange": comm,
                           "last_losses": {k: round(v, 4) for k, v in last.items()}},
                "roofline": roof, "step_roofline": step_roof, "cpu_baseline": None}
     del ts
@@ -346,7 +371,12 @@ def main():
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     from fdgan_hip.dp import DpContext
-    dp = DpContext.from_env(backend="nccl")           # RCCL; one process per GPU
+    if os.environ.get("FDGAN_BENCH_SHARED_GPU") == "1":
+        # test hook (tests/test_dp_step_gpu.py): all ranks on cuda:0 over gloo, to exercise the N > 1 code path of this
+        # file on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+        dp = DpContext.from_env(backend="gloo", device=torch.device("cuda", 0))
+    else:
+        dp = DpContext.from_env(backend="nccl")       # RCCL; one process per GPU
     world, rank, dev = dp.world, dp.rank, dp.device
     if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with `python -m torch.distributed.run "

@@ -12,8 +12,12 @@ is the generic variant for optimizers without a flat buffer.
 """
 import os
 
-import torch
-import torch.distributed as dist
+# The host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this BEFORE the HIP runtime
+# initialises (first device call), so it is set at import time, not next to init_process_group.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 class DpContext:
@@ -35,7 +39,6 @@ class DpContext:
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver
             if backend is None:
                 backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
             dist.init_process_group(backend, rank=rank, world_size=world)

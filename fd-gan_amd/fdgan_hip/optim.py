@@ -29,6 +29,9 @@ class FlatAdam:
             p.grad = self.grad[o:o + p.numel()].view_as(p)                        # and so does its gradient
             p._fd_grad_sink = p.grad                # the planned modules' backward adds into it directly (backward.grad_sink)
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        # measurement aid (bench.py, N > 1): when `comm_events` is a list, every gradient exchange appends a pair of
+        # events bracketing the point where the compute stream waits for the collectives = the EXPOSED communication time
+        self.comm_events = None
         self.param_groups = [{"lr": lr, "params": self.params}]                  # misc.adjust_learning_rate compatibility
 
     def zero_grad(self, set_to_none=False):
@@ -65,13 +68,29 @@ class FlatAdam:
         import torch.distributed as dist
         n, step = self.grad.numel(), max(1, int(bucket_mb * (1 << 20) / 4))
         works = []
+        ev = _events(self)
         for hi in range(n, 0, -step):
             lo = max(0, hi - step)
             works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
+        _events_done(self, ev)
         self.grad.div_(ctx.world)
         return len(works)
+
+
+def _events(opt):
+    if opt.comm_events is None or not opt.grad.is_cuda:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0, e1
+
+
+def _events_done(opt, ev):
+    if ev is not None:
+        ev[1].record()
+        opt.comm_events.append(ev)
 
 
 class _Overlap:
@@ -141,8 +160,10 @@ class _Overlap:
         BW.PROGRESS_HOOK = self._prev
         if et is None:
             self._sweep(final=True)
+            ev = _events(self.opt)         # the backward's kernels are all enqueued: what the stream waits for from here is exposed
             for w in self.works:
                 w.wait()
+            _events_done(self.opt, ev)
             if self.reduce_fn is None:
                 self.opt.grad.div_(self.ctx.world)
         return False

@@ -62,6 +62,7 @@ class TrainStep:
         bufs = [self.optG.flat, self.optD.flat]
         bufs += [b for m in (self.netG, self.netD) for b in m.buffers() if b.dtype.is_floating_point]
         bufs += [p.data for p in self.netG.parameters() if not any(p is q for q in self.optG.params)]   # never-trained tensors
+        bufs += [p.data for p in self.vgg.parameters()]                                                  # frozen, but must agree
         for b in bufs:
             dist.broadcast(b, src=0)
         chk = torch.stack([b.double().sum() for b in bufs[:2]])

@@ -1,0 +1,118 @@
+"""Data-parallel TRAINING STEP with two ranks (BASELINE configs[3] in miniature), on the one GPU of the test box: two
+processes share cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on one device; the collective's
+semantics are the same, and `torch.distributed` is the only thing that differs from the 8-GPU run).
+
+Each rank builds its own TrainStep from a DIFFERENT torch seed and owns its own half of the global batch.  Checked:
+  * the initial broadcast makes the replicas identical (parameters and BatchNorm buffers of rank 0 everywhere);
+  * what every rank's optimizers apply is exactly the MEAN of the two ranks' local gradients -- each all-reduced slice
+    is snapshotted before the collective, the slices tile the flat buffers -- for D (reduced after its two backward
+    passes) and for G (slices reduced while the backward walk is still running);
+  * the parameters after the step are bit-identical on both ranks and equal Adam's first update on that mean gradient;
+  * BatchNorm statistics stay per replica (nn.DataParallel semantics, /root/reference/demo.py:89): running means differ.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "fd-gan_amd")]
+    import torch.distributed as dist
+    import train as train_mod
+    from fdgan_hip.dp import DpContext
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cuda", 0))
+    torch.manual_seed(100 + rank)                          # replicas start DIFFERENT: the broadcast has to fix that
+    ts = train_mod.TrainStep(dp.device, dp=dp)
+    bn = ts.netG.dense_block1.denselayer1.norm1
+    init = dict(g=ts.optG.flat.clone().cpu(), d=ts.optD.flat.clone().cpu(), rm=bn.running_mean.clone().cpu())
+    g = torch.Generator().manual_seed(7 + rank)
+    gt = torch.rand(2, 3, 64, 64, generator=g).to(dp.device)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    snaps = {"g": [], "d": []}
+    orig = dist.all_reduce
+
+    def recording_all_reduce(t, op=dist.ReduceOp.SUM, async_op=False, **kw):
+        for key, opt in (("g", ts.optG), ("d", ts.optD)):
+            base, n = opt.grad.data_ptr(), opt.grad.numel()
+            if t.is_cuda and base <= t.data_ptr() < base + 4 * n:
+                snaps[key].append(((t.data_ptr() - base) // 4, t.detach().clone().cpu()))
+        return orig(t, op=op, async_op=async_op, **kw)
+    dist.all_reduce = recording_all_reduce
+    ts.optG.comm_events, ts.optD.comm_events = [], []
+    losses = ts.step(haze, gt)
+    dist.all_reduce = orig
+    torch.cuda.synchronize()
+    torch.save(dict(init=init, snaps=snaps, losses=losses, g_after=ts.optG.flat.cpu(), d_after=ts.optD.flat.cpu(),
+                    g_grad=ts.optG.grad.cpu(), d_grad=ts.optD.grad.cpu(), rm_after=bn.running_mean.cpu(),
+                    n_events=len(ts.optG.comm_events) + len(ts.optD.comm_events)), os.path.join(out_dir, "r%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_training_step_applies_the_mean_gradient(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(world)]
+    # replicas identical after the initial broadcast although the seeds differed
+    for k in ("g", "d", "rm"):
+        assert torch.equal(r[0]["init"][k], r[1]["init"][k]), k
+    for key, lr in (("g", 2e-4), ("d", 2e-4)):
+        n = r[0][key + "_grad"].numel()
+        local = []
+        for x in r:
+            full, cover = torch.zeros(n), torch.zeros(n, dtype=torch.bool)
+            for off, t in x["snaps"][key]:
+                assert not cover[off:off + t.numel()].any()          # every element reduced exactly once
+                full[off:off + t.numel()], cover[off:off + t.numel()] = t, True
+            assert bool(cover.all())
+            local.append(full)
+        assert not torch.equal(local[0], local[1])                   # different half-batches: different local gradients
+        mean = (local[0] + local[1]) / 2
+        for x in r:
+            assert torch.allclose(x[key + "_grad"], mean, rtol=1e-6, atol=1e-12), key
+        assert torch.equal(r[0][key + "_after"], r[1][key + "_after"]), key          # replicas stay bit-identical
+        # Adam's first step on the mean gradient: p - lr * g / (|g| + eps * sqrt(1 - beta2)) (bias-corrected), eps tiny
+        p0, gm = r[0]["init"][key], r[0][key + "_grad"]
+        m_hat, v_hat = gm, gm * gm
+        want = p0 - lr * m_hat / (v_hat.sqrt() + 1e-8)
+        assert torch.allclose(r[0][key + "_after"], want, rtol=0, atol=2e-7), float((r[0][key + "_after"] - want).abs().max())
+    assert len(r[0]["snaps"]["g"]) >= 2                                # the generator's gradient left in several slices
+    assert not torch.equal(r[0]["rm_after"], r[1]["rm_after"])         # BatchNorm statistics are per replica
+    assert r[0]["n_events"] == 2 and all(abs(v) < 1e4 for v in r[0]["losses"].values())
+
+
+def test_bench_py_runs_with_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` end to end (both ranks on cuda:0 over gloo
+    through bench.py's FDGAN_BENCH_SHARED_GPU hook): one JSON line from rank 0, whole-job images/s, the gradient-exchange
+    object with its isolated / exposed times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDGAN_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--size", "64"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(2 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-3)        # all ranks' images / slowest rank's time
+    ex = d["config"]["gradient_exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["bytes_per_step"] > 4e7 and ex["isolated_ms_per_step"] > 0 and 0.0 <= ex["hidden_fraction"] <= 1.0
+    assert d["cpu_baseline"] is None and "forward_only" not in d
