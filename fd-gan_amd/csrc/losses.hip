@@ -167,6 +167,76 @@ int mse_setup(const FdTensor* a, const FdTensor* b, const FdTensor* g, MseNhwcAr
   return FD_OK;
 }
 
+// ---- ContextualLoss rows (loss.py:49-68 of the reference's bytecode-only loss module) ------------------
+// For one row i of the cosine-distance matrix d[b][i][:] the chain  relative_distances -> weighted_average_distances ->
+// max over j  collapses to a softmax-style reduction:
+//     r_ij = d_ij / (dmin_i + e),  w_ij = exp((b - r_ij) / sigma),  cx_ij = w_ij / sum_j w_ij,
+//     m_i = max_j cx_ij = 1 / S_i,   S_i = sum_j exp(u_ij),   u_ij = (dmin_i - d_ij) / (sigma (dmin_i + e))   (b cancels)
+// so the three HW x HW intermediates (r, w, cx) of the torch formulation never exist.  One wave per row.
+// Backward, with g_i = dL/dm_i:  dL/dd_ij = g_i / S_i^2 * E_ij / (sigma (dmin_i + e))  for j != argmin, and for the argmin
+// (whose own term is identically 1)  - g_i / S_i^2 * sum_{j != j*} E_ij (d_ij + e) / (sigma (dmin_i + e)^2).
+struct CxArgs {
+  const float* d;        // [rows][n] contiguous
+  long long rows;
+  int n;
+  float sigma, eps;
+  float* m;              // [rows]   (forward out)
+  float* dmin;           // [rows]   (forward out, backward in)
+  float* S;              // [rows]
+  int* jmin;             // [rows]   first argmin
+  const float* gm;       // backward: dL/dm
+  float* gd;             // backward: dL/dd [rows][n]
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void cx_rows_kernel(CxArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const float* dr = a.d + row * a.n;
+  if (!BWD) {
+    float mn = 3.4e38f;
+    int jm = 0x7fffffff;
+    for (int j = lane; j < a.n; j += 64) {
+      const float v = dr[j];
+      if (v < mn) mn = v, jm = j;       // strided ascending: first occurrence within the lane
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) {
+      const float om = __shfl_xor(mn, dlt, 64);
+      const int oj = __shfl_xor(jm, dlt, 64);
+      if (om < mn || (om == mn && oj < jm)) mn = om, jm = oj;
+    }
+    const float inv = 1.f / (a.sigma * (mn + a.eps));
+    float s = 0.f;
+    for (int j = lane; j < a.n; j += 64) s += __expf((mn - dr[j]) * inv);
+    s = wave_sum(s);
+    if (lane == 0) {
+      a.m[row] = 1.f / s;
+      a.dmin[row] = mn;
+      a.S[row] = s;
+      a.jmin[row] = jm;
+    }
+  } else {
+    const float mn = a.dmin[row], s = a.S[row], g = a.gm[row];
+    const int jm = a.jmin[row];
+    const float inv = 1.f / (a.sigma * (mn + a.eps));
+    const float k = g / (s * s) * inv;                 // g / S^2 / (sigma (dmin + e))
+    float* gr = a.gd + row * a.n;
+    float acc = 0.f;
+    for (int j = lane; j < a.n; j += 64) {
+      const float dv = dr[j];
+      const float e = __expf((mn - dv) * inv);
+      if (j != jm) {
+        gr[j] = k * e;
+        acc += e * (dv + a.eps);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) gr[jm] = -k * acc / (mn + a.eps);
+  }
+}
+
 unsigned grid_for(long long work_items) {   // a few workgroups per CU, grid-stride beyond
   const long long nb = (work_items + 255) / 256;
   return (unsigned)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
@@ -216,4 +286,18 @@ extern "C" int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const fl
   m.scale = scale;
   m.upstream = upstream;
   return fd_launch(&mse_nhwc_kernel<true>, "mse_nhwc_bwd", dim3(grid_for(m.units)), dim3(256), 0, m, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_cx_rows_fwd(const float* d, int64_t rows, int64_t n, float sigma, float eps, float* m, float* dmin, float* S,
+                                 int32_t* jmin, FdStream stream) {
+  FD_REQUIRE(d && m && dmin && S && jmin && rows > 0 && n > 0 && n < (1ll << 30) && sigma > 0.f, "cx_rows_fwd: bad arguments");
+  CxArgs a{d, (long long)rows, (int)n, sigma, eps, m, dmin, S, jmin, nullptr, nullptr};
+  return fd_launch(&cx_rows_kernel<false>, "cx_rows_fwd", dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_cx_rows_bwd(const float* d, int64_t rows, int64_t n, float sigma, float eps, const float* dmin, const float* S,
+                                 const int32_t* jmin, const float* gm, float* gd, FdStream stream) {
+  FD_REQUIRE(d && dmin && S && jmin && gm && gd && rows > 0 && n > 0 && n < (1ll << 30) && sigma > 0.f, "cx_rows_bwd: bad arguments");
+  CxArgs a{d, (long long)rows, (int)n, sigma, eps, nullptr, const_cast<float*>(dmin), const_cast<float*>(S), const_cast<int*>(jmin), gm, gd};
+  return fd_launch(&cx_rows_kernel<true>, "cx_rows_bwd", dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
 }

@@ -100,6 +100,10 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_mse_nhwc_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p, C.c_float, C.POINTER(FdTensor),
                                      C.c_void_p]),
+    "fdgan_cx_rows_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "fdgan_cx_rows_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_maxpool2_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_maxpool2_bwd_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_blur15_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,

@@ -1,4 +1,4 @@
-"""MI355X-native `loss` module: the low/high-frequency extractors of the Fusion-discriminator.
+"""MI355X-native `loss` module: the low/high-frequency extractors of the Fusion-discriminator and ContextualLoss.
 
 The reference ships this file only as orphaned bytecode (/root/reference/__pycache__/
 loss.cpython-36.pyc; source `loss.py` absent).  Names, constructor signatures and semantics
@@ -13,6 +13,84 @@ import torch
 import torch.nn as nn
 
 from fdgan_hip import engine as E
+
+
+class _CxRowsFn(torch.autograd.Function):
+    """m[b, i] = max_j CX_ij of the cosine-distance matrix d (B, N, N): fdgan_cx_rows_fwd / _bwd (csrc/losses.hip)."""
+
+    @staticmethod
+    def forward(ctx, d, sigma, eps):
+        import ctypes as C
+        from fdgan_hip import lib as L
+        dd = d.detach().float().contiguous()
+        B, N, M = dd.shape
+        m = torch.empty((B, N), dtype=torch.float32, device=dd.device)
+        dmin, S = torch.empty_like(m), torch.empty_like(m)
+        jmin = torch.empty((B, N), dtype=torch.int32, device=dd.device)
+        L.check(L.load().fdgan_cx_rows_fwd(dd.data_ptr(), B * N, M, sigma, eps, m.data_ptr(), dmin.data_ptr(), S.data_ptr(),
+                                           jmin.data_ptr(), E.stream_ptr()), "cx_rows_fwd")
+        ctx.save_for_backward(dd, dmin, S, jmin)
+        ctx.sigma, ctx.eps = sigma, eps
+        return m
+
+    @staticmethod
+    def backward(ctx, gm):
+        from fdgan_hip import lib as L
+        dd, dmin, S, jmin = ctx.saved_tensors
+        B, N, M = dd.shape
+        gd = torch.empty_like(dd)
+        g = gm.detach().float().contiguous()
+        L.check(L.load().fdgan_cx_rows_bwd(dd.data_ptr(), B * N, M, ctx.sigma, ctx.eps, dmin.data_ptr(), S.data_ptr(), jmin.data_ptr(),
+                                           g.data_ptr(), gd.data_ptr(), E.stream_ptr()), "cx_rows_bwd")
+        return gd, None, None
+
+
+class ContextualLoss(nn.Module):
+    """loss.py:23-73 of the reference (bytecode only): same constructor, same methods.
+
+    `forward(I, T)` = CX(cos_similarity(I, T)) on (B, C, H, W) feature maps.  The centring / L2 normalisation and the final
+    -log / means are a handful of elementwise device ops; the cosine matrix is one batched library GEMM (B x HW x HW x C,
+    fp32); everything between the matrix and the per-row maximum -- relative_distances, weighted_average_distances, the max
+    over j: three HW x HW intermediates in the reference -- is ONE fused HIP pass per row, forward and backward
+    (fdgan_cx_rows_*).  GPU tensors only: the reference hard-codes .cuda() throughout this module as well."""
+
+    def __init__(self, sigma=0.1, b=1.0, epsilon=1e-5, similarity='cos'):
+        super().__init__()
+        self.sigma, self.similarity, self.b, self.e = sigma, similarity, b, epsilon
+
+    def cos_similarity(self, image_features, target_features):
+        E.require_gpu(image_features, "ContextualLoss")
+        E.require_gpu(target_features, "ContextualLoss")
+        if image_features.shape != target_features.shape or image_features.dim() != 4:
+            raise ValueError("ContextualLoss expects two (B, C, H, W) tensors of the same shape")
+        B, C = image_features.size(0), image_features.size(1)
+        i = image_features.float().reshape(B, C, -1).permute(0, 2, 1)
+        t = target_features.float().reshape(B, C, -1).permute(0, 2, 1)
+        mu = t.mean(dim=1, keepdim=True)
+        ic, tc = i - mu, t - mu
+        il = ic / torch.sqrt((ic * ic).sum(dim=2, keepdim=True))
+        tl = tc / torch.sqrt((tc * tc).sum(dim=2, keepdim=True))
+        return 1 - torch.bmm(il, tl.permute(0, 2, 1))
+
+    def L2_similarity(self, image_features, target_features):      # a stub in the reference too (loss.py:46-47)
+        pass
+
+    def relative_distances(self, distances):
+        return distances / (distances.min(dim=2, keepdim=True)[0] + self.e)
+
+    def weighted_average_distances(self, distances_normalized):
+        w = torch.exp((self.b - distances_normalized) / self.sigma)
+        return w / w.sum(dim=2, keepdim=True)
+
+    def CX(self, distances):
+        E.require_gpu(distances, "ContextualLoss.CX")
+        m = _CxRowsFn.apply(distances, float(self.sigma), float(self.e))     # == max_j weighted_average(relative(d)); b cancels
+        return torch.mean(-torch.log(torch.mean(m, dim=1)))
+
+    def forward(self, image_features, target_features):
+        if self.similarity != 'cos':
+            raise NotImplementedError("only similarity='cos' exists in the reference (L2_similarity is `pass`)")
+        return self.CX(self.cos_similarity(image_features, target_features))
 
 
 def isotropic_gaussian_kernel(l, sigma, tensor=True):

@@ -338,6 +338,16 @@ int fdgan_mse_nhwc_fwd(const FdTensor* a, const FdTensor* b, float scale, float*
 int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, const FdTensor* g,
                        FdStream stream);
 
+/* ContextualLoss (the reference's bytecode-only loss module, original loss.py:23-73): the row part.
+ * d: cosine distances [rows = B*HW][n = HW] fp32 contiguous.  relative_distances -> weighted_average_distances -> max over
+ * j collapse to m_i = 1 / sum_j exp((dmin_i - d_ij) / (sigma (dmin_i + eps))) (the constant b cancels): one fused pass per
+ * row instead of three HW x HW intermediates.  fwd writes m and the per-row (dmin, S, first argmin) the backward needs;
+ * bwd writes gd = dL/dd from gm = dL/dm. */
+int fdgan_cx_rows_fwd(const float* d, int64_t rows, int64_t n, float sigma, float eps, float* m, float* dmin, float* S,
+                      int32_t* jmin, FdStream stream);
+int fdgan_cx_rows_bwd(const float* d, int64_t rows, int64_t n, float sigma, float eps, const float* dmin, const float* S,
+                      const int32_t* jmin, const float* gm, float* gd, FdStream stream);
+
 /* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);

@@ -100,3 +100,31 @@ def test_vgg_backward_detects_overwritten_activations(LS):
     LS.vgg_perceptual(vgg, x.detach(), x.detach())            # runs slot 0 and 1 again
     with pytest.raises(RuntimeError, match="overwritten"):
         l.backward()
+
+
+def test_contextual_loss_matches_the_oracle_restatement():
+    """loss.ContextualLoss (fused row kernel) vs oracle/contextual_ref.py (the bytecode's torch formulation, fp32 CPU): value,
+    gradient w.r.t. the image features, the unfused method chain, and non-default sigma / b."""
+    import loss as hl
+    from oracle import contextual_ref as cr
+    for (shape, kw) in (((2, 64, 12, 10), {}), ((1, 512, 32, 32), {}), ((3, 16, 7, 9), dict(sigma=0.25, b=0.5))):
+        I, T = seeded(shape, 11, -1, 1), seeded(shape, 12, -1, 1)
+        I = 0.6 * I + 0.4 * T                                     # correlated features: a non-trivial best match per row
+        Ir = I.clone().requires_grad_(True)
+        lr = cr.ContextualLoss(**kw)(Ir, T)
+        lr.backward()
+        Id = I.to(DEV).requires_grad_(True)
+        mod = hl.ContextualLoss(**kw)
+        l = mod(Id, T.to(DEV))
+        l.backward()
+        assert abs(float(l) - float(lr)) < 2e-4 * max(1.0, abs(float(lr))), (float(l), float(lr))
+        rel = float((Id.grad.cpu() - Ir.grad).norm() / Ir.grad.norm())
+        assert rel < 5e-3, rel
+        with torch.no_grad():                                     # the reference's own method chain on the same matrix
+            d = mod.cos_similarity(Id, T.to(DEV))
+            cx = mod.weighted_average_distances(mod.relative_distances(d))
+            m_ref = cx.permute(0, 2, 1).max(dim=1)[0]
+            m = hl._CxRowsFn.apply(d, float(mod.sigma), float(mod.e))
+            assert ((m - m_ref).abs() / m_ref).max() < 1e-4
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hl.ContextualLoss()(torch.rand(1, 4, 3, 3), torch.rand(1, 4, 3, 3))

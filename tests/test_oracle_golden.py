@@ -182,3 +182,54 @@ def test_oracle_reproduces_wellconditioned_reference_gradients(golden_dir):
         assert np.abs(proj - gold[key]).max() < 1e-4 * scale + 1e-9, name
         n += 1
     assert n == 282
+
+
+def test_loss_module_restatements_are_pinned_to_the_reference_bytecode(golden_dir):
+    """tests/golden/loss_pyc_constants.json = names / constants / line numbers extracted from the reference's
+    __pycache__/loss.cpython-36.pyc (oracle/pin_loss_pyc.py); the Blur / Laplacian / ContextualLoss restatements must
+    carry exactly those constants, defaults and call structure."""
+    import inspect
+    import json
+    from oracle import contextual_ref
+    t = json.load(open(os.path.join(golden_dir, "loss_pyc_constants.json")))
+    assert t["__header__"]["magic"] == 3379 and t["__header__"]["source"].endswith("loss.py")
+    mod = t["<module>"]
+    # blur_kernel = isotropic_gaussian_kernel(l=15, sigma=3.0); blur = Blur(l=15, kernel=blur_kernel); laplace_filter = Laplacian(3)
+    for name in ("blur_kernel", "blur", "laplace_filter", "isotropic_gaussian_kernel", "Blur", "Laplacian", "ContextualLoss"):
+        assert name in mod["names"], name
+    assert 15 in mod["consts"] and 3.0 in mod["consts"] and ["l", "sigma"] in mod["consts"] and ["l", "kernel"] in mod["consts"]
+    assert 3 in mod["consts"] and ["kernel_size"] in mod["consts"]
+    sig = inspect.signature(freqsplit_ref.blur)
+    assert sig.parameters["l"].default == 15 and sig.parameters["sigma"].default == 3.0 and sig.parameters["use_input_norm"].default is True
+    # Blur.__init__(self, l=15, kernel=None, use_input_norm=True): ReflectionPad2d(l // 2), ImageNet mean / std buffers
+    assert t["Blur"]["consts"].count(15) >= 1 and [15, None, True] in t["Blur"]["consts"]
+    bi = t["Blur.__init__"]
+    assert bi["args"] == ["self", "l", "kernel", "use_input_norm"] and "ReflectionPad2d" in bi["names"] and 2 in bi["consts"]
+    assert [c for c in bi["consts"] if isinstance(c, float)] == list(freqsplit_ref.IMAGENET_MEAN) + list(freqsplit_ref.IMAGENET_STD)
+    assert "conv2d" in t["Blur.forward"]["names"] and "pad" in t["Blur.forward"]["names"]
+    ig = t["isotropic_gaussian_kernel"]
+    assert ig["args"] == ["l", "sigma", "tensor"] and {"arange", "meshgrid", "exp", "sum"} <= set(ig["names"]) and 2.0 in ig["consts"]
+    # Laplacian: ones(k, k) with centre 1 - k^2, conv2d(padding=, stride=, groups=), padding (k - 1) // 2
+    assert "ones" in t["get_laplacian_kernel2d"]["names"] and 2 in t["get_laplacian_kernel2d"]["consts"]
+    lf = t["Laplacian.forward"]
+    assert ["padding", "stride", "groups"] in lf["consts"] and "repeat" in lf["names"] and 4 in lf["consts"]
+    assert t["Laplacian.compute_zero_padding"]["consts"][1:] == [1, 2]
+    assert float(freqsplit_ref.laplacian_kernel2d(3)[1, 1]) == -8.0 and float(freqsplit_ref.laplacian_kernel2d(5)[2, 2]) == -24.0
+    # ContextualLoss(sigma=0.1, b=1.0, epsilon=1e-5, similarity='cos') and its methods, at the bytecode's line numbers
+    cl = t["ContextualLoss"]
+    assert [0.1, 1.0, 1e-05, "cos"] in cl["consts"]
+    d = inspect.signature(contextual_ref.ContextualLoss.__init__).parameters
+    assert [d[k].default for k in ("sigma", "b", "epsilon", "similarity")] == [0.1, 1.0, 1e-05, "cos"]
+    lines = {"__init__": 24, "cos_similarity": 31, "L2_similarity": 46, "relative_distances": 49,
+             "weighted_average_distances": 53, "CX": 59, "forward": 70}
+    for meth, line in lines.items():
+        assert t["ContextualLoss." + meth]["line"] == line and hasattr(contextual_ref.ContextualLoss, meth)
+    assert {"mean", "sqrt", "sum", "bmm", "permute", "div"} <= set(t["ContextualLoss.cos_similarity"]["names"])
+    assert {"min", "e"} <= set(t["ContextualLoss.relative_distances"]["names"])
+    assert {"exp", "b", "sigma", "sum", "div"} <= set(t["ContextualLoss.weighted_average_distances"]["names"])
+    assert {"max", "mean", "log", "permute"} <= set(t["ContextualLoss.CX"]["names"])
+    # a known answer: identical features -> every row's best match is itself with distance 0 -> CX close to its maximum
+    torch.manual_seed(0)
+    f = torch.rand(2, 8, 5, 5)
+    same, other = contextual_ref.ContextualLoss()(f, f.clone()), contextual_ref.ContextualLoss()(f, torch.rand(2, 8, 5, 5))
+    assert float(same) < 1e-3 and float(other) > float(same) + 0.1
