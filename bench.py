@@ -185,7 +185,7 @@ def train_bench(a, dp, dev, B, S):
     import train as train_mod
     from fdgan_hip import engine as E
     world, rank = dp.world, dp.rank
-    ts = train_mod.TrainStep(dev, dp=dp)
+    ts = train_mod.TrainStep(dev, dp=dp, synthetic=True)     # random-init weights of the reference architecture (no network for checkpoints)
     gt = torch.from_numpy(np.random.default_rng(99 + rank).random((B, 3, S, S), dtype=np.float32)).to(dev)
     haze = (gt * 0.6 + 0.3).clamp(0, 1)
     for _ in range(max(a.warmup, 1)):

@@ -72,7 +72,10 @@ def run(opt):
         names = dp.item_indices(len(loader.dataset))
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(loader.dataset, names), batch_size=1,
                                              shuffle=False, num_workers=int(opt.workers))
-    netG = net.FDGAN()
+    import warnings
+    with warnings.catch_warnings():           # "encoder randomly initialised": the checkpoint below overwrites every tensor
+        warnings.simplefilter("ignore")
+        netG = net.FDGAN()
     sd = load_generator_state(opt.netG)
     missing = [k for k in netG.state_dict() if k not in sd]
     if any(not k.endswith('num_batches_tracked') for k in missing):

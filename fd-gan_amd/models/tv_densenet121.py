@@ -75,6 +75,41 @@ class DenseNet121(nn.Module):
 
 
 def densenet121(pretrained=False, **_):
-    """`pretrained` is accepted for signature compatibility; ImageNet weights are not
-    available offline -- load a checkpoint with `load_state_dict` instead."""
+    """`pretrained=True` (what /root/reference/models/dehaze1113.py:707 asks torchvision for) cannot be honoured offline: the
+    encoder comes back RANDOMLY initialised and a warning says so -- load the authors' checkpoint (demo.py --netG) or a
+    torchvision densenet121 state_dict with `load_densenet121_weights` before training on the result."""
+    if pretrained:
+        import warnings
+        warnings.warn("densenet121(pretrained=True): ImageNet weights are not available offline; the DenseNet-121 encoder is "
+                      "randomly initialised.  Load a checkpoint (FDGAN.load_state_dict / models.tv_densenet121."
+                      "load_densenet121_weights) before relying on it.", stacklevel=2)
     return DenseNet121()
+
+
+def load_densenet121_weights(fdgan, path):
+    """Copies a torchvision densenet121 state_dict (features.conv0 / denseblockN / transitionN / norm5; both the 0.2-era
+    `norm.1` and the current `norm1` spellings) into the encoder modules FDGAN pulled out of it
+    (dehaze1113.py:707-728: conv0, dense_block1-3, trans_block1-3 as used by forward)."""
+    import re
+    import torch
+    sd = torch.load(path, map_location="cpu")
+    sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+    ren = {"features.conv0.": "conv0.", "features.norm0.": "norm0.", "features.denseblock1.": "dense_block1.",
+           "features.denseblock2.": "dense_block2.", "features.denseblock3.": "dense_block3.",
+           "features.transition1.": "trans_block1.", "features.transition2.": "trans_block2.", "features.transition3.": "trans_block3."}
+    own = fdgan.state_dict()
+    picked = {}
+    for k, v in sd.items():
+        k = re.sub(r"\.(norm|relu|conv)\.([12])\.", r".\1\2.", k[7:] if k.startswith("module.") else k)
+        for src, dst in ren.items():
+            if k.startswith(src) and dst + k[len(src):] in own:
+                picked[dst + k[len(src):]] = v
+    if not picked:
+        raise KeyError("%s holds no torchvision densenet121 encoder keys (features.denseblock1...)" % path)
+    missing = [k for k in own if k.split(".")[0] in ("dense_block1", "dense_block2", "dense_block3", "trans_block1", "trans_block2",
+                                                     "trans_block3") and k not in picked and not k.endswith("num_batches_tracked")]
+    if missing:
+        raise KeyError("densenet121 checkpoint lacks %d encoder tensors, e.g. %s" % (len(missing), missing[:3]))
+    fdgan.load_state_dict(picked, strict=False)
+    fdgan.encoder_weights_loaded = True
+    return fdgan

@@ -34,13 +34,33 @@ from myutils.vgg16 import Vgg16
 
 class TrainStep:
     def __init__(self, device, lrG=2e-4, lrD=2e-4, beta1=0.5, w_adv=0.01, w_perc=1.0, w_ssim=1.0, w_l1=1.0, pool_size=50,
-                 dp=None):
+                 dp=None, vgg_weights=None, densenet_weights=None, synthetic=False):
+        """vgg_weights: vgg16.weight / torchvision VGG16 state_dict / vgg16.t7 (myutils.utils.load_vgg16_weights);
+        densenet_weights: torchvision densenet121 state_dict for the generator's encoder.  The reference trains on an
+        ImageNet-pretrained encoder (dehaze1113.py:707) and a pretrained, frozen VGG16 (myutils/utils.py:84-94): without the
+        files both are RANDOM here, which only `synthetic=True` (benchmarks, tests) accepts silently."""
+        import warnings
         self.dev = device
-        self.netG = net.FDGAN().to(device)
-        self.netD = net.D(9, 36).to(device)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                 # the pretrained=True warning is replaced by the explicit check below
+            self.netG = net.FDGAN()
         self.netG.apply(misc.weights_init)
+        if densenet_weights:
+            from models.tv_densenet121 import load_densenet121_weights
+            load_densenet121_weights(self.netG, densenet_weights)
+        self.netG = self.netG.to(device)
+        self.netD = net.D(9, 36).to(device)
         self.netD.apply(misc.weights_init)
-        self.vgg = Vgg16().to(device)                       # the reference loads pretrained VGG16 weights; frozen
+        self.vgg = Vgg16()                                  # the reference loads pretrained VGG16 weights; frozen
+        if vgg_weights:
+            from myutils.utils import load_vgg16_weights
+            load_vgg16_weights(self.vgg, vgg_weights)
+        self.vgg = self.vgg.to(device)
+        if not synthetic and not (vgg_weights and densenet_weights):
+            warnings.warn("TrainStep: %s randomly initialised (no weight file given) -- the reference uses ImageNet-pretrained "
+                          "networks there; pass vgg_weights= / densenet_weights= (train.py --vgg / --densenet)"
+                          % " and ".join(n for n, w in (("the VGG16 perceptual network is", vgg_weights),
+                                                         ("the DenseNet-121 encoder is", densenet_weights)) if not w))
         for p in self.vgg.parameters():
             p.requires_grad_(False)
         # Only parameters that can receive a gradient go into the optimizer: FDGAN registers 2.2 M that never do
@@ -127,10 +147,13 @@ def main():
     ap.add_argument("--lrG", type=float, default=0.0002)
     ap.add_argument("--lrD", type=float, default=0.0002)
     ap.add_argument("--beta1", type=float, default=0.5)
+    ap.add_argument("--vgg", default="", help="pretrained VGG16: vgg16.weight, a torchvision state_dict or vgg16.t7")
+    ap.add_argument("--densenet", default="", help="torchvision densenet121 state_dict for the generator's encoder")
     opt = ap.parse_args()
     dp = DpContext.from_env()
     dev = dp.device or torch.device("cuda", 0)
-    ts = TrainStep(dev, opt.lrG, opt.lrD, opt.beta1, dp=dp)
+    ts = TrainStep(dev, opt.lrG, opt.lrD, opt.beta1, dp=dp, vgg_weights=opt.vgg or None, densenet_weights=opt.densenet or None,
+                   synthetic=not (opt.vgg or opt.densenet))
     g = torch.Generator(device="cpu").manual_seed(1234 + dp.rank)
     for it in range(opt.niter):
         gt = torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)

@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir):
     from fdgan_hip.dp import DpContext
     dp = DpContext.from_env(backend="gloo", device=torch.device("cuda", 0))
     torch.manual_seed(100 + rank)                          # replicas start DIFFERENT: the broadcast has to fix that
-    ts = train_mod.TrainStep(dp.device, dp=dp)
+    ts = train_mod.TrainStep(dp.device, dp=dp, synthetic=True)
     bn = ts.netG.dense_block1.denselayer1.norm1
     init = dict(g=ts.optG.flat.clone().cpu(), d=ts.optD.flat.clone().cpu(), rm=bn.running_mean.clone().cpu())
     g = torch.Generator().manual_seed(7 + rank)

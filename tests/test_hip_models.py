@@ -787,7 +787,7 @@ def test_training_step_smoke():
     """Two full training steps (G + Fusion-D + VGG16 + SSIM, Adam) at a small size: finite losses, both networks'
     parameters move, BatchNorm statistics advance, and the forward-before-backward guard fires."""
     import train
-    ts = train.TrainStep(torch.device(DEV))
+    ts = train.TrainStep(torch.device(DEV), synthetic=True)
     g = torch.Generator().manual_seed(7)
     gt = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
     haze = (gt * 0.6 + 0.3).clamp(0, 1)
@@ -824,7 +824,7 @@ def test_training_step_matches_oracle_step():
     import train
     from oracle.train_ref import TrainStepRef
     from oracle.detweights import det_input
-    ts = train.TrainStep(torch.device(DEV))
+    ts = train.TrainStep(torch.device(DEV), synthetic=True)
     sd_g = {k: v.detach().cpu().clone() for k, v in ts.netG.state_dict().items()}
     sd_d = {k: v.detach().cpu().clone() for k, v in ts.netD.state_dict().items()}
     sd_v = {k: v.detach().cpu().clone() for k, v in ts.vgg.state_dict().items()}
