@@ -313,8 +313,16 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   const long long item_stride = ci_tiles * zt * NW * C::TAPS * 512, item_floats = item_stride + (dbias ? ctiles * 32 : 0);
   if (strips * item_floats > workspace_floats || strips >= 65536) return 1;   // caller falls back to the per-tap kernel
   static const char* wgs_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
-  long long segs = (wgs_env ? atoll(wgs_env) : 256) / (strips * ci_tiles * zt);   // one resident workgroup per CU
+  const long long base = strips * ci_tiles * zt;
+  long long segs = (wgs_env ? atoll(wgs_env) : 256) / base;   // one resident workgroup per CU
   if (segs < 1) segs = 1;
+  if (!wgs_env && a.Cout > 32) {
+    // MFMA-bound shapes (D, the wide 3x3): two workgroups fit a CU (LDS), so fill 512 slots; and a grid just past a
+    // multiple of the resident capacity (D's 4x4 144 -> 288: 576 workgroups = 1.125 rounds) runs a nearly empty last
+    // round -- split the rows once more (measured 909 -> 805 us; 72 -> 144: 219 -> 185 us)
+    if (base < 200) segs = (1024 + base - 1) / base;   // 256-workgroup grids (160 -> 128, 512 -> 128) measured WORSE when split
+    else if (base % 512 != 0 && base % 512 <= 256 && base < 2048) segs = 2;
+  }
   if (segs > (a.Ho + 1) / 2) segs = (a.Ho + 1) / 2;             // at least 2 rows per item (KYN - 1 halo rows re-staged per item)
   while (segs > 1 && (strips * segs * item_floats > workspace_floats || strips * segs >= 65536)) --segs;
   a.seg_rows = (int)((a.Ho + segs - 1) / segs);
