@@ -926,6 +926,22 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
   a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
+  // the few-channel convs at the ends of the networks (3 -> 64, 16 -> 3, 9 -> 36 stride 2): one GEMM over all taps
+  if (workspace != nullptr && !pool && a.Cin <= 16 && cout <= 64) {
+    long long ns = 0;
+    hipStream_t sts = static_cast<hipStream_t>(stream);
+    const int rcs = conv_wgrad_small_launch(x, dy, cout, d->ksize, d->stride, d->pad, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var,
+                                            a.p_gamma, a.p_beta, dbias != nullptr, workspace, workspace_floats, &ns, sts);
+    if (rcs < 0) return rcs;
+    if (rcs == 0) {
+      const long long numels = (long long)cout * a.Cin * d->ksize * d->ksize;
+      WredArgs rs{workspace, dw, numels, (int)ns, accumulate};
+      if (int rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numels + 63) / 64)), dim3(256), 0, rs, sts)) return rc;
+      if (dbias == nullptr) return FD_OK;
+      WredArgs rb{workspace + ns * numels, dbias, cout, (int)ns, accumulate};
+      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, rb, sts);
+    }
+  }
   // row-walking transpose-read kernels (conv_wgrad_tr.hip): the growth conv and the discriminator's 4x4 conv
   const int trv = workspace != nullptr ? conv_wgrad_tr_variant(cout, a.Cin, d->ksize, d->stride, d->pad, pool) : 0;
   if (trv != 0) {

@@ -929,6 +929,10 @@ bool conv_wgrad1x1_tr_fits(const FdTensor* x, const FdTensor* dy, int cout, int 
 int conv_wgrad1x1_tr_launch(const FdTensor* x, const FdTensor* dy, int pro_mode, float p_slope, float eps, const float* mean,
                             const float* var, const float* gamma, const float* beta, float* workspace, long long workspace_floats,
                             long long* nsplit_out, hipStream_t stream);
+// few-channel weight gradient as one GEMM over all taps (conv_wgrad_small.hip)
+int conv_wgrad_small_launch(const FdTensor* x, const FdTensor* dy, int cout, int ksize, int stride, int pad, int pro_mode, float p_slope,
+                            float eps, const float* mean, const float* var, const float* gamma, const float* beta, bool want_bias,
+                            float* workspace, long long workspace_floats, long long* nsplit_out, hipStream_t stream);
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
                          float* dbias, int accumulate, hipStream_t stream);

@@ -409,3 +409,53 @@ def test_flat_adam_matches_torch_adam():
     before = o_hip.flat.clone()
     o_hip.step()
     assert torch.equal(before, o_hip.flat)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,bn,slope,n,h,w", [
+    (3, 64, 3, 1, 1, False, 1.0, 2, 37, 29),       # FDGAN.conv_refin1 (bias), ragged last pixel tile
+    (16, 3, 3, 1, 1, False, 0.0, 3, 24, 40),       # FDGAN.conv_refin3 (bias; ReLU prologue; N = 144 + the bias column)
+    (9, 36, 4, 2, 1, False, 1.0, 2, 64, 48),       # D.layer1: 4x4 stride 2
+    (12, 20, 3, 1, 1, True, 0.2, 1, 19, 23),       # BatchNorm + LeakyReLU prologue, odd sizes
+    (3, 64, 3, 1, 1, False, 1.0, 16, 256, 256)])   # full size: 8192 pixel tiles over 512 persistent workgroups
+def test_weight_gradient_few_channel_kernel(E, cin, cout, k, stride, pad, bn, slope, n, h, w):
+    """conv_wgrad_small (all taps x all input channels as the N dimension of one GEMM, bias as a column of ones) vs an
+    fp64 statement; deterministic; accumulates onto an existing gradient."""
+    from fdgan_hip import lib as L
+    x = bf16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = bf16_round(seeded((n, cout, ho, wo), 2, -1.0, 1.0))
+    p = _bn_params(cin, 10) if bn else None
+    act = {0.0: L.ACT_RELU, 0.2: L.ACT_LEAKY02, 1.0: L.ACT_NONE}[slope]
+    a = x
+    if bn:
+        sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
+        sh = (p["beta"] - p["mean"] * sc).float()
+        a = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    a = bf16_round(torch.where(a > 0, a, a * slope)).double()
+    dev_ref = n * h * w > 200000                      # the fp64 reference of the full-size case runs on the GPU
+    wref = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True, device=DEV if dev_ref else "cpu")
+    F.conv2d(a.to(wref.device), wref, None, stride, pad).backward(dy.double().to(wref.device))
+    gref = wref.grad.cpu()
+    xb, dyb = _nhwc(x), _nhwc(dy)
+    pro = None
+    if bn or act != L.ACT_NONE:
+        kw = dict(act=act)
+        if bn:
+            d = {kk: v.to(DEV) for kk, v in p.items()}
+            kw.update(mean=d["mean"], var=d["var"], gamma=d["gamma"], beta=d["beta"], eps=1e-5)
+        pro = E.make_prologue(**kw)
+    ws = torch.zeros(1 << 24, dtype=torch.float32, device=DEV)
+    desc = E.conv_desc(k, stride, pad, cout=cout)
+    dw = torch.full((cout, cin, k, k), 1.0, dtype=torch.float32, device=DEV)
+    db = torch.full((cout,), 2.0, dtype=torch.float32, device=DEV)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, desc, dw, db, ws, True)       # accumulate
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, desc, dw2, db2, ws, False)
+    dw3 = torch.empty_like(dw)
+    E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, desc, dw3, None, ws, False)  # no bias column
+    torch.cuda.synchronize()
+    assert rel_rms(dw2.cpu().double(), gref) < 2e-3, rel_rms(dw2.cpu().double(), gref)
+    assert rel_rms(dw.cpu().double() - 1.0, gref) < 2e-3
+    bref = dy.double().sum(dim=(0, 2, 3))
+    assert rel_rms(db2.cpu().double(), bref) < 1e-3 and rel_rms(db.cpu().double() - 2.0, bref) < 1e-3
+    assert torch.equal(dw2, dw3)
