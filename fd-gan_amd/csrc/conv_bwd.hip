@@ -467,6 +467,9 @@ struct BnActBwdArgs {
   const float *mean, *var, *gamma, *beta;
   float* partial;   // [rows][cpad][2] or NULL (no norm)
   int cpad;
+  // pool != 0 (the transitions' pooled prologue): `da` is the gradient w.r.t. the 2x2-AVERAGED activation at half
+  // resolution; pixel (y, x) takes da[y/2][x/2] / 4 (the un-pool), dpre is NOT written back -- only the sums leave
+  int pool;
 };
 
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
         if (p < a.P) {
           const long long n = p / HW, r = p - n * HW;
           const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-          dp[k] = a.da + n * a.da_sn + (long long)y * a.da_sh + (long long)xx * a.da_sw + c8 * 8;
+          dp[k] = a.da + n * a.da_sn + (long long)(a.pool ? y >> 1 : y) * a.da_sh + (long long)(a.pool ? xx >> 1 : xx) * a.da_sw + c8 * 8;
           dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
           xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
         }
@@ -518,11 +521,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
         for (int e = 0; e < 8; ++e) {
           const float pre = fmaf(xf[e], sc[e], sh[e]);
           const float gsl = pre > 0.f ? 1.f : a.slope;   // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
-          o[e] = d[e] * gsl;
+          o[e] = d[e] * (a.pool ? 0.25f * gsl : gsl);
           s1[e] += o[e];
           s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
         }
-        *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+        if (!a.pool) *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
       }
     }
     if (a.partial != nullptr) {
@@ -639,6 +642,11 @@ struct BnApplyArgs {
   float eps, inv_m;
   const float *mean, *var, *gamma, *dbeta, *dgamma;
   int accumulate;
+  // pool != 0: `dpre` is the half-resolution gradient w.r.t. the pooled activation; dpre(y, x) = it[y/2][x/2] / 4 *
+  // act'(bn(x)) is formed on the fly (the mask needs beta and the activation slope)
+  int pool;
+  const float* beta;
+  float slope;
 };
 // dx = A[c] * dpre + B[c] * x + C[c] with A = gamma*rstd, B = -gamma*rstd^2*dgamma/M, C = -A*dbeta/M - B*mean:
 // a thread keeps one 8-channel group (24 coefficients in registers) and walks pixels with a grid stride.
@@ -648,16 +656,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
   {   // one 64-channel chunk per blockIdx.y
     const int c8 = blockIdx.y * 8 + grp;
     if (c8 >= a.C8) return;
-    float A[8], B[8], Cc[8];
+    float A[8], B[8], Cc[8], Sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = c8 * 8 + e;
-      A[e] = B[e] = Cc[e] = 0.f;
+      A[e] = B[e] = Cc[e] = Sh[e] = 0.f;
       if (c < a.C) {
         const float rs = 1.f / sqrtf(a.var[c] + a.eps), gmm = a.gamma ? a.gamma[c] : 1.f;
         A[e] = gmm * rs;
         B[e] = -gmm * rs * rs * a.dgamma[c] * a.inv_m;
         Cc[e] = -A[e] * a.dbeta[c] * a.inv_m - B[e] * a.mean[c];
+        Sh[e] = (a.beta ? a.beta[c] : 0.f) - a.mean[c] * A[e];     // bn(x) = A x + Sh
       }
     }
     // four pixels per iteration: 8-12 independent 16-byte loads in flight per thread (the single-pixel loop ran
@@ -673,7 +682,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
         if (p < a.P) {
           const long long n = p / HW, r = p - n * HW;
           const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-          dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)y * a.dp_sh + (long long)xx * a.dp_sw + c8 * 8);
+          dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)(a.pool ? y >> 1 : y) * a.dp_sh +
+                                                  (long long)(a.pool ? xx >> 1 : xx) * a.dp_sw + c8 * 8);
           xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
           op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
           if (a.accumulate) gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
@@ -688,7 +698,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
         if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float v = fmaf(A[e], d[e], fmaf(B[e], xf[e], Cc[e]));
+          float de = d[e];
+          if (a.pool) de *= fmaf(A[e], xf[e], Sh[e]) > 0.f ? 0.25f : 0.25f * a.slope;
+          const float v = fmaf(A[e], de, fmaf(B[e], xf[e], Cc[e]));
           o[e] = a.accumulate ? o[e] + v : v;
         }
         *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
@@ -1053,8 +1065,13 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
                                 int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
   if (int rc = check_view(da, "bn_act_bwd(da)")) return rc;
   if (int rc = check_view(x, "bn_act_bwd(x)")) return rc;
-  FD_REQUIRE(da->n == x->n && da->h == x->h && da->w == x->w && da->c == x->c, "bn_act_bwd: da / x shape mismatch");
+  const bool pooled = pro && pro->pool2;
+  FD_REQUIRE(da->n == x->n && da->c == x->c && (pooled ? (da->h == x->h / 2 && da->w == x->w / 2 && x->h % 2 == 0 && x->w % 2 == 0)
+                                                       : (da->h == x->h && da->w == x->w)),
+             "bn_act_bwd: da / x shape mismatch");
+  FD_REQUIRE(!pooled || (pro->mean && partial), "bn_act_bwd: the pooled form only produces the BatchNorm sums");
   BnActBwdArgs a{};
+  a.pool = pooled ? 1 : 0;
   a.da = static_cast<unsigned short*>(da->ptr);
   a.da_sn = da->stride[0], a.da_sh = (int)da->stride[1], a.da_sw = (int)da->stride[2];
   a.x = static_cast<const unsigned short*>(x->ptr);
@@ -1229,10 +1246,16 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   if (int rc = check_view(x, "bn_bwd_apply(x)")) return rc;
   if (int rc = check_view(dx, "bn_bwd_apply(dx)")) return rc;
   FD_REQUIRE(pro && pro->mean && pro->var && dgamma && dbeta, "bn_bwd_apply: needs the forward batch statistics and dgamma/dbeta");
-  FD_REQUIRE(dpre->n == x->n && dpre->h == x->h && dpre->w == x->w && dpre->c == x->c && dx->n == x->n && dx->h == x->h &&
-                 dx->w == x->w && dx->c == x->c,
+  const bool pooled = pro->pool2 != 0;
+  FD_REQUIRE(dpre->n == x->n && dpre->c == x->c && dx->n == x->n && dx->h == x->h && dx->w == x->w && dx->c == x->c &&
+                 (pooled ? (dpre->h == x->h / 2 && dpre->w == x->w / 2 && x->h % 2 == 0 && x->w % 2 == 0)
+                         : (dpre->h == x->h && dpre->w == x->w)),
              "bn_bwd_apply: shape mismatch");
+  FD_REQUIRE(pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU || pro->act == FD_ACT_LEAKY02, "bn_bwd_apply: prologue activation %d", pro->act);
   BnApplyArgs a{};
+  a.pool = pooled ? 1 : 0;
+  a.beta = pro->beta;
+  a.slope = pro->act == FD_ACT_RELU ? 0.f : (pro->act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   a.dpre = static_cast<const unsigned short*>(dpre->ptr);
   a.dp_sn = dpre->stride[0], a.dp_sh = (int)dpre->stride[1], a.dp_sw = (int)dpre->stride[2];
   a.x = static_cast<const unsigned short*>(x->ptr);

@@ -115,6 +115,7 @@ struct MseNhwcArgs {
   long long units;           // N * H * W * C8 pieces of 8 channels
   float scale;
   const float* upstream;     // backward: device scalar (d total / d this loss)
+  int relu_mask;             // backward: g = 0 where a == 0 (a is a ReLU output: its pre-activation was <= 0 there)
   unsigned short* g;         // backward: gradient view (bf16)
   float* partial;            // forward
 };
@@ -136,8 +137,14 @@ __global__ __launch_bounds__(256) void mse_nhwc_kernel(MseNhwcArgs a) {
     const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, av), f32x8) -
                     __builtin_convertvector(__builtin_bit_cast(bf16x8, bv), f32x8);
     if (BWD) {
+      f32x8 gv = d * up;
+      if (a.relu_mask) {
+        const f32x8 af = __builtin_convertvector(__builtin_bit_cast(bf16x8, av), f32x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = af[e] > 0.f ? gv[e] : 0.f;
+      }
       *reinterpret_cast<u32x4*>(a.g + n * a.g_sn + (long long)y * a.g_sh + (long long)x * a.g_sw + c8 * 8) =
-          __builtin_bit_cast(u32x4, __builtin_convertvector(d * up, bf16x8));
+          __builtin_bit_cast(u32x4, __builtin_convertvector(gv, bf16x8));
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += d[e] * d[e];
@@ -277,14 +284,15 @@ extern "C" int fdgan_mse_nhwc_fwd(const FdTensor* a, const FdTensor* b, float sc
   return fd_launch(&mse_nhwc_kernel<false>, "mse_nhwc_fwd", dim3(nb), dim3(256), 0, m, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, const FdTensor* g,
-                                  FdStream stream) {
+extern "C" int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, int relu_mask,
+                                  const FdTensor* g, FdStream stream) {
   MseNhwcArgs m;
   FD_REQUIRE(g && upstream, "mse_nhwc_bwd: NULL gradient view / upstream scalar");
   int rc = mse_setup(a, b, g, m);
   if (rc != FD_OK) return rc;
   m.scale = scale;
   m.upstream = upstream;
+  m.relu_mask = relu_mask;
   return fd_launch(&mse_nhwc_kernel<true>, "mse_nhwc_bwd", dim3(grid_for(m.units)), dim3(256), 0, m, static_cast<hipStream_t>(stream));
 }
 

@@ -185,6 +185,35 @@ class PlanBackward:
                 r["_sole"] = sole
             self.nozero = {g for g, flags in per_gbuf.items() if all(flags)}
         self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
+        # ReLU pre-masking (enable_relu_premask): whether each conv's input region is the stored output of a ReLU epilogue
+        # (directly, or through max-pools / copies of one)
+        self.relu_premask = False
+        post, self.x_post_relu = {}, {}
+        for i, r in enumerate(self.recs):
+            if r["kind"] == "conv":
+                self.x_post_relu[i] = post.get(_region(r["x"]), False)
+                if r.get("y") is not None:
+                    post[_region(r["y"])] = r["e_act"] == L.ACT_RELU
+            else:
+                post[_region(r["dst"])] = post.get(_region(r["src"]), False)
+
+    def enable_relu_premask(self):
+        """Fold the backward of every ReLU EPILOGUE into the op that produces the gradient of its output: a consumer's
+        data-gradient epilogue masks by (stored output > 0) -- relu'(z) = [relu(z) > 0] -- so the walk needs no separate
+        mask pass per layer (10 for Vgg16).  The caller seeds masked gradients (fdgan_mse_nhwc_bwd(relu_mask = 1)).  Valid
+        when every reader of a ReLU output is a prologue-free stride-1 conv on the fused data-gradient path, a max-pool
+        (routes to the arg-max, whose value is the pooled value: masked with it) or a copy."""
+        if self.relu_premask:
+            return
+        for i, r in enumerate(self.recs):
+            if r["kind"] != "conv":
+                continue
+            meta = r["pro"]._meta if r.get("pro") is not None else None
+            if self.x_post_relu[i] and not (r["stride"] == 1 and meta is None and r["x"].c0 % 8 == 0 and not r["upsample"]):
+                raise NotImplementedError("ReLU pre-masking: record %d reads a ReLU output through a prologue / stride" % i)
+        if not (self.fuse_mask and self.defer_affine):
+            raise NotImplementedError("ReLU pre-masking needs the fused data-gradient path")
+        self.relu_premask = True
 
     def record_params(self, i):
         """Parameters whose gradient record i's backward adds to (conv weight, bias, the prologue's BatchNorm pair)."""
@@ -270,8 +299,11 @@ class PlanBackward:
         if fusable and bn is not None and not meta.get("batch_stats", False):
             raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
         if fusable:
+            mask_act = meta["act"]
+            if self.relu_premask and bn is None and mask_act == L.ACT_NONE and r.get("_post_relu", False):
+                mask_act = L.ACT_RELU          # x is a stored ReLU output: masking by (x > 0) is that ReLU's backward
             act_pro = (E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"], beta=meta["beta"],
-                                       eps=meta["eps"]) if bn is not None else E.make_prologue(act=meta["act"]))
+                                       eps=meta["eps"]) if bn is not None else E.make_prologue(act=mask_act))
         if fusable and self.defer_affine:
             # One pass: the data-gradient kernel masks, sums BatchNorm's two reductions and adds gamma * rstd * dpre straight
             # into G[x]; what is left of BatchNorm's backward, B * x + C per channel, is linear in x and waits in the buffer's
@@ -352,12 +384,28 @@ class PlanBackward:
         if check:
             rec, gx_before, dx_ref = check_state
         Tv = E.View(T, 0, cin)
+        gx = self.G(x)
+        bn = meta.get("bn")
+        if meta["pool"] and bn is not None and meta.get("batch_stats", False):
+            # pooled prologue (transitions): T is the gradient w.r.t. the 2x2-averaged activation at HALF resolution.  Two
+            # passes over the full-resolution input, both un-pooling and masking on the fly: the sums, then dx -- no
+            # full-resolution dpre tensor (it was written, masked in place and re-read: four more passes)
+            pool_pro = E.make_prologue(act=meta["act"], pool=True, mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
+                                       beta=meta["beta"], eps=meta["eps"])
+            dg = torch.empty(cin, dtype=torch.float32, device=p.device)
+            dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
+            train_bn = bn.weight is not None and bn.weight.requires_grad
+            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn)
+            E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                              sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            E.bn_bwd_apply(Tv.fd, x.fd, pool_pro, dg, dbt, gx.fd, accumulate=True)
+            if check:
+                self._finish_check(rec, x, gx_before, dx_ref)
+            return
         if meta["pool"]:
             T2 = E.new_act(n, 2 * hin, 2 * win, _r8(cin), p.device)
             E.grad_ew(E.GRAD_UNPOOL, Tv, E.View(T2, 0, cin))
             T, Tv = T2, E.View(T2, 0, cin)
-        gx = self.G(x)
-        bn = meta.get("bn")
         if bn is not None:
             if not meta.get("batch_stats", False):
                 raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
@@ -407,8 +455,10 @@ class PlanBackward:
                 t = E.new_act(n, h2 // 2, w2 // 2, _r8(y.c), y.buf.device)
                 dyv = E.View(t, 0, y.c)
                 E.grad_ew(E.GRAD_SUMPOOL, gy, dyv)
+            r["_post_relu"] = self.x_post_relu.get(i, False)
             if r["e_act"] == L.ACT_RELU:
-                E.grad_ew(E.GRAD_RELU_MASK, dyv, dyv, ref=y)
+                if not self.relu_premask:
+                    E.grad_ew(E.GRAD_RELU_MASK, dyv, dyv, ref=y)
             elif r["e_act"] != L.ACT_NONE:
                 raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
             self.conv_backward(r, dyv, grads, need_dx=(id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of))

@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FdganLibraryError(RuntimeError):
@@ -98,8 +98,8 @@ SIGNATURES = {
     "fdgan_sum_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "fdgan_mse_nhwc_fwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_float, C.c_void_p, C.c_int64,
                                      C.POINTER(C.c_int64), C.c_void_p]),
-    "fdgan_mse_nhwc_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p, C.c_float, C.POINTER(FdTensor),
-                                     C.c_void_p]),
+    "fdgan_mse_nhwc_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p, C.c_float, C.c_int,
+                                     C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_cx_rows_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "fdgan_cx_rows_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,

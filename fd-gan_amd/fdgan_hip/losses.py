@@ -121,12 +121,13 @@ class _PerceptualFn(torch.autograd.Function):
             raise RuntimeError("vgg_perceptual: the Vgg16 plan ran again between this forward and its backward; its "
                                "activations were overwritten (call backward first, or use another Vgg16 instance)")
         B = ctx.vgg.plan_backward(Px)
+        B.enable_relu_premask()        # gradients of ReLU outputs are masked where they are produced: no separate mask passes
         B.zero_()
         gs = g.detach().float().contiguous()
         lib = L.load()
         for a, b in zip(Px.taps, Pt.taps):
             n, h, w, c = a.shape
-            L.check(lib.fdgan_mse_nhwc_bwd(C.byref(a.fd), C.byref(b.fd), gs.data_ptr(), 2.0 / (n * h * w * c),
+            L.check(lib.fdgan_mse_nhwc_bwd(C.byref(a.fd), C.byref(b.fd), gs.data_ptr(), 2.0 / (n * h * w * c), 1,
                                            C.byref(B.G(a).fd), E.stream_ptr()), "mse_nhwc_bwd")
         B.run({}, skip_dx_of=())
         xin = Px.xin

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 2
+#define FDGAN_ABI_VERSION 3
 
 enum FdStatus {
   FD_OK = 0,
@@ -292,6 +292,10 @@ int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue*
                       float* bsum, float* csum, FdStream stream);
 /* dx += bsum[c] * x + csum[c] (NHWC bf16 views of equal shape). */
 int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
+/* Pooled prologues (pro->pool2, the transitions: BatchNorm + ReLU + 2x2 average in front of the 1x1 conv,
+ * torchvision _Transition as used at dehaze1113.py:716-728): fdgan_bn_act_bwd and fdgan_bn_bwd_apply accept the HALF-resolution
+ * gradient w.r.t. the pooled activation as `da` / `dpre` and un-pool (x 1/4) and mask on the fly -- bn_act_bwd then only
+ * produces the sums (nothing is written back), bn_bwd_apply forms dpre per pixel.  No full-resolution dpre tensor exists. */
 int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                        const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream);
 int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,
@@ -329,14 +333,17 @@ int fdgan_ssim_bwd(const float* x, const float* y, const float* da, const float*
  * fdgan_mse_nhwc_fwd / _bwd: mean squared difference of two NHWC bf16 views (Vgg16's tapped feature maps,
  * myutils/vgg16.py:27-49, read where the conv kernels left them): partial sums pre-multiplied by `scale` (1 / numel for
  * a mean; several maps may share one partial array and one fdgan_sum_partials), and g = upstream[0] * scale * (a - b)
- * written to the gradient view of `a` (scale = 2 / numel), `upstream` a DEVICE scalar so no host sync is needed. */
+ * written to the gradient view of `a` (scale = 2 / numel), `upstream` a DEVICE scalar so no host sync is needed.
+ * relu_mask != 0: `a` is the stored output of a ReLU epilogue and g is zeroed where a == 0, i.e. the gradient is already
+ * the one w.r.t. the PRE-activation (vgg16.py:28-46: every tapped map is F.relu(conv)), which lets the backward walk skip
+ * its separate mask pass. */
 int fdgan_loss_f32(int kind, const float* x, const float* t, float t_const, int64_t n, float* grad, float* partial,
                    int64_t partial_floats, int64_t* nparts, FdStream stream);
 int fdgan_sum_partials(const float* partial, int64_t count, double scale, float* out, FdStream stream);
 int fdgan_mse_nhwc_fwd(const FdTensor* a, const FdTensor* b, float scale, float* partial, int64_t partial_floats,
                        int64_t* nparts, FdStream stream);
-int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, const FdTensor* g,
-                       FdStream stream);
+int fdgan_mse_nhwc_bwd(const FdTensor* a, const FdTensor* b, const float* upstream, float scale, int relu_mask,
+                       const FdTensor* g, FdStream stream);
 
 /* ContextualLoss (the reference's bytecode-only loss module, original loss.py:23-73): the row part.
  * d: cosine distances [rows = B*HW][n = HW] fp32 contiguous.  relative_distances -> weighted_average_distances -> max over

@@ -127,6 +127,12 @@ def ab_suite(shapes, var="FDGAN_DEBUG_WD", variants=("",), rounds=3):
         print(json.dumps(row), flush=True)
 
 
+HEADLINE_SHAPES = [
+    dict(k=3, cin=128, cout=32, n=16, h=256, w=256, bn=True, stats=True, pitch_out=256),
+    dict(k=3, cin=128, cout=32, n=16, h=128, w=128, bn=True, stats=True, pitch_out=512),
+    dict(k=3, cin=128, cout=32, n=16, h=64, w=64, bn=True, stats=True, pitch_out=1024),
+]
+
 SUITES = {
     "netg": [
         dict(k=3, cin=128, cout=32, n=16, h=256, w=256, bn=True, stats=True, pitch_out=256),
@@ -156,6 +162,9 @@ def main():
     ap.add_argument("--variants", default="")
     a = ap.parse_args()
     L.load()
+    if a.suite == "headline_ab":
+        ab_suite(HEADLINE_SHAPES, variants=tuple(a.variants.split(",")))
+        return
     if a.suite == "mfma_ab":
         ab_suite(MFMA_SHAPES, variants=tuple(a.variants.split(",")))
         return
