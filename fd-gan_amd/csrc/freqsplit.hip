@@ -10,6 +10,7 @@
 // discriminator needs: it reads the image once and writes [img, LF(img), HF(img)] as 9 NHWC
 // bf16 channels (+ zero padding) -- the tensor D's first 4x4 conv consumes.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -100,6 +101,133 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
   }
 }
 
+// ---- row-streaming form (W % 4 == 0): one WAVE per work item = (plane, 256-column strip, row segment) -----------------
+// The tile kernel above reads a 46 x 46 halo for 32 x 32 outputs (2.07x the input) in 4-byte accesses: 1.8 TB/s at
+// 1024^2.  Here a wave walks DOWN its strip: per input row every lane loads 16 bytes (4 pixels, coalesced; the two
+// 8-pixel halos by four edge lanes, reflected / zeroed there), the row goes through a wave-private LDS line so that a lane
+// can read its 20-pixel window (the +-7 horizontal taps cross lanes: this is the "wavefront shuffle", through the LDS
+// crossbar as 16-byte reads -- ds_bpermute would need 14 of them per pixel), the horizontal 15-tap (3-tap) sum is formed in
+// registers, and the last 15 (3) such rows live in a REGISTER ring -- the loop is unrolled by the ring length so ring
+// positions are compile-time -- from which the vertical pass produces one output row per input row.  Column halo: 16 of 272
+// pixels (6 %); row halo per segment: 14 rows.  Rows are requested FS_PF ahead so a wave has several loads in flight.
+constexpr int FSR_W = 256, FSR_PF = 3;
+
+struct FsRowArgs {
+  const float* x;
+  float* y;
+  int H, W, C, norm;
+  int strips, segs, seg_rows;
+  float g[15];
+  float mean[3], istd[3];
+};
+
+template <int R, bool REFLECT>   // R = 7: Blur (reflection padding); R = 1: Laplacian box part (zero padding)
+__device__ __forceinline__ float fsr_at(const float* plane, int y, int x, int H, int W) {
+  if (REFLECT) return plane[(long long)reflect(y, H) * W + reflect(x, W)];
+  return (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] : 0.f;
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
+  constexpr bool BLUR = R == 7;
+  constexpr int NTAP = 2 * R + 1;
+  __shared__ __attribute__((aligned(16))) float line[8 + FSR_W + 8];
+  const int lane = threadIdx.x;
+  int item = blockIdx.x;
+  const int strip = item % a.strips;
+  item /= a.strips;
+  const int seg = item % a.segs, plane = item / a.segs;
+  const int x0 = strip * FSR_W, r_begin = seg * a.seg_rows, r_end = min(a.H, r_begin + a.seg_rows);
+  const float* xp = a.x + (long long)plane * a.H * a.W;
+  float* yp = a.y + (long long)plane * a.H * a.W;
+  const int ch = plane % a.C;
+  const int cx = x0 + 4 * lane;                       // this lane's four columns
+  // edge lanes also fetch one 4-pixel piece of the halo: lanes 0, 1 left (x0 - 8, x0 - 4), lanes 2, 3 right (x0 + 256, + 260)
+  const int hx = lane < 2 ? x0 - 8 + 4 * lane : x0 + FSR_W + 4 * (lane - 2);
+  const int hslot = lane < 2 ? 4 * lane : 8 + FSR_W + 4 * (lane - 2);
+  typedef __attribute__((ext_vector_type(4))) float f4;
+
+  auto fetch = [&](int iy, f4& v, f4& hv) __attribute__((always_inline)) {   // input row iy (may lie outside the image)
+    const bool rin = iy >= 0 && iy < a.H;
+    if (BLUR || rin) {
+      const int ry = BLUR ? reflect(iy, a.H) : iy;
+      if (cx + 3 < a.W) v = *reinterpret_cast<const f4*>(xp + (long long)ry * a.W + cx);
+      else
+        for (int e = 0; e < 4; ++e) v[e] = fsr_at<R, BLUR>(xp, iy, cx + e, a.H, a.W);
+      if (lane < 4) {
+        if (hx >= 0 && hx + 3 < a.W) hv = *reinterpret_cast<const f4*>(xp + (long long)ry * a.W + hx);
+        else
+          for (int e = 0; e < 4; ++e) hv[e] = fsr_at<R, BLUR>(xp, iy, hx + e, a.H, a.W);
+      }
+    } else {
+      v = f4{0.f, 0.f, 0.f, 0.f};
+      hv = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f4 ring[NTAP];       // horizontally filtered rows; ring[k % NTAP] = row (first + k)
+  f4 ctr[3];           // Laplacian: the raw centre pixels of the last 3 rows
+  f4 pv[FSR_PF], ph[FSR_PF];
+  const int first = r_begin - R, last = r_end + R;     // input rows [first, last)
+#pragma unroll
+  for (int q = 0; q < FSR_PF; ++q) fetch(first + q, pv[q], ph[q]);
+  static_assert(NTAP % FSR_PF == 0 && NTAP % 3 == 0, "one unrolled block of NTAP rows keeps ring, prefetch and centre positions constant");
+  for (int k0 = 0; first + k0 < last; k0 += NTAP) {
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {                   // unrolled: ring / prefetch positions are constants (15 bodies: fits the I-cache; 45 did not)
+      const int k = k0 + j, iy = first + k;
+      if (iy >= last) continue;          // (a `break` here kept the loop rolled: the ring went to scratch memory)
+      const f4 v = pv[j % FSR_PF], hv = ph[j % FSR_PF];
+      fetch(iy + FSR_PF, pv[j % FSR_PF], ph[j % FSR_PF]);     // FSR_PF rows ahead (rows past `last` are harmless reads inside the plane / zeros)
+      // the row through the wave's LDS line (one wave: LDS operations complete in program order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      *reinterpret_cast<f4*>(&line[8 + 4 * lane]) = v;
+      if (lane < 4) *reinterpret_cast<f4*>(&line[hslot]) = hv;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      float win[20];                                    // columns cx - 8 .. cx + 11
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const f4 t = *reinterpret_cast<const f4*>(&line[4 * lane + 4 * q]);
+        win[4 * q] = t[0], win[4 * q + 1] = t[1], win[4 * q + 2] = t[2], win[4 * q + 3] = t[3];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f4 hsum;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) s_ = BLUR ? fmaf(a.g[t], win[8 + e + t - R], s_) : s_ + win[8 + e + t - R];
+        hsum[e] = s_;
+      }
+      ring[j % NTAP] = hsum;
+      if (!BLUR) ctr[j % 3] = v;
+      const int oy = iy - R;                            // the output row this input row completes
+      if (k >= 2 * R && oy >= r_begin && oy < r_end) {
+        f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {                // rows oy - R .. oy + R = ring positions j - 2R + t
+          const f4 hr = ring[(j + 2 * NTAP - 2 * R + t) % NTAP];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = BLUR ? fmaf(a.g[t], hr[e], o[e]) : o[e] + hr[e];
+        }
+        if (BLUR) {
+          if (a.norm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (o[e] - a.mean[ch]) * a.istd[ch];
+        } else {
+          const f4 c = ctr[(j + 3 * NTAP - 1) % 3];   // centre row = the previous input row
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] -= 9.f * c[e];
+        }
+        if (cx + 3 < a.W) *reinterpret_cast<f4*>(yp + (long long)oy * a.W + cx) = o;
+        else
+          for (int e = 0; e < 4; ++e)
+            if (cx + e < a.W) yp[(long long)oy * a.W + cx + e] = o[e];
+      }
+    }
+  }
+}
+
 void gaussian15(float* g, double sigma) {   // 1-D factor of isotropic_gaussian_kernel(15, sigma), loss.py:153-159
   double v[15], s = 0.0;
   for (int i = 0; i < 15; ++i) {
@@ -156,6 +284,29 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
   for (int i = 0; i < 3; ++i) {
     a.mean[i] = m[i];
     a.istd[i] = 1.f / sd[i];
+  }
+  // row-streaming form (one wave per strip segment).  Measured, B=4 @1024^2 / B=16 @256^2: Laplacian 23.8 / 9.2 us against
+  // 52.9 / 15.9 us for the tile kernel (4.2 TB/s); Blur 40.5 / 21.6 us against 55.8 / 18.0 us -- its 14 halo rows per
+  // 16-row segment cost more than the tile kernel's halo once the planes are small, so small planes stay on the tiles
+  const bool rows_pay = a.mode == 1 || planes * (long long)a.H * a.W >= (6ll << 20);
+  if (a.mode != 2 && rows_pay && a.W % 4 == 0 && a.H >= 16 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 &&
+      FD_TUNE_GETENV("FDGAN_DEBUG_NO_FS_ROWS") == nullptr) {
+    FsRowArgs r{};
+    r.x = a.x, r.y = a.y, r.H = a.H, r.W = a.W, r.C = a.C, r.norm = a.norm;
+    for (int i = 0; i < 15; ++i) r.g[i] = a.g[i];
+    for (int i = 0; i < 3; ++i) r.mean[i] = a.mean[i], r.istd[i] = a.istd[i];
+    r.strips = (a.W + FSR_W - 1) / FSR_W;
+    // ~16 waves per CU in all; at least 16 (Blur: 14 halo rows are re-filtered per segment) / 8 (Laplacian) rows per segment
+    long long segs = 4096 / (planes * r.strips);
+    if (segs < 1) segs = 1;
+    static const char* sr = FD_TUNE_GETENV("FDGAN_DEBUG_FS_SEG");
+    const int min_rows = sr ? atoi(sr) : (a.mode == 1 ? 8 : 16);
+    if (segs > a.H / min_rows) segs = a.H / min_rows > 0 ? a.H / min_rows : 1;
+    r.seg_rows = (int)((a.H + segs - 1) / segs);
+    r.segs = (a.H + r.seg_rows - 1) / r.seg_rows;
+    const unsigned grid = (unsigned)(planes * r.strips * r.segs);
+    if (a.mode == 0) return fd_launch(&freqsplit_rows_kernel<7>, name, dim3(grid), dim3(64), 0, r, stream);
+    return fd_launch(&freqsplit_rows_kernel<1>, name, dim3(grid), dim3(64), 0, r, stream);
   }
   return fd_launch(&freqsplit_kernel, name, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)planes), dim3(256), 0, a,
                    stream);
