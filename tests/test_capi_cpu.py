@@ -104,3 +104,21 @@ def test_product_does_not_import_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, fn)
+
+
+def test_release_library_carries_no_tuning_switches():
+    """The FDGAN_DEBUG_* switches (kernel selection, phase skipping -- some make a kernel return wrong results) exist only
+    in -DFDGAN_TUNING builds (csrc/common.h: FD_TUNE_GETENV): the library the tests and the benchmark load must not contain
+    their names, and must not look at the environment for them."""
+    from fdgan_hip import lib as L
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"FDGAN_DEBUG_" not in blob and b"FDGAN_TUNING" not in blob
+    flags = os.path.join(ROOT, "fd-gan_amd", "build", ".flags")
+    if os.path.exists(flags):
+        assert "-DFDGAN_TUNING" not in open(flags).read()
+    for dp, _, fns in os.walk(os.path.join(ROOT, "fd-gan_amd", "csrc")):
+        for fn in fns:
+            src = open(os.path.join(dp, fn)).read()
+            for m in re.finditer(r"(?<![A-Z_])getenv\s*\(", src):
+                line = src[src.rfind("\n", 0, m.start()) + 1:src.find("\n", m.start())]
+                assert "#define FD_TUNE_GETENV" in line, "%s: getenv outside FD_TUNE_GETENV: %s" % (fn, line.strip())

@@ -24,8 +24,15 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
 names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
          "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256"),
          "conv1x1_bwd_kernel": ("conv1x1_bwd_stream", "train_B16_256"),
-         "conv_igemm_kernel<1, 1, 0, 4, 8, 4, 1, 1, 1>": ("conv1x1_bn128_bwd", "train_B16_256"),
-         "conv_igemm_kernel<3, 1, 0, 4, 8, 4, 1, 1, 1>": ("conv3x3_bn128_bwd", "train_B16_256")}
+         "conv3x3_bwd_kernel": ("conv3x3_bwd_stream", "train_B16_256"),
+         "affine_acc_kernel": ("affine_accumulate", "train_B16_256"),
+         "conv_wgrad1x1_tr_kernel": ("conv_wgrad1x1_tr", "train_B16_256"),
+         "conv_wgrad_tr_kernel<3, 3, 8>": ("conv_wgrad3x3_tr8", "train_B16_256"),
+         "conv_wgrad_tr_kernel<4, 2, 9>": ("conv_wgrad4x4_tr", "train_B16_256"),
+         "conv_igemm_kernel<3, 1, 0, 8, 2, 1, 4, 9, 0, 1>": ("conv3x3_wd128", "train_B16_256"),
+         "conv_igemm_kernel<3, 1, 0, 8, 2, 1, 4, 9, 1, 1>": ("conv3x3_wd128_bwd", "train_B16_256"),
+         "conv_igemm_kernel<4, 1, 0, 8, 3, 1, 3, 16, 0, 1>": ("conv4x4_wd144", "train_B16_256"),
+         "conv_igemm_kernel<4, 1, 0, 8, 3, 1, 3, 16, 1, 1>": ("conv4x4_wd144_bwd", "train_B16_256")}
 res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (training step + netG forward leg, B=16 @256^2); KiB; "
                    "FETCH_SIZE is x2-corrected by bench.py per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
 for k, cs in agg.items():

@@ -10,6 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -o p -- python "$R/bench.py" --no-cpu-baseline --steps 20 --warmup 3 "$@" > "$OUT/bench.log" 2>&1
 DB=$(find "$OUT" -name "*.db" | head -1)
 python "$R/tools/rocpd_summary.py" "$DB" > "$R/gpurun_out/${TAG}_kernel_stats.txt"
-tail -n 1 "$OUT/bench.log" > "$R/gpurun_out/${TAG}_bench.json"
+grep "^{" "$OUT/bench.log" | tail -n 1 > "$R/gpurun_out/${TAG}_prof_bench.json"
 find "$OUT" -name "*.db" -delete
 head -45 "$R/gpurun_out/${TAG}_kernel_stats.txt"
