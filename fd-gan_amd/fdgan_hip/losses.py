@@ -22,8 +22,9 @@ _PARTIAL = {}
 
 
 def _partial(dev, n=8192):
-    """Per-device scratch for the per-workgroup sums (a launch writes at most 2048)."""
-    key = (dev.index, n)
+    """Per-(device, stream) scratch for the per-workgroup sums (a launch writes at most 2048): losses evaluated on
+    different streams (train.py runs the discriminator's real half beside the generator's forward) must not share it."""
+    key = (dev.index, n, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _PARTIAL:
         _PARTIAL[key] = torch.empty(n, dtype=torch.float32, device=dev)
     return _PARTIAL[key]
@@ -108,7 +109,7 @@ def _mse_taps_fwd(Px, Pt):
 class _PerceptualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vgg, x, target):
-        Pt = vgg.run_nhwc(target, slot=1)            # targets live in their own plan: nothing overwrites them
+        Pt = target if not isinstance(target, torch.Tensor) else vgg.run_nhwc(target, slot=1)   # targets live in their own plan
         Px = vgg.run_nhwc(x, slot=0)
         ctx.vgg, ctx.Px, ctx.Pt, ctx.gen = vgg, Px, Pt, (Px._gen, Pt._gen)
         ctx.dtype = x.dtype
@@ -136,17 +137,27 @@ class _PerceptualFn(torch.autograd.Function):
         return None, dx.to(ctx.dtype), None
 
 
+def vgg_targets(vgg, target):
+    """Feature maps of `target` in the module's target slot, for a later vgg_perceptual(vgg, x, <this>): lets a training
+    step compute them early (on another stream, beside the generator's forward)."""
+    E.require_gpu(target, "vgg_targets")
+    with torch.no_grad():
+        return vgg.run_nhwc(target, slot=1)
+
+
 def vgg_perceptual(vgg, x, target):
     """sum over Vgg16's four taps of F.mse_loss(feature(x), feature(target)); differentiable w.r.t. x.  Vgg16's own
-    parameters are treated as frozen (the reference loads a pretrained, fixed VGG16: myutils/utils.py:84-94)."""
+    parameters are treated as frozen (the reference loads a pretrained, fixed VGG16: myutils/utils.py:84-94).
+    `target`: an image batch, or the result of vgg_targets(vgg, images)."""
     E.require_gpu(x, "vgg_perceptual")
-    E.require_gpu(target, "vgg_perceptual")
+    if isinstance(target, torch.Tensor):
+        E.require_gpu(target, "vgg_perceptual")
     if any(p.requires_grad for p in vgg.parameters()):
         raise NotImplementedError("vgg_perceptual treats Vgg16 as a frozen feature extractor: call "
                                   "`for p in vgg.parameters(): p.requires_grad_(False)` (or use vgg(x) + mse_loss)")
     if torch.is_grad_enabled() and x.requires_grad:
         return _PerceptualFn.apply(vgg, x, target)
     with torch.no_grad():
-        Pt = vgg.run_nhwc(target, slot=1)
+        Pt = target if not isinstance(target, torch.Tensor) else vgg.run_nhwc(target, slot=1)
         Px = vgg.run_nhwc(x, slot=0)
         return _mse_taps_fwd(Px, Pt)

@@ -26,7 +26,7 @@ import misc
 import models.dehaze1113 as net
 import models.pytorch_ssim as pytorch_ssim
 from fdgan_hip.dp import DpContext
-from fdgan_hip.losses import bce_loss, l1_loss, vgg_perceptual
+from fdgan_hip.losses import bce_loss, l1_loss, vgg_perceptual, vgg_targets
 from fdgan_hip.optim import FlatAdam
 from loss import fusion_input
 from myutils.vgg16 import Vgg16
@@ -72,6 +72,9 @@ class TrainStep:
         self.pool = misc.ImagePool(pool_size)
         self.w = dict(adv=w_adv, perc=w_perc, ssim=w_ssim, l1=w_l1)
         self.dp = dp
+        # second HIP stream: work that does not depend on the generator's output (the discriminator's real half, VGG16 on
+        # the ground truth) is enqueued there and fills the CUs the generator's small-grid launches leave idle
+        self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         if dp is not None and dp.world > 1:
             self.sync_replicas()
 
@@ -111,15 +114,22 @@ class TrainStep:
 
     def step(self, haze, gt):
         """haze, gt: (B,3,H,W) float in [0,1] on the device.  Returns a dict of python floats (ONE host sync, at the end)."""
-        fake = self.netG(haze)                                                     # autograd graph of the generator
-        # ---- D step: two backward calls (D's activations live in its plan buffers)
+        # ---- D step: two backward calls (D's activations live in its plan buffers).  The real half and VGG16's target
+        # features depend on `gt` only: they go to the side stream and run beside the generator's forward.
         self._set_d_grad(True)
         self.optD.zero_grad()
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            with torch.no_grad():
+                real_in = fusion_input(gt)
+            l_real = bce_loss(self.netD(real_in), 1.0)
+            l_real.backward()
+            feats_gt = vgg_targets(self.vgg, gt)
+        fake = self.netG(haze)                                                     # autograd graph of the generator
+        main.wait_stream(self.side)
         with torch.no_grad():
-            real_in = fusion_input(gt)
             fake_in = fusion_input(self.pool.query(fake.detach()))
-        l_real = bce_loss(self.netD(real_in), 1.0)
-        l_real.backward()
         l_fake = bce_loss(self.netD(fake_in), 0.0)
         l_fake.backward()
         self.optD.allreduce_grads(self.dp)
@@ -127,10 +137,15 @@ class TrainStep:
         # ---- G step
         self._set_d_grad(False)                                                    # D is a fixed critic here: no dW work
         self.optG.zero_grad()
-        l_perc = vgg_perceptual(self.vgg, fake, gt)
+        # the adversarial branch (frequency split -> D -> BCE) and the perceptual / SSIM / L1 branch only meet at `fake`:
+        # forward AND backward of the former run on the side stream (autograd replays a node on its forward's stream)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        l_perc = vgg_perceptual(self.vgg, fake, feats_gt)
         ssim = pytorch_ssim.ssim(fake, gt)
         l_l1 = l1_loss(fake, gt)
-        l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        main.wait_stream(self.side)
         lossG = self.w["l1"] * l_l1 + self.w["ssim"] * (1.0 - ssim) + self.w["perc"] * l_perc + self.w["adv"] * l_adv
         with self.optG.overlap(self.dp):            # slices of the flat gradient are all-reduced while the backward still runs
             lossG.backward()
