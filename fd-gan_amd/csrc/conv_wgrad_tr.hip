@@ -248,6 +248,307 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   }
 }
 
+// ---- second generation, 3x3 pad 1 without a bias: walk INPUT rows, keep the dy fragments of three output rows in registers.
+// Input row r serves filter row ky of output row r - ky + 1, so one B fragment (row r, shift kx) feeds 3 filter rows x 2
+// cout tiles = 6 MFMAs instead of 2, and a step reads 10 fragments instead of 22 (the first kernel sat at 13 % MFMA busy:
+// every wave waited on its 44 transpose reads per row, then on the staging, then on the barrier).  A step is software-
+// pipelined inside each wave:
+//   * the fragments of row r + 1 are requested while row r's MFMAs run -- every B fragment is refilled in place right after
+//     the block of 6 MFMAs that used it, the newest dy fragments after the last block of their 32-pixel half;
+//   * rows travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers), R3_PFX + 2 rows ahead: raw input
+//     rows into a ring of 6 linear slots, dy rows straight into their fragment layout (the swizzle is applied to the SOURCE
+//     address, the LDS side of the DMA is lane-linear).  A wave transforms the units it fetched itself (BatchNorm + ReLU +
+//     zero padding, raw slot -> one of two swizzled slots), two dwords per MFMA block, so its own s_waitcnt vmcnt is the only
+//     synchronisation between fetch and transform;
+//   * one raw barrier per row (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would also drain the DMA queue).
+// Six steps are unrolled so that every ring slot and register set is a compile-time constant.  Same work split and the same
+// partial-sum layout as the first kernel (wgrad_tr_reduce_kernel maps it back): the summation order is unchanged.
+template <int V> struct IC { static constexpr int value = V; };
+#define R3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The step's barrier: LDS operations of a wave complete in order, and the last six issued before it are the fragment reads
+// that refill B[1][2] and the newest dy fragments of the second half -- wanted only at the END of the next step.  Waiting for
+// all but those six publishes this wave's transformed units without exposing the reads' latency at every barrier.
+#define R3_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory")
+constexpr int R3_PFX = 4;                       // group m (input row m + dy row m) is requested in step m - 2 - R3_PFX
+constexpr int R3_RAW_B = 66 * 256, R3_D_B = 64 * 64;
+constexpr int R3_LDS = 6 * R3_RAW_B + 2 * R3_RAW_B + 6 * R3_D_B + 1024;
+
+// LDS-DMA of 16 bytes per lane: global (uniform base + 32-bit lane byte offset) -> LDS (uniform base + 16 lane).  Inline
+// assembly on purpose: with the builtin hipcc knows the instruction writes LDS and puts s_waitcnt vmcnt(0) in front of the
+// wave's next LDS read, i.e. drains the whole prefetch queue every step.  The waits are counted by hand (r3_wait_vm).
+__device__ __forceinline__ void r3_dma16(const unsigned short* base, unsigned lane_bytes, char* lds_wave_base) {
+  const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_bytes), "s"(base), "s"(lds) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void r3_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one dword (two channels) of the prologue transform; RELU: BatchNorm + ReLU on the packed result (fd_bn_relu8's recipe)
+template <bool RELU>
+__device__ __forceinline__ unsigned r3_xform2(unsigned raw, float sc0, float sc1, float sh0, float sh1, float slope, unsigned mask) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+  f32x2_t f = {__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
+  f = __builtin_elementwise_fma(f, (f32x2_t){sc0, sc1}, (f32x2_t){sh0, sh1});
+  unsigned out;
+  if constexpr (RELU) {
+    const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+    out = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
+  } else {
+    f = __builtin_elementwise_max(f, f * slope);
+    out = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+  }
+  return out & mask;   // zero padding of the ACTIVATED input
+}
+
+// Cin a multiple of 128 (one 128-channel slice per workgroup), Cout a multiple of 32, W a multiple of 64
+// DBG (tuning builds only, results wrong): 1 no MFMAs, 2 no transform arithmetic, 4 no DMA requests / waits, 8 no fragment refills
+template <bool RELU, int DBG = 0>
+__global__ __launch_bounds__(512) void conv_wgrad_r3_kernel(WgradRowsArgs a) {
+  using C = G3Cfg<3, 3, 8>;
+  static_assert(C::XROW_B == R3_RAW_B && C::DROW_B == R3_D_B, "slot sizes");
+  extern __shared__ __attribute__((aligned(16))) char g3_lds[];
+  char* Raw = g3_lds;                               // 6 raw input rows, linear: unit u = pixel u / 16, 8-channel chunk u % 16
+  char* Xs = g3_lds + 6 * R3_RAW_B;                 // 2 transformed rows in the fragment layout
+  char* Ds = Xs + 2 * R3_RAW_B;                     // 6 dy rows in the fragment layout
+  float* sc_s = reinterpret_cast<float*>(Ds + 6 * R3_D_B);   // scale / shift until they are in registers, then the DMA dump
+  float* sh_s = sc_s + 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci0 = blockIdx.x * 128, co0 = (int)blockIdx.z * 32;
+  const int item = blockIdx.y;
+  const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
+  const int y_begin = seg * a.seg_rows, y_end = min(a.Ho, y_begin + a.seg_rows);
+  const int nsteps = y_end - y_begin + 2;     // input rows y_begin - 1 .. y_end
+  const int r0 = y_begin - 1, xbase = xb * G3_PB;
+  if (tid < 128) {
+    const int c = ci0 + tid;
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
+      sc = g / sqrtf(a.p_var[c] + a.eps);
+      sh = b - a.p_mean[c] * sc;
+    }
+    sc_s[tid] = sc;
+    sh_s[tid] = sh;
+  }
+  __syncthreads();
+  const float slope = a.pro_mode == 0 ? 1.f : a.p_slope;   // no prologue: max(t, 1 t) = t
+  // ---- a thread's units: input pixels tid / 16 and 32 + tid / 16 (chunk tid % 16) of every row, fetched by its wave's two
+  // full DMA instructions; the halo pixels 64, 65 are wave 0's third instruction (32 lanes); dy rows: 32 lanes of every wave.
+  const int xchunk = tid & 15, xpix0 = tid >> 4;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_s + xchunk * 8), s1 = *reinterpret_cast<const f32x4*>(sc_s + xchunk * 8 + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_s + xchunk * 8), h1 = *reinterpret_cast<const f32x4*>(sh_s + xchunk * 8 + 4);
+  __syncthreads();   // every thread holds its scale / shift: the area becomes the dump of the other waves' third DMA
+  // global sources as a wave-uniform row pointer + a 32-bit lane offset (saddr-form DMA: no 64-bit lane arithmetic)
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0;
+  char* xwp[3];            // where this thread's transformed units go (slot 0)
+  unsigned xsrc[3];
+  unsigned xcol[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pix = xpix0 + 32 * k, px = xbase - 1 + pix;
+    xwp[k] = Xs + C::xoff(pix, xchunk >> 1) + ((xchunk & 1) << 4);
+    xsrc[k] = 2u * (unsigned)(min(max(px, 0), a.W - 1) * a.x_sw + xchunk * 8);   // bytes
+    xcol[k] = px >= 0 && px < a.W ? 0xffffffffu : 0u;
+  }
+  const bool halo_t = tid < 32;
+  // dy row: waves 1-4, lane l of wave w fetches linear position q = 64 (w - 1) + l of the row's fragment layout -> pixel q / 4,
+  // 16-filter group ((q >> 1) & 1) ^ ((pixel >> 3) & 1), half q & 1
+  const int dq = ((wave - 1) & 3) * 64 + lane, dpix = dq >> 2;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + co0;
+  const unsigned dsrc = 2u * (unsigned)((xbase + dpix) * a.dy_sw + ((((dq >> 1) & 1) ^ ((dpix >> 3) & 1)) << 4) + ((dq & 1) << 3));
+  char* dump = reinterpret_cast<char*>(sc_s);
+  // group m: input row r0 + m (clamped: rows outside the image are masked by the transform) and dy row y_begin + m (rows
+  // outside the segment: zeros are written instead, the DMA goes to the dump so that the instruction count stays the same).
+  // Waves 0-4 issue three DMA instructions per group (wave 0: the halo pixels, 1-4: a quarter of the dy row), waves 5-7 two.
+  const bool three = wave <= 4;
+  auto request = [&](int m, auto SLOT) __attribute__((always_inline)) {
+    constexpr int sl = decltype(SLOT)::value;
+    if constexpr (DBG & 4) return;
+    const unsigned short* rp = ximg + (long long)min(max(r0 + m, 0), a.H - 1) * a.x_sh;
+    char* raw = Raw + sl * R3_RAW_B + wave * 1024;
+    r3_dma16(rp, xsrc[0], raw);
+    r3_dma16(rp, xsrc[1], raw + 8192);
+    if (wave == 0) {
+      if (lane < 32) r3_dma16(rp, xsrc[2], Raw + sl * R3_RAW_B + 16384);
+    } else if (three) {
+      char* dslot = Ds + sl * R3_D_B + (wave - 1) * 1024;
+      if (y_begin + m < y_end) {
+        r3_dma16(dimg + (long long)(y_begin + m) * a.dy_sh, dsrc, dslot);
+      } else {
+        if (lane == 0) r3_dma16(rp, xsrc[0], dump + wave * 16);
+        lds_write16(dslot + lane * 16, u32x4{0u, 0u, 0u, 0u});
+      }
+    }
+  };
+  auto wait_landed = [&](auto NG) __attribute__((always_inline)) {   // at most NG younger groups of this wave still in flight
+    constexpr int ng = decltype(NG)::value;
+    if constexpr (DBG & 4) return;
+    if (three) r3_wait_vm<3 * ng>(); else r3_wait_vm<2 * ng>();
+  };
+  auto rowmask = [&](int m) __attribute__((always_inline)) -> unsigned {   // is input row r0 + m inside the image (and wanted)
+    const int row = r0 + m;
+    return m < nsteps && row >= 0 && row < a.H ? 0xffffffffu : 0u;
+  };
+  // dword q of a unit through the prologue, masked
+  auto xf = [&](u32x4& v, int q, unsigned m) __attribute__((always_inline)) {
+    const float sa = q < 2 ? s0[2 * q] : s1[2 * q - 4], sb = q < 2 ? s0[2 * q + 1] : s1[2 * q - 3];
+    const float ha = q < 2 ? h0[2 * q] : h1[2 * q - 4], hb = q < 2 ? h0[2 * q + 1] : h1[2 * q - 3];
+    if constexpr (!(DBG & 2)) v[q] = r3_xform2<RELU>(v[q], sa, sb, ha, hb, slope, m);
+  };
+  auto xform_halo = [&](unsigned rm, auto RS, auto XS) __attribute__((always_inline)) {   // pixels 64, 65: threads 0-31
+    if constexpr (DBG & 64) return;
+    if (halo_t) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(Raw + decltype(RS)::value * R3_RAW_B + 16384 + tid * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xf(v, q, rm & xcol[2]);
+      lds_write16(xwp[2] + decltype(XS)::value * R3_RAW_B, v);
+    }
+  };
+
+  // fragment offsets inside a row slot: lane (g, i) -> k rows 8 g + (i >> 2) (+ 4 for the second read), piece i & 3;
+  // the second 32-pixel half of a row is a constant 8192 / 2048 bytes further (the swizzles repeat every 16 pixels)
+  const int g = lane >> 4, i = lane & 15;
+  const int kpix = 8 * g + (i >> 2), piece = (i & 3) * 8;
+  // per-lane POINTERS into slot 0, so that slot and half are immediate offsets of the reads
+  const char *bp[3][2], *ap[2][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    bp[kx][0] = Xs + C::xoff(kpix + kx, wave) + piece;
+    bp[kx][1] = Xs + C::xoff(kpix + kx + 4, wave) + piece;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    ap[ct][0] = Ds + g3_doff(kpix, ct) + piece;
+    ap[ct][1] = Ds + g3_doff(kpix + 4, ct) + piece;
+  }
+  const char* rawp = Raw + tid * 16;
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 A[3][2][2], B[2][3];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bf16x8 zfrag = __builtin_bit_cast(bf16x8, zero4);
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) A[s][sub][0] = A[s][sub][1] = zfrag;
+
+  // prologue: groups 0 .. R3_PFX + 1 requested; rows 0 and 1 transformed; the fragments of row 0 read
+  request(0, IC<0>{});
+  request(1, IC<1>{});
+  request(2, IC<2>{});
+  request(3, IC<3>{});
+  request(4, IC<4>{});
+  request(5, IC<5>{});
+  static_assert(R3_PFX == 4, "six groups in flight = six ring slots");
+  wait_landed(IC<R3_PFX>{});
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned rm = rowmask(j);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(rawp + j * R3_RAW_B + k * 8192);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xf(v, q, rm & xcol[k]);
+      lds_write16(xwp[k] + j * R3_RAW_B, v);
+    }
+    if (j == 0) xform_halo(rm, IC<0>{}, IC<0>{}); else xform_halo(rm, IC<1>{}, IC<1>{});
+  }
+  R3_BARRIER();
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) B[sub][kx] = g3_frag(bp[kx][0] + sub * 8192, bp[kx][1] + sub * 8192);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) A[0][sub][ct] = g3_frag(ap[ct][0] + sub * 2048, ap[ct][1] + sub * 2048);
+  }
+
+  // step j (phase P = j mod 6): MFMAs of input row j; dy row j - ky is in A[(j - ky) mod 3].  Six blocks of 6 MFMAs; the
+  // transform of row j + 2's two full units is spread over blocks 1-4 (two dwords each), pinned by sched_barriers so that
+  // neither the reads nor the VALU work pile up in front of the MFMAs.
+  auto step = [&](int j, auto P) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value, p3 = p % 3, p2 = p & 1;
+    constexpr int xn = (p2 ^ 1) * R3_RAW_B;             // transformed slot of row j + 1
+    constexpr int dn = ((p + 1) % 6) * R3_D_B;          // dy row j + 1
+    constexpr int xw = p2 * R3_RAW_B;                   // transformed slot of row j = of row j + 2
+    constexpr int rw = ((p + 2) % 6) * R3_RAW_B;        // raw slot of row j + 2
+    const unsigned rm = rowmask(j + 2);
+    wait_landed(IC<R3_PFX - 1>{});                      // group j + 2 has landed (this wave's part of it)
+    u32x4 u[2];
+    u[0] = *reinterpret_cast<const u32x4*>(rawp + rw);
+    u[1] = *reinterpret_cast<const u32x4*>(rawp + rw + 8192);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int blk = sub * 3 + kx;
+#pragma unroll
+        for (int ky = 2; ky >= 0; --ky) {
+          const int s = (p3 + 3 - ky) % 3;
+          if constexpr (DBG & 1) {
+            acc[ky * 3 + kx][0][0] += (float)A[s][sub][0][0] * (float)B[sub][kx][0];
+            acc[ky * 3 + kx][1][0] += (float)A[s][sub][1][0] * (float)B[sub][kx][0];
+            continue;
+          }
+          acc[ky * 3 + kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][sub][0], B[sub][kx], acc[ky * 3 + kx][0], 0, 0, 0);
+          acc[ky * 3 + kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][sub][1], B[sub][kx], acc[ky * 3 + kx][1], 0, 0, 0);
+        }
+        if constexpr (!(DBG & 8)) B[sub][kx] = g3_frag(bp[kx][0] + (xn + sub * 8192), bp[kx][1] + (xn + sub * 8192));
+        if (blk >= 1 && blk <= 4) {
+          const int k = (blk - 1) >> 1, q0 = ((blk - 1) & 1) * 2;
+          xf(u[k], q0, rm & xcol[k]);
+          xf(u[k], q0 + 1, rm & xcol[k]);
+          if ((blk - 1) & 1) lds_write16(xwp[k] + xw, u[k]);
+        }
+        if (kx == 2 && !(DBG & 8)) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) A[(p3 + 1) % 3][sub][ct] = g3_frag(ap[ct][0] + (dn + sub * 2048), ap[ct][1] + (dn + sub * 2048));
+        }
+        // a wave issues in order: six MFMAs in a row would hold the block's VALU work back for ~100 cycles while the
+        // matrix pipe drains them one by one.  Two VALU instructions ride in every MFMA's shadow instead.
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk == 4) {   // before the last block: its refills stay the youngest LDS operations of the step
+          xform_halo(rm, IC<(p + 2) % 6>{}, IC<p2>{});
+          request(j + 2 + R3_PFX, IC<p>{});            // into the ring slots of row j (raw: transformed two steps ago)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if constexpr (DBG & 32) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (DBG & 8) R3_BARRIER(); else R3_STEP_BARRIER();
+  };
+  // whole groups of six steps (one exit: with a break after every step the accumulators lost their fixed registers);
+  // steps past the segment's last row see zero rows.  Row counts of 4, 16 and 64 per segment give 6, 18 and 66 steps.
+  for (int j = 0; j < nsteps; j += 6) {
+    step(j, IC<0>{});
+    step(j + 1, IC<1>{});
+    step(j + 2, IC<2>{});
+    step(j + 3, IC<3>{});
+    step(j + 4, IC<4>{});
+    step(j + 5, IC<5>{});
+  }
+  r3_wait_vm<0>();   // the last requests land in LDS nobody reads; do not leave them in flight at exit
+  float* blk = a.part + ((((long long)item * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 8 + wave) * (9 * 512) + lane;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
+}
+
 // sum over items of the accumulator-order partials -> dw[co][ci][tap] (+= when accumulate): 64 partial-sum columns x 4
 // item lanes per workgroup, fixed summation order.  D layout of the MFMA: lane & 15 = cin, (lane >> 4) * 4 + r = cout.
 struct TrRedArgs {
@@ -349,6 +650,38 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   return fd_launch(&wgrad_tr_bias_reduce_kernel, "wgrad_tr_bias_reduce", dim3((unsigned)((a.Cout + 63) / 64)), dim3(64), 0, rb, stream);
 }
 
+template <bool RELU, int DBG = 0>
+int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, int accumulate, hipStream_t stream,
+              const char* name) {
+  a.xblocks = a.Wo / G3_PB;
+  const long long strips = nimg * a.xblocks, ci_tiles = a.Cin / 128, zt = a.Cout / 32;
+  const long long item_stride = ci_tiles * zt * 8 * 9 * 512;
+  if (strips * item_stride > workspace_floats || strips >= 65536) return 1;
+  static const char* wgs_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
+  const long long base = strips * ci_tiles * zt;
+  long long segs = (wgs_env ? atoll(wgs_env) : 256) / base;   // one resident workgroup per CU
+  if (segs < 1) segs = 1;
+  if (segs > (a.Ho + 3) / 4) segs = (a.Ho + 3) / 4;             // two of a segment's steps only see one or two of its rows
+  while (segs > 1 && (strips * segs * item_stride > workspace_floats || strips * segs >= 65536)) --segs;
+  a.seg_rows = (int)((a.Ho + segs - 1) / segs);
+  a.segs = (int)((a.Ho + a.seg_rows - 1) / a.seg_rows);
+  a.part = workspace;
+  a.bias_part = nullptr;
+  a.dbg_skip = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_r3_kernel<RELU, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(%s): %s", name, hipGetErrorString(e));
+    attr_done = true;
+  }
+  const long long items = strips * a.segs;
+  if (int rc = fd_launch(&conv_wgrad_r3_kernel<RELU, DBG>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(512), R3_LDS, a, stream))
+    return rc;
+  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 3, 3, 8, 9, a.Cin, a.Cout, accumulate};
+  return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
+}
+
 }  // namespace
 
 // Which instantiation covers a stride-1 conv (0: none, the caller uses the per-tap kernel).  3x3 pad 1: 8, 5 or 3 cin
@@ -376,7 +709,31 @@ int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, boo
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
                          float* dbias, int accumulate, hipStream_t stream) {
   switch (variant) {
-    case 8: return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8");
+    case 8: {
+      static const char* r3 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R3");   // tuning aid: '0' first-generation kernel
+      if (dbias == nullptr && a.Cin % 128 == 0 && a.Cout % 32 == 0 && a.Wo % G3_PB == 0 && a.W == a.Wo && !(r3 && r3[0] == '0')) {
+#ifdef FDGAN_TUNING
+        if (const char* dbg = getenv("FDGAN_DEBUG_R3DBG")) {
+          switch (atoi(dbg)) {
+            case 1: return r3_launch<true, 1>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg1");
+            case 2: return r3_launch<true, 2>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg2");
+            case 4: return r3_launch<true, 4>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg4");
+            case 8: return r3_launch<true, 8>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg8");
+            case 6: return r3_launch<true, 6>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg6");
+            case 14: return r3_launch<true, 14>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg14");
+            case 15: return r3_launch<true, 15>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg15");
+            case 32: return r3_launch<true, 32>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg32");
+            case 64: return r3_launch<true, 64>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg64");
+            case 96: return r3_launch<true, 96>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg96");
+            case 7: return r3_launch<true, 7>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg7");
+          }
+        }
+#endif
+        if (a.pro_mode != 0 && a.p_slope == 0.f) return r3_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3");
+        return r3_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_leaky");
+      }
+      return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8");
+    }
     case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5");
     case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3");
     case 9: return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr");
