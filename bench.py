@@ -545,7 +545,9 @@ def main():
                              "GB/s": round(c["bytes"] / (c["ms"] * 1e-3) / 1e9, 1) if c["bytes"] else None,
                              "TFLOP/s": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 1) if c["flops"] else None})
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
-            with open(a.breakdown, "w") as f:
+            # attached to the training line: the step's own table already sits in a.breakdown
+            path = a.breakdown if train_res is None else os.path.splitext(a.breakdown)[0] + "_forward.json"
+            with open(path, "w") as f:
                 json.dump({"total_ms_instrumented": total_ms, "rows": rows}, f, indent=1)
         if train_res is not None:       # default line: the training step, with the forward-only measurement attached
             train_res["forward_only"] = {"value": res["value"], "unit": "images/sec", "ms_per_step": res["ms_per_step"],

@@ -196,6 +196,265 @@ __global__ __launch_bounds__(512) void conv3x3_bwd_kernel(Bwd3Args a) {
   }
 }
 
+// ---- second generation (image width a multiple of 64).  What the first kernel paid for: 45 LDS fragment reads per 36 MFMAs
+// (the filter lived in LDS), a row phase with nothing to overlap (both waves of a SIMD reach it together), 7200 cycles per
+// row.  Here:
+//   * wave (w & 1, w >> 1) owns 32 pixels x 32 channels: its 18 filter fragments (9 taps x 2 channel tiles) stay in
+//     REGISTERS for the whole kernel -- no filter in LDS, no A-operand reads; 18 dy-fragment reads per 36 MFMAs;
+//   * the row phase of output row y - 1 (mask by act'(bn(x)), BatchNorm sums, scale, store) is issued between the MFMAs of
+//     row y: the accumulator tile of a finished row waits in the wave's LDS transposition tile, so VALU and matrix pipe
+//     overlap inside every wave;
+//   * dy rows two steps, x rows one step ahead in registers; a 4-slot dy ring, one raw barrier per row.
+// Four steps unrolled: every register set and LDS slot is a compile-time constant.
+template <int V> struct IC3 { static constexpr int value = V; };
+constexpr int B4_DROW = 66 * 64;                 // a staged dy row: 66 pixels x 32 channels
+constexpr int B4_TBP = 80;                       // transposition pitch of one pixel (32 channels x 2 B + 16)
+constexpr int B4_TB = 32 * B4_TBP;
+constexpr int B4_WF = 6 * 1024;                  // a wave's filter fragments of the third filter row
+constexpr int B4_LDS = 4 * B4_DROW + 8 * B4_TB + 8 * B4_WF;
+
+// a pointer hipcc must keep in SGPRs: the loads that add a 32-bit lane offset to it take the saddr form instead of keeping one
+// 64-bit lane pointer per stream alive (those were what spilled)
+typedef __attribute__((address_space(1))) char* b4_gptr;   // explicitly global: an integer round trip must not turn it into a flat pointer
+__device__ __forceinline__ b4_gptr b4_uniform(const unsigned short* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (b4_gptr)(((unsigned long long)hi << 32) | lo);
+}
+typedef __attribute__((address_space(1))) u32x4* b4_g16;
+
+template <int ACC>
+__global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char b3_lds[];
+  char* ring = b3_lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kgl = lane >> 4;
+  const int pxh = wave & 1, chq = wave >> 1;                  // 32-pixel half, 32-channel quarter
+  char* tb = b3_lds + 4 * B4_DROW + wave * B4_TB;
+  const int item = blockIdx.x;
+  const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
+  const int y_begin = seg * a.seg_rows, y_end = min(a.H, y_begin + a.seg_rows);
+  const int rows = y_end - y_begin, xbase = xb * B3_PB;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  // ---- filter fragments of this wave's two 16-channel tiles, once: filter rows 0 and 1 stay in registers (48), row 2 in
+  // a wave-private LDS area (all 18 in registers did not fit beside the row phase: scratch reloads drained the prefetch)
+  bf16x8 A[6][2];
+  char* wf = b3_lds + 4 * B4_DROW + 8 * B4_TB + wave * B4_WF + lane * 16;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const u32x4 f = *reinterpret_cast<const u32x4*>(a.w + ((long long)((t * 8 + chq * 2 + c2) * 64 + lane)) * 8);
+      if (t < 6) A[t][c2] = __builtin_bit_cast(bf16x8, f);
+      else lds_write16(wf + ((t - 6) * 2 + c2) * 1024, f);
+    }
+  // ---- row phase ownership: lane -> 8 channels (piece) of pixels pl0 and pl0 + 16 of the wave's 32
+  const int piece = lane & 3, pl0 = lane >> 2;
+  const int cg = chq * 32 + piece * 8;
+  float sc8[8], sh8[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg + e;
+    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
+    if (a.mode == 2) {
+      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
+      sh8[e] = bt - a.mean[c] * sc8[e];
+    }
+  }
+  // ---- dy staging: thread -> (pixel tid / 4, 16-byte piece tid % 4) of the 66-pixel row; waves 0-4 (264 threads).
+  // Row index rr counts from the segment's first halo row: rr = row - (y_begin - 1); slot = rr & 3.
+  const int dpix = tid >> 2, dpiece = tid & 3;
+  const bool d_wave = wave <= 4, d_thr = dpix < 66;
+  const int dpx = xbase - 1 + dpix;
+  const bool dcol = d_thr && dpx >= 0 && dpx < a.W;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn;
+  const unsigned dvo = dcol ? 2u * (unsigned)(dpx * a.dy_sw + dpiece * 8) : 0u;   // bytes
+  char* dwp = ring + (d_thr ? dpix * 64 + dpiece * 16 : 0);
+  u32x4 dyr[2];
+  unsigned dym[2];
+  auto request_dy = [&](int rr, auto S) __attribute__((always_inline)) {
+    constexpr int s_ = decltype(S)::value;
+    if (d_wave) {
+      const int row = y_begin - 1 + rr;
+      const bool rok = row >= 0 && row < a.H && rr <= rows + 1;
+      dyr[s_] = *(b4_g16)(b4_uniform(dimg + (long long)min(max(row, 0), a.H - 1) * a.dy_sh) + dvo);
+      dym[s_] = rok && dcol ? 0xffffffffu : 0u;
+    }
+  };
+  auto store_dy = [&](auto S, auto SLOT) __attribute__((always_inline)) {
+    constexpr int s_ = decltype(S)::value, sl = decltype(SLOT)::value;
+    if (d_wave) {
+      u32x4 v = dyr[s_];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] &= dym[s_];
+      if (d_thr) lds_write16(dwp + sl * B4_DROW, v);
+    }
+  };
+  // ---- x / G rows: two 16-byte units per lane (pixels pl0, pl0 + 16), wave-uniform row pointer + 32-bit lane offset
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn;
+  unsigned short* gimg = a.g + (long long)n * a.g_sn;
+  unsigned xvo[2], gvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int px = xbase + pxh * 32 + pl0 + 16 * i;
+    xvo[i] = 2u * (unsigned)(px * a.x_sw + cg);   // bytes
+    gvo[i] = 2u * (unsigned)(px * a.g_sw + cg);
+  }
+  u32x4 xs[2][2], gs[2][2];
+  auto request_rows = [&](int row, auto S) __attribute__((always_inline)) {   // clamped to the segment: always readable
+    constexpr int s_ = decltype(S)::value;
+    const int rc = min(max(row, y_begin), y_end - 1);
+    const b4_gptr xrow = b4_uniform(ximg + (long long)rc * a.x_sh);
+    const b4_gptr grow = b4_uniform(gimg + (long long)rc * a.g_sh);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      xs[s_][i] = *(b4_g16)(xrow + xvo[i]);
+      if constexpr (ACC == 1) gs[s_][i] = *(b4_g16)(grow + gvo[i]);
+    }
+  };
+  // B fragment (pixel tile t, shift kx) of a staged row = 16 pixels x 64 B starting at pixel 32 pxh + 16 t + kx
+  const char* bptr = ring + (pxh * 32 + m) * 64 + kgl * 16;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one unit (8 channels of one pixel) of the row phase of output row yr: inputs in registers, result returned
+  // (w1, w0): the activation's two slopes, or (0, 0) when the step has no row to finish -- uniform VALUES, not a branch
+  auto row_unit = [&](u32x4 dat, u32x4 xv, u32x4 gv, float w1, float w0) __attribute__((always_inline)) -> u32x4 {
+    const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dat), f32x8);
+    const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv), f32x8);
+    f32x8 o;
+    if constexpr (ACC == 1) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv), f32x8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pre = fmaf(fx[e], sc8[e], sh8[e]);
+      const float v = da[e] * (pre > 0.f ? w1 : w0);
+      s1[e] += v;
+      s2[e] += v * fx[e];
+      o[e] = ACC == 1 ? fmaf(sc8[e], v, o[e]) : (ACC == 2 ? sc8[e] * v : v);
+    }
+    return __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+  };
+
+  // ---- prologue: dy rows rr = 0 .. 2 in LDS, rr = 3, 4 requested; x (and G) of the first row requested
+  request_dy(0, IC3<0>{});
+  request_dy(1, IC3<1>{});
+  store_dy(IC3<0>{}, IC3<0>{});
+  store_dy(IC3<1>{}, IC3<1>{});
+  request_dy(2, IC3<0>{});
+  store_dy(IC3<0>{}, IC3<2>{});
+  request_dy(3, IC3<0>{});
+  request_rows(y_begin, IC3<0>{});
+  request_rows(y_begin, IC3<1>{});
+  for (int q = lane; q < B4_TB / 16; q += 64) lds_write16(tb + q * 16, zero4);   // read by the first step's (disabled) row phase
+  B3_BARRIER();
+
+  // step j (phase P = j mod 4): MFMAs of output row y_begin + j from the dy rows rr = j, j + 1, j + 2, interleaved with the
+  // row phase of output row y_begin + j - 1
+  auto step = [&](int j, auto P) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value, p2 = p & 1;
+    // dy: row rr = j + 3 (requested a step ago) into the slot row rr = j - 1 left; then request rr = j + 4
+    store_dy(IC3<0>{}, IC3<(p + 3) & 3>{});
+    request_dy(j + 4, IC3<0>{});
+    const int yr = y_begin + j - 1;
+    const bool rp_ok = j >= 1 && j <= rows;
+    const float w1 = rp_ok ? 1.f : 0.f, w0 = rp_ok ? a.slope : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      u32x4 dat = zero4;
+      if (ky < 2) dat = lds_read16(tb + (pl0 + 16 * ky) * B4_TBP + piece * 16);
+      const char* rowp = bptr + ((p + ky) & 3) * B4_DROW;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(rowp + (16 * t + kx) * 64));
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const bf16x8 afr = ky < 2 ? A[ky * 3 + kx][c2] : __builtin_bit_cast(bf16x8, lds_read16(wf + (kx * 2 + c2) * 1024));
+            acc[t][c2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[t][c2], 0, 0, 0);
+          }
+        }
+      u32x4 outv = zero4;
+      if (ky < 2) outv = row_unit(dat, xs[p2 ^ 1][ky], gs[p2 ^ 1][ky], w1, w0);   // one unit of the row phase per 12-MFMA block
+      // issue order of the block: two fragment reads ahead, then per fragment its two MFMAs with the row phase's VALU work
+      // in their shadow and the read of the fragment after next (unconstrained, hipcc hoists all 18 reads and spills)
+      if (ky < 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (ky < 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (ky < 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (ky == 2 && q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ky < 2 && rp_ok) *(b4_g16)(b4_uniform(gimg + (long long)yr * a.g_sh) + gvo[ky]) = outv;
+    }
+    // ---- this row's accumulators -> the transposition tile (bf16), accumulators cleared
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){acc[t][c2][0], acc[t][c2][1], acc[t][c2][2], acc[t][c2][3]}, bf16x4_t));
+        *reinterpret_cast<u32x2*>(tb + (16 * t + m) * B4_TBP + c2 * 32 + kgl * 8) = bits;
+        acc[t][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    request_rows(y_begin + j + 1, IC3<p2 ^ 1>{});   // x of the NEXT step's output row: its row phase runs two steps from now
+    B3_BARRIER();
+  };
+  const int nloop = (rows + 3) & ~3;
+  for (int j = 0; j < nloop; j += 4) {
+    step(j, IC3<0>{});
+    step(j + 1, IC3<1>{});
+    step(j + 2, IC3<2>{});
+    step(j + 3, IC3<3>{});
+  }
+  if (nloop == rows) {   // the last row's phase (otherwise it ran inside one of the padding steps)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const u32x4 dat = lds_read16(tb + (pl0 + 16 * i) * B4_TBP + piece * 16);
+      const u32x4 outv = row_unit(dat, xs[1][i], gs[1][i], 1.f, a.slope);   // rows is a multiple of 4: step rows - 1 left its row in set 1... see request_rows
+      *(b4_g16)(b4_uniform(gimg + (long long)(y_end - 1) * a.g_sh) + gvo[i]) = outv;
+    }
+  }
+  if (a.partial != nullptr) {   // lanes 4 apart own the same channels; then the two pixel halves in a fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int d = 4; d < 64; d <<= 1) {
+        s1[e] += __shfl_xor(s1[e], d, 64);
+        s2[e] += __shfl_xor(s2[e], d, 64);
+      }
+    B3_BARRIER();                                             // every wave is through its last row phase (red aliases the tiles)
+    float* red = reinterpret_cast<float*>(b3_lds + 4 * B4_DROW);   // [8 waves][32][2]
+    if (pl0 == 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 32 + piece * 8 + e) * 2] = s1[e];
+        red[(wave * 32 + piece * 8 + e) * 2 + 1] = s2[e];
+      }
+    B3_BARRIER();
+    if (tid < 256) {
+      const int c = tid >> 1, which = tid & 1, q = c >> 5, cl = c & 31;   // channel quarter q: waves 2 q, 2 q + 1
+      const float t = red[((2 * q) * 32 + cl) * 2 + which] + red[((2 * q + 1) * 32 + cl) * 2 + which];
+      a.partial[((long long)item * 128 + c) * 2 + which] = t;
+    }
+  }
+}
+
 }  // namespace
 
 bool conv3x3_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre, const FdConvDesc* d) {
@@ -238,6 +497,13 @@ int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv3x3_bwd): %s", hipGetErrorString(e));
     attr_done = true;
+  }
+  if (a.W % B3_PB == 0 && FD_TUNE_GETENV("FDGAN_DEBUG_BWD3_V1") == nullptr) {   // second-generation kernel
+    switch (a.acc) {
+      case 0: return fd_launch(&conv3x3_bwd2_kernel<0>, "conv3x3_bwd_stream2", dim3((unsigned)items), dim3(512), B4_LDS, a, stream);
+      case 1: return fd_launch(&conv3x3_bwd2_kernel<1>, "conv3x3_bwd_stream2", dim3((unsigned)items), dim3(512), B4_LDS, a, stream);
+      default: return fd_launch(&conv3x3_bwd2_kernel<2>, "conv3x3_bwd_stream2", dim3((unsigned)items), dim3(512), B4_LDS, a, stream);
+    }
   }
   return fd_launch(&conv3x3_bwd_kernel, "conv3x3_bwd_stream", dim3((unsigned)items), dim3(512), B3_LDS, a, stream);
 }
