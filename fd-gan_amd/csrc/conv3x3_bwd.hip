@@ -208,7 +208,11 @@ __global__ __launch_bounds__(512) void conv3x3_bwd_kernel(Bwd3Args a) {
 // Four steps unrolled: every register set and LDS slot is a compile-time constant.
 template <int V> struct IC3 { static constexpr int value = V; };
 constexpr int B4_DROW = 66 * 64;                 // a staged dy row: 66 pixels x 32 channels
-constexpr int B4_TBP = 80;                       // transposition pitch of one pixel (32 channels x 2 B + 16)
+constexpr int B4_TBP = 64;                       // transposition tile: 32 channels x 2 B per pixel, no padding: the 16-byte unit u
+                                                 // of pixel p sits at u ^ ((p >> 1) & 3), which makes the ds_read_b128 lane groups
+                                                 // (pixels {0,3,5,6} / {1,2,4,7} of eight) cover all 64 banks once and the
+                                                 // ds_write_b64 of the accumulators 2-way at worst (pitch 80 measured 2 conflict
+                                                 // cycles per LDS cycle)
 constexpr int B4_TB = 32 * B4_TBP;
 constexpr int B4_WF = 6 * 1024;                  // a wave's filter fragments of the third filter row
 constexpr int B4_LDS = 4 * B4_DROW + 8 * B4_TB + 8 * B4_WF;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       u32x4 dat = zero4;
-      if (ky < 2) dat = lds_read16(tb + (pl0 + 16 * ky) * B4_TBP + piece * 16);
+      if (ky < 2) dat = lds_read16(tb + (pl0 + 16 * ky) * B4_TBP + ((piece ^ ((pl0 >> 1) & 3)) << 4));
       const char* rowp = bptr + ((p + ky) & 3) * B4_DROW;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
         const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){acc[t][c2][0], acc[t][c2][1], acc[t][c2][2], acc[t][c2][3]}, bf16x4_t));
-        *reinterpret_cast<u32x2*>(tb + (16 * t + m) * B4_TBP + c2 * 32 + kgl * 8) = bits;
+        *reinterpret_cast<u32x2*>(tb + (16 * t + m) * B4_TBP + (((c2 * 2 + (kgl >> 1)) ^ ((m >> 1) & 3)) << 4) + (kgl & 1) * 8) = bits;
         acc[t][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const u32x4 dat = lds_read16(tb + (pl0 + 16 * i) * B4_TBP + piece * 16);
+      const u32x4 dat = lds_read16(tb + (pl0 + 16 * i) * B4_TBP + ((piece ^ ((pl0 >> 1) & 3)) << 4));
       const u32x4 outv = row_unit(dat, xs[1][i], gs[1][i], 1.f, a.slope);   // rows is a multiple of 4: step rows - 1 left its row in set 1... see request_rows
       *(b4_g16)(b4_uniform(gimg + (long long)(y_end - 1) * a.g_sh) + gvo[i]) = outv;
     }

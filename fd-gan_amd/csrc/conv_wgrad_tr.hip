@@ -713,7 +713,7 @@ int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* w
       static const char* r3 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R3");   // tuning aid: '0' first-generation kernel
       if (dbias == nullptr && a.Cin % 128 == 0 && a.Cout % 32 == 0 && a.Wo % G3_PB == 0 && a.W == a.Wo && !(r3 && r3[0] == '0')) {
 #ifdef FDGAN_TUNING
-        if (const char* dbg = getenv("FDGAN_DEBUG_R3DBG")) {
+        if (const char* dbg = FD_TUNE_GETENV("FDGAN_DEBUG_R3DBG")) {
           switch (atoi(dbg)) {
             case 1: return r3_launch<true, 1>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg1");
             case 2: return r3_launch<true, 2>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_dbg2");

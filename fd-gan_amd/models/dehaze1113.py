@@ -22,7 +22,9 @@ from . import tv_densenet121 as _tv
 
 
 class _PlannedModule(nn.Module):
-    """Caches one NetPlan per (shape, BN train/eval flags, parameter storage)."""
+    """Caches one NetPlan per (shape, BN train/eval flags, parameter storage), least-recently-used first out: a plan owns
+    its whole activation set (and, once trained through, a PlanBackward workspace), so the cache is bounded."""
+    MAX_PLANS = 8
 
     def _plan_for(self, x):
         E.require_gpu(x, type(self).__name__ + ".forward")
@@ -33,9 +35,11 @@ class _PlannedModule(nn.Module):
         # next to 288 GB); an inference plan reuses one bottleneck buffer per dense block
         keep = self.__dict__.get("_in_autograd", False) or _wants_grad(self, x)    # grad mode is off inside Function.forward
         key = (tuple(x.shape), x.device.index, bn_flags(self), keep)
-        plan = cache.get(key)
-        if plan is not None and plan.param_ptrs() != plan._built_ptrs:
-            plan = None                                   # parameters were moved / re-allocated
+        # plans whose parameters were moved / re-allocated (FlatAdam re-points them into its flat buffer, .to()) can never
+        # be used again: drop them and their activation sets instead of keeping them behind a dead key
+        for k_ in [k_ for k_, pl in cache.items() if pl.param_ptrs() != pl._built_ptrs]:
+            del cache[k_]
+        plan = cache.pop(key, None)                       # re-inserted below: the dict's order is the LRU order
         if plan is None:
             for p in self.parameters():
                 if p.device != x.device:
@@ -43,8 +47,10 @@ class _PlannedModule(nn.Module):
             self.__dict__["_plan_keep"] = keep
             plan = self._build_plan(tuple(x.shape), x.device)
             plan._built_ptrs = plan.param_ptrs()
-            cache[key] = plan
-        self.__dict__.setdefault("_last_plan", {})[key[:3]] = plan
+            while len(cache) >= self.MAX_PLANS:           # least recently used first
+                cache.pop(next(iter(cache)))
+        cache[key] = plan
+        self.__dict__.setdefault("_last_plan", {})[key[:3]] = key     # a key, not the plan: eviction must free it
         return plan
 
     def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
@@ -56,6 +62,7 @@ class _PlannedModule(nn.Module):
         """The NetPlan serving inputs shaped like `x` (for benchmarks / profiling): the one the last forward of that
         shape ran (training and inference plans differ in what they keep), else a new one for the current grad mode."""
         last = self.__dict__.get("_last_plan", {}).get((tuple(x.shape), x.device.index, bn_flags(self)))
+        last = self.__dict__.get("_plans", {}).get(last) if last is not None else None
         if last is not None and last.param_ptrs() == last._built_ptrs:
             return last
         return self._plan_for(x)

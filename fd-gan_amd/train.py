@@ -106,6 +106,8 @@ class TrainStep:
         for n, m in module.named_modules():                          # the probe must not count as a training step
             if n in was:
                 m.running_mean.copy_(was[n][0]), m.running_var.copy_(was[n][1]), m.num_batches_tracked.copy_(was[n][2])
+        module.__dict__.pop("_plans", None)                          # the 1x3x32x32 probe plan and its buffers
+        module.__dict__.pop("_last_plan", None)
         return got
 
     def _set_d_grad(self, flag):

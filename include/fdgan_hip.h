@@ -22,6 +22,18 @@
  *    (torch.cat, dehaze1113.py:275,773,783,786, is never materialised).
  *    stride[2] (the pixel pitch) must be a multiple of 8 elements and ptr 16-byte
  *    aligned.  Network input / output may be NCHW fp32 (dtype FD_F32).
+ *
+ * What is deliberately NOT behind this boundary: the data-parallel gradient exchange.
+ * The reference's only multi-GPU mechanism is nn.DataParallel (demo.py:89); a trainer
+ * built on it would reduce gradients with torch.distributed.  The training path here
+ * keeps parameters and gradients in two flat fp32 buffers (fdgan_adam_step below
+ * takes exactly those), so the exchange is a handful of large torch.distributed
+ * all_reduce calls on slices of one buffer -- RCCL on its own stream, overlapped with
+ * the backward walk (fdgan_hip/optim.py: FlatAdam.overlap).  An fdgan_allreduce_*
+ * entry point would have to own an ncclComm_t, a bootstrap (ncclUniqueId exchange)
+ * and a stream: state and rendezvous the host framework already has, with nothing
+ * for a gfx950 kernel to add.  A host that is not PyTorch calls ncclAllReduce on the
+ * same two buffers.
  */
 #ifndef FDGAN_HIP_H
 #define FDGAN_HIP_H
