@@ -1,0 +1,153 @@
+// legacy.hip -- the two element-wise pieces the DCPDN-era networks of the reference need beside the convolution kernels
+// (models/dehaze22.py G :205-362, G2 :364-488, Dense :531-660, dehaze :662-753):
+//
+//   fdgan_pyramid_pool4   the "1mm" multi-scale head (dehaze22.py:343-356, :634-651): for four window sizes k0, k0/2, k0/4,
+//                         k0/8:  avg_pool2d(x, k) -> Conv2d(C, 1, 1) -> LeakyReLU(0.2) -> upsample_nearest(size of x).
+//                         The 1x1 conv is linear, so it commutes with the average: per pixel four dot products, block means,
+//                         bias, activation, broadcast -- one pass over x, one 8-byte store per pixel, nothing intermediate.
+//   fdgan_bn_dropout_nhwc y = mask[n][c] * bn(x): train-mode BatchNorm followed by train-mode Dropout2d (a per-(sample,
+//                         channel) mask, dehaze22.py:60-63) on the U-Net's three innermost decoder outputs (at most 8 x 8
+//                         pixels): the consumer then sees finished values.
+#include "common.h"
+
+namespace {
+
+struct PyrArgs {
+  const unsigned short* x;
+  long long x_sn, x_sh, x_sw;
+  unsigned short* y;
+  long long y_sn, y_sh, y_sw;
+  const float* w;   // [4][C]
+  const float* b;   // [4]
+  int C, k0, tiles_x, tiles_y;
+  float slope;
+};
+
+// one workgroup per k0 x k0 tile of one image; k0 = 8 f, f = the finest window
+__global__ __launch_bounds__(256) void pyramid_pool4_kernel(PyrArgs a) {
+  extern __shared__ float pyr_lds[];
+  float* s = pyr_lds;                       // [4][k0 * k0] per-pixel dot products
+  float* t = s + 4 * a.k0 * a.k0;           // [4][64] sums of the f x f blocks
+  float* m = t + 256;                       // [4][64] value of the window each fine block lies in, per scale
+  float* wl = m + 256;                      // [4][C]
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x % (a.tiles_x * a.tiles_y), n = blockIdx.x / (a.tiles_x * a.tiles_y);
+  const int ty = tile / a.tiles_x, tx = tile % a.tiles_x;
+  const int k0 = a.k0, f = k0 / 8, npx = k0 * k0;
+  for (int i = tid; i < 4 * a.C; i += 256) wl[i] = a.w[i];
+  __syncthreads();
+  const unsigned short* xb = a.x + n * a.x_sn + (long long)(ty * k0) * a.x_sh + (long long)(tx * k0) * a.x_sw;
+  for (int p = tid; p < npx; p += 256) {
+    const int py = p / k0, px = p % k0;
+    const unsigned short* xp = xb + py * a.x_sh + px * a.x_sw;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      const float v = __uint_as_float((unsigned)xp[c] << 16);
+      d0 = fmaf(v, wl[c], d0);
+      d1 = fmaf(v, wl[a.C + c], d1);
+      d2 = fmaf(v, wl[2 * a.C + c], d2);
+      d3 = fmaf(v, wl[3 * a.C + c], d3);
+    }
+    s[p] = d0, s[npx + p] = d1, s[2 * npx + p] = d2, s[3 * npx + p] = d3;
+  }
+  __syncthreads();
+  {   // thread (scale j, fine block b): sum of its f x f values, rows then columns (fixed order)
+    const int j = tid >> 6, bidx = tid & 63, by = bidx >> 3, bx = bidx & 7;
+    float acc = 0.f;
+    for (int r = 0; r < f; ++r)
+      for (int q = 0; q < f; ++q) acc += s[j * npx + (by * f + r) * k0 + bx * f + q];
+    t[j * 64 + bidx] = acc;
+  }
+  __syncthreads();
+  {   // scale j has windows of g x g fine blocks, g = 8 >> j: every fine block learns its window's mean
+    const int j = tid >> 6, bidx = tid & 63, by = bidx >> 3, bx = bidx & 7;
+    const int g = 8 >> j, wy = by / g * g, wx = bx / g * g;
+    float acc = 0.f;
+    for (int r = 0; r < g; ++r)
+      for (int q = 0; q < g; ++q) acc += t[j * 64 + (wy + r) * 8 + wx + q];
+    const float v = acc / (float)(g * f * g * f) + a.b[j];
+    m[j * 64 + bidx] = fmaxf(v, a.slope * v);
+  }
+  __syncthreads();
+  unsigned short* yb = a.y + n * a.y_sn + (long long)(ty * k0) * a.y_sh + (long long)(tx * k0) * a.y_sw;
+  for (int p = tid; p < npx; p += 256) {
+    const int py = p / k0, px = p % k0, bidx = (py / f) * 8 + px / f;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((ext_vector_type(4))) float f4_t;
+    const bf16x4_t o = __builtin_convertvector((f4_t){m[bidx], m[64 + bidx], m[128 + bidx], m[192 + bidx]}, bf16x4_t);
+    *reinterpret_cast<u32x2*>(yb + py * a.y_sh + px * a.y_sw) = __builtin_bit_cast(u32x2, o);
+  }
+}
+
+struct BnDropArgs {
+  const unsigned short* x;
+  unsigned short* y;
+  long long x_sn, x_sh, x_sw, y_sn, y_sh, y_sw, h, w;
+  const float *mean, *var, *gamma, *beta, *mask;   // per channel (mean NULL: no normalisation); mask [N][C] or NULL
+  float eps;
+  int C, groups;
+  long long total;
+};
+
+__global__ void bn_dropout_kernel(BnDropArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  long long r = u;
+  const int g = (int)(r % a.groups);
+  r /= a.groups;
+  const long long px = r % a.w;
+  r /= a.w;
+  const long long py = r % a.h, n = r / a.h;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + py * a.x_sh + px * a.x_sw + g * 8);
+  f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = g * 8 + e;
+    float o = 0.f;
+    if (c < a.C) {
+      o = f[e];
+      if (a.mean != nullptr) {
+        const float sc = (a.gamma ? a.gamma[c] : 1.f) / sqrtf(a.var[c] + a.eps);
+        o = fmaf(o, sc, (a.beta ? a.beta[c] : 0.f) - a.mean[c] * sc);
+      }
+      if (a.mask != nullptr) o *= a.mask[n * a.C + c];
+    }
+    f[e] = o;
+  }
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+}
+
+}  // namespace
+
+extern "C" int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* y,
+                                   FdStream stream) {
+  FD_REQUIRE(x && y && x->ptr && y->ptr && weight && bias, "pyramid_pool4: NULL pointer");
+  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "pyramid_pool4: NHWC bf16 views required");
+  FD_REQUIRE(k0 == 16 || k0 == 32, "pyramid_pool4: largest window %d (16 or 32: windows k0, k0/2, k0/4, k0/8)", k0);
+  FD_REQUIRE(x->n == y->n && x->h == y->h && x->w == y->w && y->c == 4 && x->c >= 1 && x->c <= 64, "pyramid_pool4: shapes");
+  FD_REQUIRE(x->h % k0 == 0 && x->w % k0 == 0, "pyramid_pool4: %lld x %lld is not a multiple of the largest window %d", (long long)x->h,
+             (long long)x->w, k0);
+  FD_REQUIRE(((uintptr_t)y->ptr & 7) == 0 && y->stride[2] % 4 == 0 && y->stride[1] % 4 == 0 && y->stride[0] % 4 == 0,
+             "pyramid_pool4: the four output channels must be 8-byte aligned");
+  PyrArgs a{static_cast<const unsigned short*>(x->ptr), x->stride[0], x->stride[1], x->stride[2],
+            static_cast<unsigned short*>(y->ptr), y->stride[0], y->stride[1], y->stride[2], weight, bias,
+            (int)x->c, k0, (int)(x->w / k0), (int)(x->h / k0), slope};
+  const unsigned lds = (4 * k0 * k0 + 512 + 4 * (unsigned)x->c) * 4;
+  return fd_launch(&pyramid_pool4_kernel, "pyramid_pool4", dim3((unsigned)(x->n * a.tiles_x * a.tiles_y)), dim3(256), lds, a,
+                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_bn_dropout_nhwc(const FdTensor* x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                     const float* mask, const FdTensor* y, FdStream stream) {
+  FD_REQUIRE(x && y && x->ptr && y->ptr, "bn_dropout_nhwc: NULL pointer");
+  FD_REQUIRE((mean == nullptr) == (var == nullptr), "bn_dropout_nhwc: mean and var go together");
+  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "bn_dropout_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(x->n == y->n && x->h == y->h && x->w == y->w && x->c == y->c, "bn_dropout_nhwc: shape mismatch");
+  FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0, "bn_dropout_nhwc: 16-byte alignment");
+  for (int i = 0; i < 3; ++i) FD_REQUIRE(x->stride[i] % 8 == 0 && y->stride[i] % 8 == 0, "bn_dropout_nhwc: strides must be multiples of 8");
+  const int groups = (int)((x->c + 7) / 8);
+  BnDropArgs a{static_cast<const unsigned short*>(x->ptr), static_cast<unsigned short*>(y->ptr), x->stride[0], x->stride[1], x->stride[2],
+               y->stride[0], y->stride[1], y->stride[2], x->h, x->w, mean, var, gamma, beta, mask, eps, (int)x->c, groups,
+               x->n * x->h * x->w * groups};
+  return fd_launch(&bn_dropout_kernel, "bn_dropout_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}

@@ -232,6 +232,41 @@ def copy_nhwc(src, dst):
     L.check(L.load().fdgan_copy_nhwc(C.byref(src.fd), C.byref(dst.fd), stream_ptr()), "copy_nhwc")
 
 
+def pyramid_pool4(x, weight, bias, k0, slope, y):
+    """x, y: View (y: 4 channels).  weight (4, C) / bias (4,) fp32 device tensors.  include/fdgan_hip.h: fdgan_pyramid_pool4."""
+    L.check(L.load().fdgan_pyramid_pool4(C.byref(x.fd), weight.data_ptr(), bias.data_ptr(), int(k0), float(slope), C.byref(y.fd),
+                                         stream_ptr()), "pyramid_pool4")
+
+
+def bn_dropout(x, mean, var, gamma, beta, eps, mask, y):
+    """y = mask[n][c] * bn(x) on NHWC bf16 views; any of (mean, var) / gamma / beta / mask may be None."""
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    L.check(L.load().fdgan_bn_dropout_nhwc(C.byref(x.fd), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(mask),
+                                           C.byref(y.fd), stream_ptr()), "bn_dropout_nhwc")
+
+
+class StridedView:
+    """An NHWC bf16 view that steps over rows and pixels of its buffer: channels [c0, c0 + c) of the pixels
+    (y0 + sy i, x0 + sx j), i < h, j < w -- the output positions of one parity of a stride-2 transposed convolution."""
+    __slots__ = ("buf", "c0", "c", "fd")
+
+    def __init__(self, buf, c0, c, y0, x0, sy, sx, h, w):
+        assert buf.dtype == torch.bfloat16 and buf.dim() == 4 and buf.is_contiguous()
+        n, hh, ww, ctot = buf.shape
+        assert y0 + sy * (h - 1) < hh and x0 + sx * (w - 1) < ww and c0 + c <= ctot
+        self.buf, self.c0, self.c = buf, c0, c
+        t = L.FdTensor()
+        t.ptr = buf.data_ptr() + 2 * ((y0 * ww + x0) * ctot + c0)
+        t.n, t.h, t.w, t.c = n, h, w, c
+        t.stride[0], t.stride[1], t.stride[2], t.stride[3] = hh * ww * ctot, sy * ww * ctot, sx * ctot, 1
+        t.dtype = L.FD_BF16
+        self.fd = t
+
+    @property
+    def shape(self):
+        return self.fd.n, self.fd.h, self.fd.w, self.c
+
+
 class Plan:
     """RAII wrapper of FdPlan: `with plan.record(): <op calls>` then plan.launch()."""
 

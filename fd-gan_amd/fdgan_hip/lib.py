@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FdganLibraryError(RuntimeError):
@@ -75,6 +75,9 @@ SIGNATURES = {
                                               C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_nhwc_bf16_to_nchw_f32": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p]),
     "fdgan_copy_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_pyramid_pool4": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_bn_dropout_nhwc": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                              C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_plan_create": (C.c_void_p, []),
     "fdgan_plan_destroy": (None, [C.c_void_p]),
     "fdgan_plan_begin": (C.c_int, [C.c_void_p]),

@@ -1,7 +1,10 @@
 """`models.dehaze22` surface of the reference (/root/reference/models/dehaze22.py): the pix2pix
-PatchGAN discriminator `D(nc, nf)` (:114-156) on the HIP path.  The legacy DCPDN generators in that
-file (G :205, G2 :364, dehaze :662) are not on FD-GAN's hot path and are not
-provided; asking for them raises.
+PatchGAN discriminator `D(nc, nf)` (:114-156, `D_tran` :159-201 is the same network) and, from the
+DCPDN-era generators of that file (not on FD-GAN's hot path), the two U-Nets
+`G` (:205-362) and `G2` (:364-488) -- forward only, on the same primitives: 4x4 stride-2 convolutions,
+ConvTranspose2d(4, 2, 1) as four stride-1 3x3 convolutions (one per output parity, strided output
+views), train- or eval-mode BatchNorm folded into the consumers' prologues, train-mode Dropout2d,
+the multi-scale pooling head as one kernel.  `Dense` (:531) and `dehaze` (:662) are not provided.
 
 Dataflow (one recorded plan, NHWC bf16, BatchNorm folded into the consumer's prologue):
     x -> 4x4 s2 -> [LReLU | 4x4 s2 | BN] x2 -> LReLU, 4x4 s1, BN -> LReLU, 4x4 s1 (->1), sigmoid
@@ -16,13 +19,17 @@ from models.dehaze1113 import _Named, _PlannedModule, _apply_plan_function, _pla
 
 
 def blockUNet(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
-    """dehaze22.py:51-65 (4x4 stride-2 block); only the forward-conv form `D` uses runs on the HIP path."""
-    if transposed or dropout:
-        raise NotImplementedError("blockUNet(transposed/dropout) belongs to the legacy DCPDN nets, not to FD-GAN")
-    kids = {"relu" if relu else "leakyrelu": nn.ReLU(inplace=True) if relu else nn.LeakyReLU(0.2, inplace=True),
-            "conv": nn.Conv2d(in_c, out_c, 4, 2, 1, bias=False)}
+    """dehaze22.py:51-65: [ReLU | LeakyReLU(0.2)] -> Conv2d(4, 2, 1) | ConvTranspose2d(4, 2, 1) -> [BatchNorm2d] -> [Dropout2d(0.5)],
+    as a parameter container with the reference's key names (`layer2.layer2.conv.weight`, `dlayer7.dlayer7.tconv.weight`)."""
+    kids = {"relu" if relu else "leakyrelu": nn.ReLU(inplace=True) if relu else nn.LeakyReLU(0.2, inplace=True)}
+    if not transposed:
+        kids["conv"] = nn.Conv2d(in_c, out_c, 4, 2, 1, bias=False)
+    else:
+        kids["tconv"] = nn.ConvTranspose2d(in_c, out_c, 4, 2, 1, bias=False)
     if bn:
         kids["bn"] = nn.BatchNorm2d(out_c)
+    if dropout:
+        kids["dropout"] = nn.Dropout2d(0.5, inplace=True)
     return _Named(**{name: _Named(**kids)})
 
 
@@ -122,12 +129,297 @@ class D(_PlannedModule):
         return dx, grads
 
 
+class D_tran(D):
+    """dehaze22.py:159-201: layer for layer the network of `D` (same children, same key names)."""
+
+
+# ConvTranspose2d(4, 2, 1): out[2 m + a] = sum_i x[i] w[2 (m - i) + a + 1].  Per output parity a that is a 3-tap correlation
+# over x[m - 1 .. m + 1] with taps (w[3], w[1], 0) for a = 0 and (0, w[2], w[0]) for a = 1 -- in 2-D four 3x3 stride-1 pad-1
+# convolutions whose results interleave.  (5 of the 9 taps are zero: the legacy nets pay 2.25x the MFMA work of a dedicated
+# 2x2 kernel and get every forward kernel of the hot path in exchange.)
+_TAP = {0: (3, 1, None), 1: (None, 2, 0)}
+
+
+def _phase_filters(w_t, out):
+    """w_t: ConvTranspose2d weight (cin, cout, 4, 4) -> out (4, cout, cin, 3, 3): the conv filters of parities (a, b)."""
+    wt = w_t.detach().permute(1, 0, 2, 3)
+    out.zero_()
+    for a in range(2):
+        for b in range(2):
+            for ty, ky in enumerate(_TAP[a]):
+                for tx, kx in enumerate(_TAP[b]):
+                    if ky is not None and kx is not None:
+                        out[a * 2 + b, :, :, ty, tx] = wt[:, :, ky, kx]
+    return out
+
+
+class _Stats:
+    """(mean, var) tensor pair: what NetPlan.bn_prologue / NetPlan.conv(stats=...) take; here slices of a concat buffer's."""
+
+    def __init__(self, mean, var):
+        self.mean, self.var = mean, var
+
+
+class _UNet(_PlannedModule):
+    """The 8-level pix2pix U-Net shared by `G` and `G2` (dehaze22.py:205-362, :364-488), forward only.
+
+    Buffers (NHWC bf16): level k = 1..7 owns ONE concat buffer cat_k = [dout_{k+1} | out_k] at H / 2^k -- the encoder conv of
+    level k stores out_k into its right half, the decoder's transposed conv of level k+1 stores dout_{k+1} into the left
+    half, so `torch.cat` (dehaze22.py:320-333) never runs.  Buffers hold RAW conv outputs; BatchNorm and the in-place
+    (Leaky)ReLU of the consumer are its prologue.  The reference's in-place activations (dehaze22.py:54-56) make the skip
+    tensors leaky_relu(out_k); the decoder then applies ReLU to the concatenation, and relu(leaky_relu(v)) = relu(v): one
+    per-channel prologue (batch or running statistics of two different norms side by side, then ReLU) covers both halves.
+    Train-mode Dropout2d (dlayers 8, 7, 6: at most 8 x 8 pixels) is applied together with that layer's BatchNorm by one small
+    pass over the stored tensor, with an (N, C) mask drawn by torch's generator exactly as F.dropout2d draws it."""
+
+    def __init__(self, input_nc, output_nc, nf):
+        super().__init__()
+        self.input_nc, self.output_nc, self.nf = input_nc, output_nc, nf
+        self.ce = [nf, nf * 2, nf * 4, nf * 8, nf * 8, nf * 8, nf * 8, nf * 8]          # out_1 .. out_8
+        self.cd = {8: nf * 8, 7: nf * 8, 6: nf * 8, 5: nf * 8, 4: nf * 4, 3: nf * 2, 2: nf}   # dout_8 .. dout_2
+        if nf % 8:
+            raise ValueError("the HIP path needs nf to be a multiple of 8, got %d" % nf)
+
+    def _make_layers(self, last_cout):
+        nf, ce = self.nf, self.ce
+        self.layer1 = _Named(layer1=nn.Conv2d(self.input_nc, nf, 4, 2, 1, bias=False))
+        for k in range(2, 9):
+            setattr(self, "layer%d" % k, blockUNet(ce[k - 2], ce[k - 1], "layer%d" % k, transposed=False, bn=True, relu=False))
+        self.dlayer8 = blockUNet(nf * 8, nf * 8, "dlayer8", transposed=True, bn=False, relu=True, dropout=True)
+        for k in range(7, 1, -1):
+            setattr(self, "dlayer%d" % k, blockUNet(self.cd[k + 1] + ce[k - 1], self.cd[k], "dlayer%d" % k, transposed=True, bn=True,
+                                                     relu=True, dropout=k >= 6))
+        self.dlayer1 = _Named(dlayer1=_Named(relu=nn.ReLU(inplace=True), tconv=nn.ConvTranspose2d(nf * 2, last_cout, 4, 2, 1, bias=False)))
+
+    # ---- plan ---------------------------------------------------------------------------------------------
+    def _tconv(self, P, src, pro, w_param, cout, cin, dst_buf, c0, hin, win, e_act, stats, count, label):
+        """ConvTranspose2d(4, 2, 1) of `src` (View, hin x win) into channels [c0, c0 + cout) of dst_buf (2 hin x 2 win)."""
+        dev = dst_buf.device
+        filt = torch.zeros((4, cout, cin, 3, 3), dtype=torch.float32, device=dev)
+        P.derived.append((w_param, filt))
+        ws4 = [P.weight(filt[i], cout, cin, 3) for i in range(4)]
+        ys = [E.StridedView(dst_buf, c0, cout, a, b, 2, 2, hin, win) for a in range(2) for b in range(2)]
+        desc = E.conv_desc(3, 1, 1, e_act, False, cout=cout, w_layout=ws4[0].layout)
+        need, info = 0, None
+        if stats is not None:
+            info = E.conv_info(src.fd, ys[0].fd, cout, desc, pro)
+            need = 4 * info.stats_rows * info.stats_cpad * 2
+        rows = info.stats_rows if info is not None else 0
+        per = rows * (info.stats_cpad if info is not None else 0) * 2
+
+        pro_rest = E.prologue_without_side_effects(pro)     # a norm's running statistics move once, not once per parity
+
+        def run():
+            for i in range(4):
+                E.conv2d(src.fd, ws4[i], None, pro if i == 0 else pro_rest, ys[i].fd, desc, P.ws[i * per:] if stats is not None else None)
+            if stats is not None:
+                info4 = L.FdConvInfo()
+                info4.stats_rows, info4.stats_cpad = 4 * rows, info.stats_cpad
+                E.bn_finalize(P.ws, info4, cout, count, stats.mean, stats.var, 0)
+        n = dst_buf.shape[0]
+        P._ops.append((run, need, dict(label=label, k=4, cin=cin, cout=cout, n=n, h_out=2 * hin, w_out=2 * win,
+                                       flops=2.0 * n * (2 * hin) * (2 * win) * cout * cin * 4, flops_done=2.0 * n * hin * win * 4 * cout * cin * 9,
+                                       bytes=n * hin * win * cin * 2 + n * 4 * hin * win * cout * 2)))
+        P.keep += [src, pro, pro_rest, ws4, ys, desc, filt]
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != self.input_nc:
+            raise ValueError("%s expects %d input channels, got %d" % (type(self).__name__, self.input_nc, c))
+        if h % 256 or w % 256:
+            raise ValueError("%s: the 8-level U-Net halves the image eight times; H and W must be multiples of 256, got %dx%d"
+                             % (type(self).__name__, h, w))
+        nf, ce, cd = self.nf, self.ce, self.cd
+        train = self.training
+        if train and n * (h // 256) * (w // 256) < 2:
+            raise ValueError("train-mode BatchNorm at the 1x1 bottleneck needs more than one value per channel (batch >= 2 at 256x256)")
+        r8 = lambda v: (v + 7) // 8 * 8
+        P = NetPlan(dev)
+        P.derived = []
+        P.xin = E.new_act(n, h, w, r8(c), dev, zero=True)
+        hs = [h >> k for k in range(9)]
+        ws_ = [w >> k for k in range(9)]
+        # concat buffers of levels 1..7, the bottleneck, per-channel tables of the decoder prologues
+        cat = {k: E.new_act(n, hs[k], ws_[k], cd[k + 1] + ce[k - 1], dev) for k in range(1, 8)}
+        out8 = E.new_act(n, hs[8], ws_[8], ce[7], dev)
+        f32 = lambda cnt, v: torch.full((cnt,), v, dtype=torch.float32, device=dev)
+        tab = {k: dict(mean=f32(cd[k + 1] + ce[k - 1], 0.0), var=f32(cd[k + 1] + ce[k - 1], 1.0 - 1e-5),
+                       gamma=f32(cd[k + 1] + ce[k - 1], 1.0), beta=f32(cd[k + 1] + ce[k - 1], 0.0)) for k in range(1, 8)}
+        P.tab, P.cat, P.out8 = tab, cat, out8
+        enc_bn = {k: getattr(self, "layer%d" % k)[0].bn for k in range(2, 9)}
+        dec_bn = {k: getattr(self, "dlayer%d" % k)[0].bn for k in range(2, 8)}
+        P.copies = []      # (dst table slice, source tensor): refreshed before every launch (parameters / running statistics)
+        P.running = []     # (bn, mean slice, var slice, count): train-mode running-statistics updates done after the launch
+        P.masks = []       # (mask tensor (N, C)): train-mode Dropout2d
+        lrelu = E.make_prologue(act=L.ACT_LEAKY02)
+        # ---- encoder
+        enc_w = lambda k: (self.layer1.layer1 if k == 1 else getattr(self, "layer%d" % k)[0].conv).weight
+        out_view = lambda k: E.View(cat[k], cd[k + 1], ce[k - 1]) if k <= 7 else E.View(out8)
+        enc_stats = {}
+        for k in range(1, 9):
+            src = E.View(P.xin, 0, c) if k == 1 else out_view(k - 1)
+            cin = c if k == 1 else ce[k - 2]
+            if k == 1:
+                pro = None
+            elif k == 2:
+                pro = lrelu
+            else:
+                pro = P.bn_prologue(enc_bn[k - 1], enc_stats[k - 1], n * hs[k - 1] * ws_[k - 1], act=L.ACT_LEAKY02)
+            st = None
+            if k >= 2:
+                if k <= 7:      # statistics land in the concat buffer's table, where the decoder reads them too
+                    st = _Stats(tab[k]["mean"][cd[k + 1]:], tab[k]["var"][cd[k + 1]:])
+                else:
+                    st = ChanStats(ce[7], dev)
+                enc_stats[k] = st
+                if k <= 7:
+                    P.copies += [(tab[k]["gamma"][cd[k + 1]:], enc_bn[k].weight), (tab[k]["beta"][cd[k + 1]:], enc_bn[k].bias)]
+                    if not train:
+                        P.copies += [(tab[k]["mean"][cd[k + 1]:], enc_bn[k].running_mean), (tab[k]["var"][cd[k + 1]:], enc_bn[k].running_var)]
+            P.conv(src, P.weight(enc_w(k), ce[k - 1], cin, 4, stride=2), out_view(k), 4, pad=1, stride=2, pro=pro,
+                   stats=st if (k >= 2 and train) else None, label="layer%d" % k)
+        # ---- decoder: dlayer k reads cat_k (k <= 7) / out8 (k = 8) and writes dout_k into the left half of cat_{k-1}
+        for k in range(8, 1, -1):
+            blk = getattr(self, "dlayer%d" % k)[0]
+            if k == 8:
+                src, cin = E.View(out8), ce[7]
+                pro = P.bn_prologue(enc_bn[8], enc_stats[8], n * hs[8] * ws_[8], act=L.ACT_RELU)
+            else:
+                src, cin = E.View(cat[k]), cd[k + 1] + ce[k - 1]
+                t = tab[k]
+                pro = E.make_prologue(act=L.ACT_RELU, mean=t["mean"], var=t["var"], gamma=t["gamma"], beta=t["beta"], eps=1e-5)
+            dst, cout = cat[k - 1], cd[k]
+            bn = dec_bn.get(k)
+            drop = train and k >= 6
+            left = _Stats(tab[k - 1]["mean"][:cout], tab[k - 1]["var"][:cout])
+            st = left if (bn is not None and train and not drop) else (ChanStats(cout, dev) if (bn is not None and train) else None)
+            self._tconv(P, src, pro, blk.tconv.weight, cout, cin, dst, 0, hs[k], ws_[k], L.ACT_NONE, st, n * hs[k - 1] * ws_[k - 1], "dlayer%d" % k)
+            if bn is not None and train:
+                P.running.append((bn, st.mean, st.var, n * hs[k - 1] * ws_[k - 1]))
+            if drop:        # BatchNorm + Dropout2d applied in place: the consumer sees finished values (identity entries in its table)
+                mask = torch.ones((n, cout), dtype=torch.float32, device=dev)
+                P.masks.append(mask)
+                v = E.View(dst, 0, cout)
+                if bn is not None:
+                    P.op(lambda v=v, st=st, bn=bn, mask=mask: E.bn_dropout(v, st.mean, st.var, bn.weight, bn.bias, bn.eps, mask, v))
+                else:
+                    P.op(lambda v=v, mask=mask: E.bn_dropout(v, None, None, None, None, 0.0, mask, v))
+                P.keep += [v, mask, st]
+            elif bn is not None:
+                P.copies += [(tab[k - 1]["gamma"][:cout], bn.weight), (tab[k - 1]["beta"][:cout], bn.bias)]
+                if not train:
+                    P.copies += [(tab[k - 1]["mean"][:cout], bn.running_mean), (tab[k - 1]["var"][:cout], bn.running_var)]
+        t = tab[1]
+        P.last_pro = E.make_prologue(act=L.ACT_RELU, mean=t["mean"], var=t["var"], gamma=t["gamma"], beta=t["beta"], eps=1e-5)
+        self._build_head(P, n, h, w, dev)
+        P.keep += [cat, out8, tab, enc_stats]
+        return P.finish()
+
+    def _run(self, x):
+        P = self._plan_for(x)
+        with torch.no_grad():
+            for w_t, filt in P.derived:
+                ver = w_t._version
+                if getattr(filt, "_src_version", None) != (ver, w_t.data_ptr()):
+                    _phase_filters(w_t, filt)
+                    filt._src_version = (ver, w_t.data_ptr())
+            for dst, src_t in P.copies:
+                dst.copy_(src_t.detach())
+            forced = self.__dict__.get("_forced_dropout_masks")     # tests: the masks the oracle used, order dlayer8, 7, 6
+            for i, mask in enumerate(P.masks):     # F.dropout2d draws a (N, C, 1, 1) Bernoulli(0.5) / 0.5 field (dehaze22.py:62-63)
+                if forced is not None:
+                    mask.copy_(forced[i])
+                else:
+                    mask.copy_(torch.nn.functional.dropout2d(torch.ones_like(mask)[:, :, None, None], 0.5, True)[:, :, 0, 0])
+            E.to_nhwc(x.detach().float().contiguous(), E.View(P.xin))
+            P.launch()
+            for bn, mean, var, count in P.running:     # decoder norms: their consumers' prologues carry two norms at once
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var, alpha=m * count / max(count - 1, 1))
+                bn.num_batches_tracked.add_(1)
+            return self._finish(P, x)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("models.dehaze22.%s runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): "
+                                      "call it under torch.no_grad()" % type(self).__name__)
+        return self._run(x)
+
+
+class G(_UNet):
+    """dehaze22.py:205-362: U-Net -> 20 channels -> four-scale pooling head (avg_pool 16 / 8 / 4 / 2, Conv2d(20, 1, 1),
+    LeakyReLU, nearest upsampling, :343-354) -> Conv2d(24, output_nc, 3, 1, 1) -> tanh.  (B,3,H,W) -> (B,output_nc,H,W)."""
+
+    def __init__(self, input_nc, output_nc, nf):
+        super().__init__(input_nc, output_nc, nf)
+        for nm in ("conv1010", "conv1020", "conv1030", "conv1040"):
+            setattr(self, nm, nn.Conv2d(20, 1, kernel_size=1, stride=1, padding=0))
+        self.refine3 = nn.Conv2d(20 + 4, 3, kernel_size=3, stride=1, padding=1)     # registered, never called (:316)
+        self._make_layers(20)
+        self.dlayerfinal = _Named(dlayer1=_Named(conv=nn.Conv2d(24, output_nc, 3, 1, 1, bias=False), tanh=nn.Tanh()))
+        self.relu = nn.LeakyReLU(0.2, inplace=True)
+
+    def _build_head(self, P, n, h, w, dev):
+        nf = self.nf
+        head = E.new_act(n, h, w, 24, dev)          # [dout1 (20) | x1010 x1020 x1030 x1040]: the reference's order is pyramid first,
+        P.head = head                                # the final filter's input channels are permuted instead (16-byte alignment)
+        self._tconv(P, E.View(P.cat[1]), P.last_pro, self.dlayer1.dlayer1.tconv.weight, 20, 2 * nf, head, 0, h // 2, w // 2,
+                    L.ACT_NONE, None, 0, "dlayer1")
+        P.pw = torch.zeros((4, 20), dtype=torch.float32, device=dev)
+        P.pb = torch.zeros((4,), dtype=torch.float32, device=dev)
+        for i, nm in enumerate(("conv1010", "conv1020", "conv1030", "conv1040")):
+            conv = getattr(self, nm)
+            P.copies += [(P.pw[i], conv.weight.view(20)), (P.pb[i:i + 1], conv.bias)]
+        x20, y4 = E.View(head, 0, 20), E.View(head, 20, 4)
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 16, 0.2, y4))
+        P.wfinal = torch.zeros((self.output_nc, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.out = torch.empty((n, self.output_nc, h, w), dtype=torch.float32, device=dev)
+        P.conv(E.View(head), P.weight(P.wfinal, self.output_nc, 24, 3), None, 3, pad=1, e_act=L.ACT_TANH, y_fd=E.nchw_f32_view(P.out),
+               label="dlayerfinal")
+        P.keep += [x20, y4]
+
+    def _run(self, x):
+        P = self._plan_for(x)
+        wf = self.dlayerfinal.dlayer1.conv.weight
+        with torch.no_grad():                        # reference channel order [pyramid 0-3 | dout1 4-23] -> buffer order
+            if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
+                P.wfinal[:, :20].copy_(wf.detach()[:, 4:])
+                P.wfinal[:, 20:].copy_(wf.detach()[:, :4])
+                P.wfinal._src_version = (wf._version, wf.data_ptr())
+        return super()._run(x)
+
+    def _finish(self, P, x):
+        return P.out.clone()
+
+
+class G2(_UNet):
+    """dehaze22.py:364-488: the same U-Net ending in ConvTranspose2d(2 nf, output_nc) + LeakyReLU(0.2) (:384-386)."""
+
+    def __init__(self, input_nc, output_nc, nf):
+        super().__init__(input_nc, output_nc, nf)
+        self._make_layers(output_nc)
+        self.dlayer1.dlayer1.add_module("tanh", nn.LeakyReLU(0.2, inplace=True))     # named `tanh` in the reference too
+
+    def _build_head(self, P, n, h, w, dev):
+        r8 = (self.output_nc + 7) // 8 * 8
+        P.head = E.new_act(n, h, w, r8, dev, zero=True)
+        self._tconv(P, E.View(P.cat[1]), P.last_pro, self.dlayer1.dlayer1.tconv.weight, self.output_nc, 2 * self.nf, P.head, 0, h // 2, w // 2,
+                    L.ACT_LEAKY02, None, 0, "dlayer1")
+
+    def _finish(self, P, x):
+        out = torch.empty((x.shape[0], self.output_nc, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        E.to_nchw(E.View(P.head, 0, self.output_nc), out)
+        return out
+
+
 def _legacy(name):
     def ctor(*a, **k):
         raise NotImplementedError("models.dehaze22.%s is a legacy DCPDN network outside FD-GAN's hot path "
-                                  "(reference demo.py uses models.dehaze1113.FDGAN)" % name)
+                                  "(reference demo.py uses models.dehaze1113.FDGAN); of that family only the U-Nets G and G2 "
+                                  "are provided" % name)
     ctor.__name__ = name
     return ctor
 
 
-G, G2, dehaze, D_tran = _legacy("G"), _legacy("G2"), _legacy("dehaze"), _legacy("D_tran")
+Dense, dehaze = _legacy("Dense"), _legacy("dehaze")

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 3
+#define FDGAN_ABI_VERSION 4
 
 enum FdStatus {
   FD_OK = 0,
@@ -208,6 +208,25 @@ int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c, int64_t h,
 int fdgan_nhwc_bf16_to_nchw_f32(const FdTensor* x, float* y, FdStream stream);
 /* Channel-slice copy between NHWC bf16 views of equal n,h,w,c (c multiple of 8). */
 int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
+
+/* ---- legacy DCPDN-era networks (/root/reference/models/dehaze22.py G :205-362, G2 :364-488,
+ * Dense :531-660; models/dehaze1113.py Dense :431-570).  Everything else those networks need is fdgan_conv2d_fwd: the
+ * ConvTranspose2d(4, 2, 1) of blockUNet (dehaze22.py:60) is four stride-1 3x3 convolutions, one per output parity,
+ * writing through strided views.
+ *
+ * fdgan_pyramid_pool4: the multi-scale head, dehaze22.py:343-356 / :634-651.  For the four windows k0, k0/2, k0/4, k0/8
+ * (k0 = 16 or 32): avg_pool2d(x, k) -> Conv2d(C, 1, 1)(weight[j], bias[j]) -> LeakyReLU(slope) -> upsample_nearest to
+ * x's size; the four maps land in the 4-channel view y (typically a slice of the buffer the next conv reads).  H and W
+ * must be multiples of k0.  weight: [4][C] fp32, bias: [4] fp32.
+ *
+ * fdgan_bn_dropout_nhwc: y = mask[n][c] * ((x - mean[c]) / sqrt(var[c] + eps) * gamma[c] + beta[c]) on NHWC bf16 views:
+ * train-mode nn.BatchNorm2d followed by train-mode nn.Dropout2d (dehaze22.py:60-63; the caller draws the (N, C) mask of
+ * 0 / 1/(1-p) values).  mean == NULL: no normalisation; gamma / beta == NULL: 1 / 0; mask == NULL: no dropout.  Padding
+ * channels of the 8-channel groups are written as zero. */
+int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* y,
+                        FdStream stream);
+int fdgan_bn_dropout_nhwc(const FdTensor* x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                          const float* mask, const FdTensor* y, FdStream stream);
 
 /* ---- plan: record once, replay many ----------------------------------------- */
 /* Between fdgan_plan_begin and fdgan_plan_end every launching entry point above,

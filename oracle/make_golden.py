@@ -180,6 +180,38 @@ def main():
     np.savez_compressed(os.path.join(OUT, "d22_2x64.npz"), y=y22.numpy())
     man["d22_keys"] = list(sd22.keys())
 
+    # ---------------- legacy U-Nets dehaze22.G / G2, 2x3x256x256, nf = 8 ----------------
+    from . import legacy_ref
+    xl = det_input((2, 3, 256, 256), seed=21)
+    for kind, cls in (("G", r22.G), ("G2", r22.G2)):
+        net = cls(3, 3, 8)
+        fill_state_dict(net, seed=5)
+        for kk, vv in net.state_dict().items():         # the generic fill saturates G's tanh: keep the last filter small
+            if kk == "dlayerfinal.dlayer1.conv.weight":
+                vv.mul_(0.3)
+        sd0 = {kk: vv.clone() for kk, vv in net.state_dict().items()}
+        net.eval()
+        with torch.no_grad():
+            ye = net(xl.clone())
+            yo, _ = legacy_ref.unet_forward({kk: vv.clone() for kk, vv in sd0.items()}, xl.clone(), False, kind)
+        man["ref_vs_oracle_maxabs"]["legacy_%s_eval" % kind] = float((ye - yo).abs().max())
+        net.train()
+        sdt = {kk: vv.clone() for kk, vv in sd0.items()}
+        with torch.no_grad():
+            torch.manual_seed(77)
+            yt = net(xl.clone())
+            torch.manual_seed(77)
+            yot, masks = legacy_ref.unet_forward(sdt, xl.clone(), True, kind)
+        man["ref_vs_oracle_maxabs"]["legacy_%s_train" % kind] = float((yt - yot).abs().max())
+        after = net.state_dict()
+        np.savez_compressed(os.path.join(OUT, "legacy_%s_2x256.npz" % kind.lower()), y_eval=ye.numpy()[:, :, ::4, ::4],
+                            y_train=yt.numpy()[:, :, ::4, ::4], masks=torch.stack(masks).numpy(),
+                            rm_dlayer5=after["dlayer5.dlayer5.bn.running_mean"].numpy(),
+                            rv_dlayer5=after["dlayer5.dlayer5.bn.running_var"].numpy(),
+                            rm_layer8=after["layer8.layer8.bn.running_mean"].numpy(),
+                            rv_layer8=after["layer8.layer8.bn.running_var"].numpy())
+        man["legacy_%s_keys" % kind] = list(sd0.keys())
+
     # ---------------- VGG16 features, 1x3x32x32 ----------------
     ov, rv = OVgg(), RVgg()
     fill_state_dict(ov, seed=0)

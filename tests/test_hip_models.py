@@ -1021,3 +1021,88 @@ def test_dehaze22_d_backward():
     rep["dx"] = rel_rms(xg.grad.cpu(), xo.grad)
     _report("dehaze22_d_backward", rep)
     assert max(rep.values()) < 0.12, rep
+
+
+def test_pyramid_pool4_and_bn_dropout_kernels():
+    """The two element-wise kernels of the legacy networks (csrc/legacy.hip) against plain torch on the same bf16 values."""
+    import torch.nn.functional as F
+    from fdgan_hip import engine as E
+    torch.manual_seed(5)
+    for k0, (h, w) in ((16, (64, 96)), (32, (64, 64))):
+        buf = torch.zeros(2, h, w, 24, dtype=torch.bfloat16, device=DEV)
+        xs = torch.randn(2, h, w, 20, device=DEV)
+        buf[..., :20] = xs.bfloat16()
+        wt = torch.randn(4, 20, device=DEV) * 0.3
+        bs = torch.randn(4, device=DEV) * 0.1
+        E.pyramid_pool4(E.View(buf, 0, 20), wt, bs, k0, 0.2, E.View(buf, 20, 4))
+        torch.cuda.synchronize()
+        x = buf[..., :20].float().permute(0, 3, 1, 2)
+        want = []
+        for j, k in enumerate((k0, k0 // 2, k0 // 4, k0 // 8)):
+            p = F.conv2d(F.avg_pool2d(x, k), wt[j].view(1, 20, 1, 1), bs[j:j + 1])
+            want.append(F.interpolate(F.leaky_relu(p, 0.2), size=(h, w), mode="nearest"))
+        want = torch.cat(want, 1)
+        got = buf[..., 20:].float().permute(0, 3, 1, 2)
+        assert float((got - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max())), (k0, float((got - want).abs().max()))
+    x = torch.randn(3, 4, 4, 16, device=DEV).bfloat16()
+    mean, var = torch.randn(12, device=DEV) * 0.2, torch.rand(12, device=DEV) + 0.5
+    gamma, beta = torch.rand(12, device=DEV) + 0.5, torch.randn(12, device=DEV) * 0.1
+    mask = (torch.rand(3, 12, device=DEV) > 0.5).float() * 2.0
+    y = torch.full_like(x, 7.0)
+    E.bn_dropout(E.View(x, 0, 12), mean, var, gamma, beta, 1e-5, mask, E.View(y, 0, 12))
+    torch.cuda.synchronize()
+    want = ((x[..., :12].float() - mean) / torch.sqrt(var + 1e-5) * gamma + beta) * mask[:, None, None, :]
+    assert float((y[..., :12].float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+    assert float(y[..., 12:].abs().max()) == 0.0          # the padding channels of the last 8-channel group
+
+
+@pytest.mark.parametrize("kind", ["G", "G2"])
+def test_legacy_unets_match_oracle_and_golden(golden_dir, kind):
+    """models.dehaze22.G / G2 (dehaze22.py:205-362, :364-488) on the HIP path -- 4x4 stride-2 convs,
+    ConvTranspose2d as four parity convolutions, BatchNorm of two norms side by side in one prologue, Dropout2d, the pooling
+    head -- against the fp32 oracle (itself 0.0 from the real reference) and the reference's own outputs, eval and train mode
+    (train: with the dropout masks the reference drew; running statistics compared too)."""
+    import models.dehaze22 as net22
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = getattr(net22, kind)(3, 3, 8)
+    fill_state_dict(net, seed=5)
+    if kind == "G":
+        with torch.no_grad():
+            net.dlayerfinal.dlayer1.conv.weight.mul_(0.3)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = det_input((2, 3, 256, 256), seed=21)
+    g = np.load(os.path.join(golden_dir, "legacy_%s_2x256.npz" % kind.lower()))
+    rep = {}
+    net.eval()
+    with torch.no_grad():
+        y = net(x.to(DEV)).cpu()
+        yo, _ = legacy_ref.unet_forward({k: v.clone() for k, v in sd.items()}, x.clone(), False, kind)
+    assert y.shape == (2, 3, 256, 256)
+    rep["eval_rel_rms_vs_oracle"] = rel_rms(y, yo)
+    rep["eval_max_abs_vs_reference"] = float((y[:, :, ::4, ::4] - torch.from_numpy(g["y_eval"])).abs().max())
+    net.train()
+    masks = torch.from_numpy(g["masks"])
+    net.__dict__["_forced_dropout_masks"] = [m.to(DEV) for m in masks]
+    with torch.no_grad():
+        yt = net(x.to(DEV)).cpu()
+        sdt = {k: v.clone() for k, v in sd.items()}
+        yot, _ = legacy_ref.unet_forward(sdt, x.clone(), True, kind, masks=list(masks))
+    rep["train_rel_rms_vs_oracle"] = rel_rms(yt, yot)
+    rep["train_max_abs_vs_reference"] = float((yt[:, :, ::4, ::4] - torch.from_numpy(g["y_train"])).abs().max())
+    after = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for nm in ("dlayer5.dlayer5.bn", "layer8.layer8.bn", "layer3.layer3.bn", "dlayer7.dlayer7.bn"):
+        rep["running_mean_" + nm] = float((after[nm + ".running_mean"] - sdt[nm + ".running_mean"]).abs().max())
+        rep["running_var_" + nm] = rel_rms(after[nm + ".running_var"], sdt[nm + ".running_var"])
+        assert int(after[nm + ".num_batches_tracked"]) == 1, nm
+    del net.__dict__["_forced_dropout_masks"]
+    with torch.no_grad():                       # without forced masks the draw is torch's: different masks, still finite and changing
+        y2, y3 = net(x.to(DEV)), net(x.to(DEV))
+    assert bool(torch.isfinite(y2).all()) and float((y2 - y3).abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV).requires_grad_(True))
+    _report("legacy_" + kind, rep)
+    assert rep["eval_rel_rms_vs_oracle"] < 2e-2 and rep["train_rel_rms_vs_oracle"] < 3e-2, rep
+    assert rep["eval_max_abs_vs_reference"] < 3e-2 and rep["train_max_abs_vs_reference"] < 6e-2, rep
+    assert max(v for k, v in rep.items() if k.startswith("running_")) < 2e-2, rep

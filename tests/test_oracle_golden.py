@@ -233,3 +233,47 @@ def test_loss_module_restatements_are_pinned_to_the_reference_bytecode(golden_di
     f = torch.rand(2, 8, 5, 5)
     same, other = contextual_ref.ContextualLoss()(f, f.clone()), contextual_ref.ContextualLoss()(f, torch.rand(2, 8, 5, 5))
     assert float(same) < 1e-3 and float(other) > float(same) + 0.1
+
+
+@pytest.mark.parametrize("kind", ["G", "G2"])
+def test_legacy_unets_match_golden(golden_dir, manifest, kind):
+    """oracle/legacy_ref.py (dehaze22.G :205-362, G2 :364-488) against outputs of the REAL reference --
+    eval mode, and train mode with the Dropout2d masks the reference drew (stored with the fixture)."""
+    from oracle import legacy_ref
+    import models.dehaze22 as net22
+    assert manifest["ref_vs_oracle_maxabs"]["legacy_%s_eval" % kind] == 0.0
+    assert manifest["ref_vs_oracle_maxabs"]["legacy_%s_train" % kind] == 0.0
+    net = getattr(net22, kind)(3, 3, 8)                     # the product's parameter container: same keys, same shapes
+    assert list(net.state_dict().keys()) == manifest["legacy_%s_keys" % kind]
+    fill_state_dict(net, seed=5)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    if kind == "G":
+        sd["dlayerfinal.dlayer1.conv.weight"] *= 0.3
+    x = det_input((2, 3, 256, 256), seed=21)
+    g = _load(golden_dir, "legacy_%s_2x256.npz" % kind.lower())
+    with torch.no_grad():
+        ye, _ = legacy_ref.unet_forward({k: v.clone() for k, v in sd.items()}, x.clone(), False, kind)
+        sdt = {k: v.clone() for k, v in sd.items()}
+        yt, used = legacy_ref.unet_forward(sdt, x.clone(), True, kind, masks=list(torch.from_numpy(g["masks"])))
+    assert float((ye[:, :, ::4, ::4] - torch.from_numpy(g["y_eval"])).abs().max()) < 1e-6
+    assert float((yt[:, :, ::4, ::4] - torch.from_numpy(g["y_train"])).abs().max()) < 1e-5
+    assert float((sdt["dlayer5.dlayer5.bn.running_mean"] - torch.from_numpy(g["rm_dlayer5"])).abs().max()) < 1e-6
+    assert float((sdt["layer8.layer8.bn.running_var"] - torch.from_numpy(g["rv_layer8"])).abs().max()) < 1e-6
+    assert int(sdt["layer8.layer8.bn.num_batches_tracked"]) == 1
+
+
+def test_transposed_conv_as_four_parity_convolutions():
+    """models/dehaze22.py expresses ConvTranspose2d(4, 2, 1) as four stride-1 3x3 pad-1 convolutions, one per output parity:
+    the filter rearrangement against torch's own conv_transpose2d."""
+    import torch.nn.functional as F
+    import models.dehaze22 as net22
+    torch.manual_seed(3)
+    w = torch.randn(5, 7, 4, 4)
+    x = torch.randn(2, 5, 6, 9)
+    ref = F.conv_transpose2d(x, w, None, 2, 1)
+    filt = net22._phase_filters(w, torch.empty(4, 7, 5, 3, 3))
+    out = torch.zeros_like(ref)
+    for a in range(2):
+        for b in range(2):
+            out[:, :, a::2, b::2] = F.conv2d(x, filt[a * 2 + b], None, 1, 1)
+    assert float((out - ref).abs().max()) < 1e-5
