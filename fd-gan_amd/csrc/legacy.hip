@@ -5,6 +5,8 @@
 //                         k0/8:  avg_pool2d(x, k) -> Conv2d(C, 1, 1) -> LeakyReLU(0.2) -> upsample_nearest(size of x).
 //                         The 1x1 conv is linear, so it commutes with the average: per pixel four dot products, block means,
 //                         bias, activation, broadcast -- one pass over x, one 8-byte store per pixel, nothing intermediate.
+//   fdgan_maxpool3s2_nhwc MaxPool2d(3, 2, 1) of relu(bn(x)): the DenseNet stem's norm0 / relu0 / pool0, with the statistics of what it
+//                         stores for the first dense layer's norm1.
 //   fdgan_bn_dropout_nhwc y = mask[n][c] * bn(x): train-mode BatchNorm followed by train-mode Dropout2d (a per-(sample,
 //                         channel) mask, dehaze22.py:60-63) on the U-Net's three innermost decoder outputs (at most 8 x 8
 //                         pixels): the consumer then sees finished values.
@@ -117,7 +119,106 @@ __global__ void bn_dropout_kernel(BnDropArgs a) {
   *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
 }
 
+struct Mp3Args {
+  const unsigned short* x;
+  unsigned short* y;
+  long long x_sn, x_sh, x_sw, y_sn, y_sh, y_sw;
+  int H, W, Ho, Wo, C, groups;
+  const float *mean, *var, *gamma, *beta;   // mean NULL: no normalisation
+  float eps;
+  int relu;
+  float* partial;                           // [blocks][cpad][2] or NULL
+  int cpad;
+  long long npix;                           // N * Ho * Wo
+};
+
+// MaxPool2d(3, 2, 1) of relu(bn(x)) -- torchvision DenseNet's norm0 / relu0 / pool0 (dehaze22.py:540-543).  A thread owns
+// (output pixel, 8-channel group); a workgroup = 32 consecutive output pixels x up to 8 groups per pass, and emits one row of
+// (sum, sum of squares) of what it stored: the statistics the first dense layer's norm1 needs (fixed summation order).
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(Mp3Args a) {
+  __shared__ float red[2][32][8][8];
+  const int tid = threadIdx.x, pl = tid >> 3, gl = tid & 7;
+  const long long p = (long long)blockIdx.x * 32 + pl;
+  const bool live = p < a.npix;
+  const int wo = live ? (int)(p % a.Wo) : 0, ho = live ? (int)((p / a.Wo) % a.Ho) : 0;
+  const long long n = live ? p / ((long long)a.Wo * a.Ho) : 0;
+  for (int g0 = 0; g0 < a.groups; g0 += 8) {
+    const int g = g0 + gl;
+    f32x8 best, s1, s2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) best[e] = -3.0e38f, s1[e] = s2[e] = 0.f;
+    if (live && g < a.groups) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        sc[e] = 1.f, sh[e] = 0.f;
+        if (a.mean != nullptr && c < a.C) {
+          sc[e] = (a.gamma ? a.gamma[c] : 1.f) / sqrtf(a.var[c] + a.eps);
+          sh[e] = (a.beta ? a.beta[c] : 0.f) - a.mean[c] * sc[e];
+        }
+      }
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = 2 * ho - 1 + dy;
+        if (yy < 0 || yy >= a.H) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = 2 * wo - 1 + dx;
+          if (xx < 0 || xx >= a.W) continue;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)yy * a.x_sh + (long long)xx * a.x_sw + g * 8);
+          const f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = fmaf(f[e], sc[e], sh[e]);
+            if (a.relu) t = fmaxf(t, 0.f);
+            best[e] = fmaxf(best[e], t);
+          }
+        }
+      }
+      const bf16x8 ob = __builtin_convertvector(best, bf16x8);
+      *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)ho * a.y_sh + (long long)wo * a.y_sw + g * 8) = __builtin_bit_cast(u32x4, ob);
+      const f32x8 r = __builtin_convertvector(ob, f32x8);      // statistics of the STORED (bf16) values, as the conv kernels do
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = r[e], s2[e] = r[e] * r[e];
+    }
+    if (a.partial != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[0][pl][gl][e] = s1[e], red[1][pl][gl][e] = s2[e];
+      __syncthreads();
+      if (tid < 128) {     // (which, group, element): sum over the 32 pixels in order
+        const int which = tid >> 6, g2 = (tid >> 3) & 7, e = tid & 7;
+        float t = 0.f;
+        for (int q = 0; q < 32; ++q) t += red[which][q][g2][e];
+        const int c = (g0 + g2) * 8 + e;
+        if (c < a.cpad) a.partial[((long long)blockIdx.x * a.cpad + c) * 2 + which] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int fdgan_maxpool3s2_nhwc(const FdTensor* x, const FdPrologue* pro, const FdTensor* y, float* partial, int64_t capacity_floats,
+                                     int64_t* rows_out, FdStream stream) {
+  FD_REQUIRE(x && y && x->ptr && y->ptr, "maxpool3s2_nhwc: NULL pointer");
+  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "maxpool3s2_nhwc: NHWC bf16 views required");
+  const int64_t ho = (x->h + 2 - 3) / 2 + 1, wo = (x->w + 2 - 3) / 2 + 1;
+  FD_REQUIRE(y->n == x->n && y->h == ho && y->w == wo && y->c == x->c && x->c % 8 == 0, "maxpool3s2_nhwc: y must be N x %lld x %lld x C (C %% 8 == 0)",
+             (long long)ho, (long long)wo);
+  FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0, "maxpool3s2_nhwc: 16-byte alignment");
+  for (int i = 0; i < 3; ++i) FD_REQUIRE(x->stride[i] % 8 == 0 && y->stride[i] % 8 == 0, "maxpool3s2_nhwc: strides must be multiples of 8");
+  FD_REQUIRE(!pro || !pro->pool2, "maxpool3s2_nhwc: the prologue's 2x2 average pool does not apply here");
+  FD_REQUIRE(!pro || pro->act == FD_ACT_NONE || pro->act == FD_ACT_RELU, "maxpool3s2_nhwc: prologue activation must be NONE or RELU");
+  const long long npix = x->n * ho * wo, blocks = (npix + 31) / 32;
+  const int cpad = (int)x->c;
+  if (rows_out) *rows_out = blocks;
+  if (partial) FD_REQUIRE(blocks * cpad * 2 <= capacity_floats, "maxpool3s2_nhwc: statistics workspace too small (%lld floats needed)", blocks * cpad * 2);
+  Mp3Args a{static_cast<const unsigned short*>(x->ptr), static_cast<unsigned short*>(y->ptr), x->stride[0], x->stride[1], x->stride[2],
+            y->stride[0], y->stride[1], y->stride[2], (int)x->h, (int)x->w, (int)ho, (int)wo, (int)x->c, (int)(x->c / 8),
+            pro ? pro->mean : nullptr, pro ? pro->var : nullptr, pro ? pro->gamma : nullptr, pro ? pro->beta : nullptr, pro ? pro->eps : 0.f,
+            pro && pro->act == FD_ACT_RELU ? 1 : 0, partial, cpad, npix};
+  return fd_launch(&maxpool3s2_kernel, "maxpool3s2_nhwc", dim3((unsigned)blocks), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* y,
                                    FdStream stream) {

@@ -238,6 +238,15 @@ def pyramid_pool4(x, weight, bias, k0, slope, y):
                                          stream_ptr()), "pyramid_pool4")
 
 
+def maxpool3s2(x, pro, y, stats_buf=None):
+    """y = MaxPool2d(3, 2, 1)(act(bn(x))); returns the number of statistics rows written to stats_buf (0 without one)."""
+    rows = C.c_int64(0)
+    L.check(L.load().fdgan_maxpool3s2_nhwc(C.byref(x.fd), C.byref(pro) if pro is not None else None, C.byref(y.fd),
+                                           stats_buf.data_ptr() if stats_buf is not None else None,
+                                           stats_buf.numel() if stats_buf is not None else 0, C.byref(rows), stream_ptr()), "maxpool3s2_nhwc")
+    return rows.value
+
+
 def bn_dropout(x, mean, var, gamma, beta, eps, mask, y):
     """y = mask[n][c] * bn(x) on NHWC bf16 views; any of (mean, var) / gamma / beta / mask may be None."""
     ptr = lambda t: t.data_ptr() if t is not None else None

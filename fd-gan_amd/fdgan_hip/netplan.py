@@ -70,9 +70,11 @@ class NetPlan:
         return p
 
     def conv(self, x, w, y, k, pad=0, stride=1, bias=None, pro=None, e_act=L.ACT_NONE, upsample=False,
-             stats=None, stats_c0=0, y_fd=None, label=None):
+             stats=None, stats_c0=0, y_fd=None, label=None, stats_also=()):
         """x, y: engine.View (y_fd overrides for NCHW fp32 output).  stats: ChanStats to
-        receive the batch statistics of the `w.cout` stored channels at [stats_c0, ...)."""
+        receive the batch statistics of the `w.cout` stored channels at [stats_c0, ...); stats_also: further
+        (ChanStats, c0) targets for the same statistics (a tensor that is concatenated into two buffers).
+        With upsample the kernel sums each value once, before the replication: the count follows."""
         yfd = y_fd if y_fd is not None else y.fd
         desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=w.cout, w_layout=w.layout)
         need = 0
@@ -81,7 +83,7 @@ class NetPlan:
             info = E.conv_info(x.fd, yfd, w.cout, desc, pro)
             need = info.stats_rows * info.stats_cpad * 2
             n, h, ww, _ = (yfd.n, yfd.h, yfd.w, yfd.c)
-            count = n * h * ww
+            count = n * h * ww // (4 if upsample else 1)
 
         fused = None
         if stats is not None and info.fused_finalize and self.fuse_finalize:
@@ -91,6 +93,8 @@ class NetPlan:
             E.conv2d(x.fd, w, bias, pro, yfd, desc, self.ws if stats is not None else None, fused)
             if stats is not None and fused is None:
                 E.bn_finalize(self.ws, info, w.cout, count, stats.mean, stats.var, stats_c0)
+                for st2, c2 in stats_also:
+                    E.bn_finalize(self.ws, info, w.cout, count, st2.mean, st2.var, c2)
 
         pro_nofx = E.prologue_without_side_effects(pro)
 
@@ -112,7 +116,7 @@ class NetPlan:
             n=yfd.n, h_out=yfd.h, w_out=yfd.w, flops=2.0 * yfd.n * macs_px * w.cout * w.cin * k * k,
             flops_done=2.0 * yfd.n * ho * wo * w.cout * w.cin * k * k,
             bytes=x.fd.n * x.fd.h * x.fd.w * w.cin * 2 + out_bytes)))
-        self.keep += [x, y, w, bias, pro, yfd, desc, stats]
+        self.keep += [x, y, w, bias, pro, yfd, desc, stats, stats_also]
 
     def copy(self, src, dst):
         self._ops.append((lambda: E.copy_nhwc(src, dst), 0, dict(label="copy", flops=0.0, flops_done=0.0,

@@ -440,6 +440,257 @@ class FDGAN(_PlannedModule):
 
 
 # ---------------------------------------------------------------------------------------
+# legacy DCPDN network `Dense`, forward only
+# ---------------------------------------------------------------------------------------
+class BottleneckBlock(nn.Module):
+    """dehaze1113.py:234-254 / dehaze22.py:491-510: BN-ReLU-1x1 (4 x out), BN-ReLU-3x3, concat.  Parameter container with
+    `emit`; used inside `Dense`'s plan."""
+
+    def __init__(self, in_planes, out_planes, dropRate=0.0):
+        super().__init__()
+        if dropRate > 0:
+            raise NotImplementedError("dropRate > 0 is never used by the reference's networks")
+        inter = out_planes * 4
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(in_planes, inter, 1, 1, 0, bias=False)
+        self.bn2 = nn.BatchNorm2d(inter)
+        self.conv2 = nn.Conv2d(inter, out_planes, 3, 1, 1, bias=False)
+        self.droprate = dropRate
+        self.in_planes, self.inter, self.out_planes = in_planes, inter, out_planes
+
+    def forward(self, x):
+        raise RuntimeError("container only; the math runs in the enclosing network's HIP plan")
+
+    def emit(self, P, buf, stats, tmp, count):
+        """buf: (in + out)-channel buffer whose first `in_planes` channels hold x (their statistics in stats[0:in])."""
+        cin, cout = self.in_planes, self.out_planes
+        tstats = ChanStats(self.inter, P.device)
+        P.keep.append(tstats)
+        P.conv(E.View(buf, 0, cin), P.weight(self.conv1.weight, self.inter, cin, 1), E.View(tmp), 1,
+               pro=P.bn_prologue(self.bn1, stats, count), stats=tstats if self.bn2.training else None)
+        P.conv(E.View(tmp), P.weight(self.conv2.weight, cout, self.inter, 3), E.View(buf, cin, cout), 3, pad=1,
+               pro=P.bn_prologue(self.bn2, tstats, count), stats=stats, stats_c0=cin)
+
+
+class TransitionBlock(nn.Module):
+    """dehaze1113.py:343-356 / dehaze22.py:512-529: BN-ReLU-ConvTranspose2d 1x1 (weight (Cin, Cout, 1, 1)), nearest x2."""
+
+    def __init__(self, in_planes, out_planes, dropRate=0.0):
+        super().__init__()
+        if dropRate > 0:
+            raise NotImplementedError("dropRate > 0 is never used by the reference's networks")
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv1 = nn.ConvTranspose2d(in_planes, out_planes, 1, 1, 0, bias=False)
+        self.droprate = dropRate
+        self.in_planes, self.out_planes = in_planes, out_planes
+
+    def forward(self, x):
+        raise RuntimeError("container only; the math runs in the enclosing network's HIP plan")
+
+    def emit(self, P, buf, stats, count, y, out_stats=None, out_c0=0):
+        w = P.weight(self.conv1.weight, self.out_planes, self.in_planes, 1, transposed=True)
+        P.conv(E.View(buf), w, y, 1, pro=P.bn_prologue(self.bn1, stats, count), upsample=True, stats=out_stats, stats_c0=out_c0)
+
+
+def _stem_filter(w7, out):
+    """conv0 (64, 3, 7, 7), stride 2, pad 3  ->  (64, 16, 4, 4) stride 1 on the 2x2 space-to-depth image (channel c 4 + dy 2 + dx,
+    as F.pixel_unshuffle orders them; 12 used + 4 zero): the 7x7 window is extended by a zero tap in front to 8x8 = 4x4 blocks."""
+    out.zero_()
+    w8 = torch.zeros((w7.shape[0], w7.shape[1], 8, 8), dtype=w7.dtype, device=w7.device)
+    w8[:, :, 1:, 1:] = w7.detach()
+    for dy in range(2):
+        for dx in range(2):
+            out[:, dy * 2 + dx:12:4] = w8[:, :, dy::2, dx::2]
+    return out
+
+
+class _DenseBase(_PlannedModule):
+    """The DCPDN `Dense` network (dehaze1113.py:431-570, :572-699; dehaze22.py:531-660), forward only, on the generator's own
+    machinery: torchvision's dense blocks and transitions on concat buffers, BatchNorm in the consumers' prologues.  New
+    here: the DenseNet stem -- the 7x7 stride-2 conv runs as a 4x4 stride-1 conv on the space-to-depth image (exact: a
+    zero-extended 8x8 window), norm0 / relu0 / MaxPool2d(3, 2, 1) as `fdgan_maxpool3s2_nhwc` -- and decoder blocks WITH
+    BatchNorm.  H and W must be multiples of 32."""
+    TAIL = None
+
+    def _make_layers(self):
+        feats = _tv.densenet121(pretrained=True).features
+        self.conv0, self.norm0, self.relu0, self.pool0 = feats.conv0, feats.norm0, feats.relu0, feats.pool0
+        self.dense_block1, self.trans_block1 = feats.denseblock1, feats.transition1
+        self.dense_block2, self.trans_block2 = feats.denseblock2, feats.transition2
+        self.dense_block3, self.trans_block3 = feats.denseblock3, feats.transition3
+        self.dense_block4, self.trans_block4 = BottleneckBlock(512, 256), TransitionBlock(768, 128)
+        self.dense_block5, self.trans_block5 = BottleneckBlock(384, 256), TransitionBlock(640, 128)
+        self.dense_block6, self.trans_block6 = BottleneckBlock(256, 128), TransitionBlock(384, 64)
+        self.dense_block7, self.trans_block7 = BottleneckBlock(64, 64), TransitionBlock(128, 32)
+        self.dense_block8, self.trans_block8 = BottleneckBlock(32, 32), TransitionBlock(64, 16)
+        self.conv_refin = nn.Conv2d(19, 20, 3, 1, 1)
+        self.tanh = nn.Tanh()
+        for nm in ("conv1010", "conv1020", "conv1030", "conv1040"):
+            setattr(self, nm, nn.Conv2d(20, 1, kernel_size=1, stride=1, padding=0))
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        if c != 3:
+            raise ValueError("%s expects 3 input channels, got %d" % (type(self).__name__, c))
+        if h % 32 or w % 32:
+            raise ValueError("%s needs H and W to be multiples of 32, got %dx%d" % (type(self).__name__, h, w))
+        train = self.training
+        P = NetPlan(dev)
+        A = lambda hh, ww, cc, zero=False: E.new_act(n, hh, ww, cc, dev, zero=zero)
+        h2, w2, h4, w4, h8, w8, h16, w16, h32, w32 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8, h // 16, w // 16, h // 32, w // 32
+        # ---- stem: conv0 on the space-to-depth image (two zero block rows / columns in front, one behind: pad 3 of the 7x7)
+        P.xs = A(h2 + 3, w2 + 3, 16, zero=True)
+        P.xs_in = E.StridedView(P.xs, 0, 16, 2, 2, 1, 1, h2, w2)
+        P.w0 = torch.zeros((64, 16, 4, 4), dtype=torch.float32, device=dev)
+        c0 = A(h2, w2, 64)
+        st0 = ChanStats(64, dev)
+        P.conv(E.View(P.xs), P.weight(P.w0, 64, 16, 4), E.View(c0), 4, pad=0, stats=st0 if train else None, label="conv0")
+        blk1, bott1 = A(h4, w4, 256), A(h4, w4, 128)
+        st1 = ChanStats(256, dev)
+        pro0 = P.bn_prologue(self.norm0, st0, n * h2 * w2, act=L.ACT_RELU)
+        pro0 = E.prologue_without_side_effects(pro0)          # norm0's running statistics: updated after the launch (`_run`)
+        pool_info = L.FdConvInfo()
+        pool_rows = (n * h4 * w4 + 31) // 32
+        pool_info.stats_rows, pool_info.stats_cpad = pool_rows, 64
+        x0 = E.View(blk1, 0, 64)
+        P._ops.append((lambda: (E.maxpool3s2(E.View(c0), pro0, x0, P.ws if train else None),
+                                E.bn_finalize(P.ws, pool_info, 64, n * h4 * w4, st1.mean, st1.var, 0) if train else None),
+                       pool_rows * 64 * 2 if train else 0, dict(label="pool0", flops=0.0, flops_done=0.0, bytes=n * h2 * w2 * 64 * 2 * 5 // 4)))
+        P.st0, P.cnt0 = st0, n * h2 * w2
+        # ---- encoder
+        blk2, bott2 = A(h8, w8, 512), A(h8, w8, 128)
+        blk3, bott3 = A(h16, w16, 1024), A(h16, w16, 128)
+        st2, st3 = ChanStats(512, dev), ChanStats(1024, dev)
+        b4, t4 = A(h32, w32, 768), A(h32, w32, 1024)
+        b5, t5 = A(h16, w16, 640), A(h16, w16, 1024)
+        b6, t6 = A(h8, w8, 384), A(h8, w8, 512)
+        b7, t7 = A(h4, w4, 128), A(h4, w4, 256)
+        b8, t8 = A(h2, w2, 64), A(h2, w2, 128)
+        s4, s5, s6, s7, s8 = (ChanStats(cc, dev) for cc in (768, 640, 384, 128, 64))
+        cnt4, cnt8, cnt16, cnt32, cnt2 = n * h4 * w4, n * h8 * w8, n * h16 * w16, n * h32 * w32, n * h2 * w2
+        _emit_dense_block(P, self.dense_block1, blk1, st1, bott1, cnt4)
+        # x1 feeds dense_block2 AND the concat x52 = [x5, x1] (:617): stored once, copied, statistics finalized into both tables
+        tb = self.trans_block1
+        P.conv(E.View(blk1), P.weight(tb.conv.weight, 128, 256, 1), E.View(blk2, 0, 128), 1, pro=P.bn_prologue(tb.norm, st1, cnt4, pool=True),
+               stats=st2 if train else None, stats_also=((s6, 128),) if train else ())
+        P.copy(E.View(blk2, 0, 128), E.View(b6, 128, 128))
+        _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt8)
+        tb = self.trans_block2      # x2: dense_block3's input and the concat x42 = [x4, x2] (:612)
+        P.conv(E.View(blk2), P.weight(tb.conv.weight, 256, 512, 1), E.View(blk3, 0, 256), 1, pro=P.bn_prologue(tb.norm, st2, cnt8, pool=True),
+               stats=st3 if train else None, stats_also=((s5, 128),) if train else ())
+        P.copy(E.View(blk3, 0, 256), E.View(b5, 128, 256))
+        _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt16)
+        _emit_transition(P, self.trans_block3, E.View(blk3), st3, E.View(b4, 0, 512), cnt16, out_stats=s4 if train else None)
+        # ---- decoder
+        self.dense_block4.emit(P, b4, s4, t4, cnt32)
+        self.trans_block4.emit(P, b4, s4, cnt32, E.View(b5, 0, 128), out_stats=s5 if train else None)
+        self.dense_block5.emit(P, b5, s5, t5, cnt16)
+        self.trans_block5.emit(P, b5, s5, cnt16, E.View(b6, 0, 128), out_stats=s6 if train else None)
+        self.dense_block6.emit(P, b6, s6, t6, cnt8)
+        self.trans_block6.emit(P, b6, s6, cnt8, E.View(b7, 0, 64), out_stats=s7 if train else None)
+        self.dense_block7.emit(P, b7, s7, t7, cnt4)
+        self.trans_block7.emit(P, b7, s7, cnt4, E.View(b8, 0, 32), out_stats=s8 if train else None)
+        self.dense_block8.emit(P, b8, s8, t8, cnt2)
+        P.cat8 = A(h, w, 24, zero=True)                                   # [x8 (16) | x (3) | 5 zero]
+        self.trans_block8.emit(P, b8, s8, cnt2, E.View(P.cat8, 0, 16))
+        P.out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+        P.copies = []
+        self._build_tail(P, n, h, w, dev, train)
+        P.keep += [c0, st0, st1, st2, st3, s4, s5, s6, s7, s8, blk1, blk2, blk3, b4, b5, b6, b7, b8, t4, t5, t6, t7, t8, bott1, bott2, bott3, x0, pro0]
+        return P.finish()
+
+    def forward(self, x):
+        if _wants_grad(self, x):
+            raise NotImplementedError("models.%s runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): call it "
+                                      "under torch.no_grad()" % type(self).__name__)
+        P = self._plan_for(x)
+        w7 = self.conv0.weight
+        with torch.no_grad():
+            if getattr(P.w0, "_src_version", None) != (w7._version, w7.data_ptr()):
+                _stem_filter(w7, P.w0)
+                P.w0._src_version = (w7._version, w7.data_ptr())
+            for dst, src_t in P.copies:
+                dst.copy_(src_t.detach())
+            self._refresh_tail(P)
+            xf = x.detach().float().contiguous()
+            E.to_nhwc(torch.nn.functional.pixel_unshuffle(xf, 2).contiguous(), P.xs_in)
+            E.to_nhwc(xf, E.View(P.cat8, 16, 8))
+            P.launch()
+            if self.training:       # norm0 is consumed by the pooling kernel, which has no side effects
+                bn, m = self.norm0, self.norm0.momentum if self.norm0.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(P.st0.mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(P.st0.var, alpha=m * P.cnt0 / max(P.cnt0 - 1, 1))
+                bn.num_batches_tracked.add_(1)
+            return P.out.clone()
+
+
+class _DensePyramid(_DenseBase):
+    """tail of dehaze1113.Dense2 (:688-699) and dehaze22.Dense (:634-660): LeakyReLU(conv_refin) -> four-scale head (32 / 16 / 8 / 4)
+    -> refine3(24 -> 3) -> tanh."""
+
+    def __init__(self):
+        super().__init__()
+        self._make_layers()
+        self.refine3 = nn.Conv2d(20 + 4, 3, kernel_size=3, stride=1, padding=1)
+        self.upsample = nn.functional.interpolate
+        self.relu = nn.LeakyReLU(0.2, inplace=True)
+
+    def _build_tail(self, P, n, h, w, dev, train):
+        P.head = E.new_act(n, h, w, 24, dev)          # [x9 (20) | pyramid (4)]; refine3's input channels permuted to match
+        P.conv(E.View(P.cat8, 0, 19), P.weight(self.conv_refin.weight, 20, 19, 3), E.View(P.head, 0, 20), 3, pad=1, bias=self.conv_refin.bias,
+               e_act=L.ACT_LEAKY02, label="conv_refin")
+        P.pw = torch.zeros((4, 20), dtype=torch.float32, device=dev)
+        P.pb = torch.zeros((4,), dtype=torch.float32, device=dev)
+        for i, nm in enumerate(("conv1010", "conv1020", "conv1030", "conv1040")):
+            conv = getattr(self, nm)
+            P.copies += [(P.pw[i], conv.weight.view(20)), (P.pb[i:i + 1], conv.bias)]
+        x20, y4 = E.View(P.head, 0, 20), E.View(P.head, 20, 4)
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4))
+        P.wfinal = torch.zeros((3, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.conv(E.View(P.head), P.weight(P.wfinal, 3, 24, 3), None, 3, pad=1, bias=self.refine3.bias, e_act=L.ACT_TANH,
+               y_fd=E.nchw_f32_view(P.out), label="refine3")
+        P.keep += [x20, y4]
+
+    def _refresh_tail(self, P):
+        wf = self.refine3.weight
+        if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
+            P.wfinal[:, :20].copy_(wf.detach()[:, 4:])       # reference order: [pyramid 0-3 | x9 4-23]
+            P.wfinal[:, 20:].copy_(wf.detach()[:, :4])
+            P.wfinal._src_version = (wf._version, wf.data_ptr())
+
+
+class Dense(_DenseBase):
+    """dehaze1113.py:431-570: tail conv_refin -> batchnorm20 -> LeakyReLU -> refine3(20 -> 3) -> tanh."""
+
+    def __init__(self):
+        super().__init__()
+        self._make_layers()
+        self.refine3 = nn.Conv2d(20, 3, kernel_size=3, stride=1, padding=1)
+        self.upsample = nn.functional.interpolate
+        self.relu = nn.LeakyReLU(0.2, inplace=True)
+        self.batchnorm20 = nn.BatchNorm2d(20)
+        self.batchnorm1 = nn.BatchNorm2d(1)            # registered, never called (:466)
+
+    def _build_tail(self, P, n, h, w, dev, train):
+        P.head = E.new_act(n, h, w, 24, dev, zero=True)
+        s20 = ChanStats(24, dev)
+        P.conv(E.View(P.cat8, 0, 19), P.weight(self.conv_refin.weight, 20, 19, 3), E.View(P.head, 0, 20), 3, pad=1, bias=self.conv_refin.bias,
+               stats=s20 if train else None, label="conv_refin")
+        P.conv(E.View(P.head, 0, 20), P.weight(self.refine3.weight, 3, 20, 3), None, 3, pad=1, bias=self.refine3.bias,
+               pro=P.bn_prologue(self.batchnorm20, s20, n * h * w, act=L.ACT_LEAKY02), e_act=L.ACT_TANH, y_fd=E.nchw_f32_view(P.out), label="refine3")
+        P.keep.append(s20)
+
+    def _refresh_tail(self, P):
+        pass
+
+
+class Dense2(_DensePyramid):
+    """dehaze1113.py:572-699."""
+
+
+# ---------------------------------------------------------------------------------------
 # Fusion-discriminator
 # ---------------------------------------------------------------------------------------
 class _Named(nn.Sequential):

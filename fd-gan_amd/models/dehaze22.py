@@ -4,7 +4,8 @@ DCPDN-era generators of that file (not on FD-GAN's hot path), 
 `G` (:205-362) and `G2` (:364-488) -- forward only, on the same primitives: 4x4 stride-2 convolutions,
 ConvTranspose2d(4, 2, 1) as four stride-1 3x3 convolutions (one per output parity, strided output
 views), train- or eval-mode BatchNorm folded into the consumers' prologues, train-mode Dropout2d,
-the multi-scale pooling head as one kernel.  `Dense` (:531) and `dehaze` (:662) are not provided.
+the multi-scale pooling head as one kernel -- and `Dense` (:531-660, built in models/dehaze1113.py).
+`dehaze` (:662-753) is not provided.
 
 Dataflow (one recorded plan, NHWC bf16, BatchNorm folded into the consumer's prologue):
     x -> 4x4 s2 -> [LReLU | 4x4 s2 | BN] x2 -> LReLU, 4x4 s1, BN -> LReLU, 4x4 s1 (->1), sigmoid
@@ -15,7 +16,8 @@ import torch.nn as nn
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
 from fdgan_hip.netplan import ChanStats, NetPlan
-from models.dehaze1113 import _Named, _PlannedModule, _apply_plan_function, _plan_backward, _wants_grad
+from models.dehaze1113 import (BottleneckBlock, TransitionBlock, _DensePyramid, _Named, _PlannedModule, _apply_plan_function,
+                               _plan_backward, _wants_grad)
 
 
 def blockUNet(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
@@ -416,10 +418,14 @@ class G2(_UNet):
 def _legacy(name):
     def ctor(*a, **k):
         raise NotImplementedError("models.dehaze22.%s is a legacy DCPDN network outside FD-GAN's hot path "
-                                  "(reference demo.py uses models.dehaze1113.FDGAN); of that family only the U-Nets G and G2 "
-                                  "are provided" % name)
+                                  "(reference demo.py uses models.dehaze1113.FDGAN); of that family G, G2 and Dense are "
+                                  "provided" % name)
     ctor.__name__ = name
     return ctor
 
 
-Dense, dehaze = _legacy("Dense"), _legacy("dehaze")
+class Dense(_DensePyramid):
+    """dehaze22.py:531-660: the DCPDN transmission network (the same network as dehaze1113.Dense2)."""
+
+
+dehaze = _legacy("dehaze")

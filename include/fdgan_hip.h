@@ -223,6 +223,12 @@ int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
  * train-mode nn.BatchNorm2d followed by train-mode nn.Dropout2d (dehaze22.py:60-63; the caller draws the (N, C) mask of
  * 0 / 1/(1-p) values).  mean == NULL: no normalisation; gamma / beta == NULL: 1 / 0; mask == NULL: no dropout.  Padding
  * channels of the 8-channel groups are written as zero. */
+/* fdgan_maxpool3s2_nhwc: y = MaxPool2d(kernel 3, stride 2, padding 1)(act(bn(x))) -- torchvision DenseNet-121's norm0 / relu0 /
+ * pool0 as `Dense` uses them (dehaze22.py:540-543, :607).  `pro` as for a convolution (mean == NULL: no normalisation; act NONE or
+ * RELU; the running-statistics side effect is NOT applied here).  partial != NULL: one row of per-channel (sum, sum of squares)
+ * of the stored values per workgroup, rows_out rows of y->c channels, for fdgan_bn_finalize. */
+int fdgan_maxpool3s2_nhwc(const FdTensor* x, const FdPrologue* pro, const FdTensor* y, float* partial, int64_t capacity_floats,
+                          int64_t* rows_out, FdStream stream);
 int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* y,
                         FdStream stream);
 int fdgan_bn_dropout_nhwc(const FdTensor* x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,

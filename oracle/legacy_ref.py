@@ -64,3 +64,60 @@ def unet_forward(sd, x, training, kind, masks=None):
         pyr.append(F.interpolate(F.leaky_relu(p, 0.2), size=size, mode="nearest"))
     d = torch.cat(pyr + [d], 1)
     return torch.tanh(F.conv2d(d, sd["dlayerfinal.dlayer1.conv.weight"], None, 1, 1)), used
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# `Dense`: the DCPDN dehazing network, three spellings of one topology --
+#   /root/reference/models/dehaze1113.py Dense  :431-570   tail: conv_refin -> batchnorm20 -> LeakyReLU -> refine3(20 -> 3) -> tanh
+#   /root/reference/models/dehaze1113.py Dense2 :572-699 } tail: conv_refin -> LeakyReLU -> four-scale pooling head (avg_pool 32 / 16 /
+#   /root/reference/models/dehaze22.py   Dense  :531-660 }       8 / 4, Conv2d(20, 1, 1), LeakyReLU, nearest upsampling) in FRONT of the
+#                                                                20 channels -> refine3(24 -> 3) -> tanh
+# Encoder: torchvision DenseNet-121 stem (conv0 7x7 stride 2, norm0, relu0, MaxPool2d(3, 2, 1)) + dense blocks 1-3 with their
+# transitions; decoder: BottleneckBlock (BN-ReLU-1x1, BN-ReLU-3x3, concat) / TransitionBlock (BN-ReLU-ConvTranspose 1x1, nearest x2)
+# with the skip concatenations x42 = [x4, x2], x52 = [x5, x1], x8 = [x8, x] (dehaze22.py:491-529, :604-632).
+# ------------------------------------------------------------------------------------------------------------------
+def dense_forward(sd, x, training, tail):
+    """sd: state_dict (running statistics updated in place in training mode).  tail: "bn" (dehaze1113.Dense) or "pyramid"."""
+    sd = dict(sd)
+    bn = lambda t, p: _bn(t, sd, p, training)
+
+    def dense_block(t, name, layers):
+        for i in range(1, layers + 1):
+            p = "%s.denselayer%d." % (name, i)
+            y = F.conv2d(F.relu(bn(t, p + "norm1")), sd[p + "conv1.weight"])
+            y = F.conv2d(F.relu(bn(y, p + "norm2")), sd[p + "conv2.weight"], None, 1, 1)
+            t = torch.cat([t, y], 1)
+        return t
+
+    def transition(t, name):
+        return F.avg_pool2d(F.conv2d(F.relu(bn(t, name + ".norm")), sd[name + ".conv.weight"]), 2)
+
+    def bottleneck(t, name):
+        y = F.conv2d(F.relu(bn(t, name + ".bn1")), sd[name + ".conv1.weight"])
+        y = F.conv2d(F.relu(bn(y, name + ".bn2")), sd[name + ".conv2.weight"], None, 1, 1)
+        return torch.cat([t, y], 1)
+
+    def transup(t, name):
+        y = F.conv_transpose2d(F.relu(bn(t, name + ".bn1")), sd[name + ".conv1.weight"])
+        return F.interpolate(y, scale_factor=2, mode="nearest")
+
+    x0 = F.max_pool2d(F.relu(bn(F.conv2d(x, sd["conv0.weight"], None, 2, 3), "norm0")), 3, 2, 1)
+    x1 = transition(dense_block(x0, "dense_block1", 6), "trans_block1")
+    x2 = transition(dense_block(x1, "dense_block2", 12), "trans_block2")
+    x3 = transition(dense_block(x2, "dense_block3", 24), "trans_block3")
+    x4 = transup(bottleneck(x3, "dense_block4"), "trans_block4")
+    x5 = transup(bottleneck(torch.cat([x4, x2], 1), "dense_block5"), "trans_block5")
+    x6 = transup(bottleneck(torch.cat([x5, x1], 1), "dense_block6"), "trans_block6")
+    x7 = transup(bottleneck(x6, "dense_block7"), "trans_block7")
+    x8 = transup(bottleneck(x7, "dense_block8"), "trans_block8")
+    x9 = F.conv2d(torch.cat([x8, x], 1), sd["conv_refin.weight"], sd["conv_refin.bias"], 1, 1)
+    if tail == "bn":
+        x9 = F.leaky_relu(bn(x9, "batchnorm20"), 0.2)
+        return torch.tanh(F.conv2d(x9, sd["refine3.weight"], sd["refine3.bias"], 1, 1))
+    x9 = F.leaky_relu(x9, 0.2)
+    size = x9.shape[2:4]
+    pyr = []
+    for k, nm in ((32, "conv1010"), (16, "conv1020"), (8, "conv1030"), (4, "conv1040")):
+        p = F.conv2d(F.avg_pool2d(x9, k), sd[nm + ".weight"], sd[nm + ".bias"])
+        pyr.append(F.interpolate(F.leaky_relu(p, 0.2), size=size, mode="nearest"))
+    return torch.tanh(F.conv2d(torch.cat(pyr + [x9], 1), sd["refine3.weight"], sd["refine3.bias"], 1, 1))

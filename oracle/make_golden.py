@@ -212,6 +212,31 @@ def main():
                             rv_layer8=after["layer8.layer8.bn.running_var"].numpy())
         man["legacy_%s_keys" % kind] = list(sd0.keys())
 
+    # ---------------- legacy `Dense` (three spellings of one topology), 2x3x128x160 ----------------
+    xd_ = det_input((2, 3, 128, 160), seed=31)
+    for nm, cls, tail in (("dense1113", r1113.Dense, "bn"), ("dense2_1113", r1113.Dense2, "pyramid"), ("dense22", r22.Dense, "pyramid")):
+        net = cls()
+        fill_state_dict(net, seed=6)
+        with torch.no_grad():                        # keep the tanh unsaturated
+            net.refine3.weight.mul_(0.1), net.refine3.bias.mul_(0.1)
+        sd0 = {kk: vv.clone() for kk, vv in net.state_dict().items()}
+        outs = {}
+        for mode in (False, True):
+            net.load_state_dict(sd0)
+            net.train(mode)
+            sdm = {kk: vv.clone() for kk, vv in sd0.items()}
+            with torch.no_grad():
+                yr = net(xd_.clone())
+                yo = legacy_ref.dense_forward(sdm, xd_.clone(), mode, tail)
+            man["ref_vs_oracle_maxabs"]["legacy_%s_%s" % (nm, "train" if mode else "eval")] = float((yr - yo).abs().max())
+            outs["y_train" if mode else "y_eval"] = yr.numpy()[:, :, ::2, ::2]
+            if mode:
+                after = net.state_dict()
+                outs["rm_norm0"], outs["rv_norm0"] = after["norm0.running_mean"].numpy(), after["norm0.running_var"].numpy()
+                outs["rm_tb5"], outs["rv_tb5"] = after["trans_block5.bn1.running_mean"].numpy(), after["trans_block5.bn1.running_var"].numpy()
+        np.savez_compressed(os.path.join(OUT, "legacy_%s_2x128.npz" % nm), **outs)
+        man["legacy_%s_keys" % nm] = len(sd0)
+
     # ---------------- VGG16 features, 1x3x32x32 ----------------
     ov, rv = OVgg(), RVgg()
     fill_state_dict(ov, seed=0)

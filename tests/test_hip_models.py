@@ -1106,3 +1106,47 @@ def test_legacy_unets_match_oracle_and_golden(golden_dir, kind):
     assert rep["eval_rel_rms_vs_oracle"] < 2e-2 and rep["train_rel_rms_vs_oracle"] < 3e-2, rep
     assert rep["eval_max_abs_vs_reference"] < 3e-2 and rep["train_max_abs_vs_reference"] < 6e-2, rep
     assert max(v for k, v in rep.items() if k.startswith("running_")) < 2e-2, rep
+
+
+@pytest.mark.parametrize("nm,mod,cls,tail", [("dense1113", "dehaze1113", "Dense", "bn"), ("dense2_1113", "dehaze1113", "Dense2", "pyramid"),
+                                            ("dense22", "dehaze22", "Dense", "pyramid")])
+def test_legacy_dense_matches_oracle_and_golden(golden_dir, nm, mod, cls, tail):
+    """the DCPDN `Dense` network on the HIP path -- DenseNet stem (7x7 stride-2 conv as a space-to-depth 4x4
+    conv, norm0 / relu0 / MaxPool2d(3, 2, 1) in one kernel), torchvision dense blocks, decoder blocks WITH BatchNorm (statistics
+    through nearest upsampling), both tails -- against the fp32 oracle (0.0 from the real reference) and the reference's own
+    outputs, eval and train mode; running statistics compared."""
+    import importlib
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = getattr(importlib.import_module("models." + mod), cls)()
+    fill_state_dict(net, seed=6)
+    with torch.no_grad():
+        net.refine3.weight.mul_(0.1), net.refine3.bias.mul_(0.1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = det_input((2, 3, 128, 160), seed=31)
+    g = np.load(os.path.join(golden_dir, "legacy_%s_2x128.npz" % nm))
+    rep = {}
+    for mode in (False, True):
+        net.load_state_dict(sd)
+        net.train(mode)
+        sdm = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad():
+            y = net(x.to(DEV)).cpu()
+            yo = legacy_ref.dense_forward(sdm, x.clone(), mode, tail)
+        tag = "train" if mode else "eval"
+        assert y.shape == (2, 3, 128, 160)
+        rep[tag + "_psnr_vs_oracle"] = psnr(y, yo)
+        rep[tag + "_rel_rms_vs_oracle"] = rel_rms(y, yo)
+        rep[tag + "_max_abs_vs_reference"] = float((y[:, :, ::2, ::2] - torch.from_numpy(g["y_" + tag])).abs().max())
+        if mode:
+            after = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            for bn in ("norm0", "trans_block5.bn1", "dense_block1.denselayer3.norm2", "dense_block7.bn2", "trans_block1.norm"):
+                rep["running_mean_" + bn] = float((after[bn + ".running_mean"] - sdm[bn + ".running_mean"]).abs().max())
+                rep["running_var_" + bn] = rel_rms(after[bn + ".running_var"], sdm[bn + ".running_var"])
+                assert int(after[bn + ".num_batches_tracked"]) == 1, bn
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV).requires_grad_(True))
+    _report("legacy_" + nm, rep)
+    assert rep["eval_psnr_vs_oracle"] > 35.0 and rep["train_psnr_vs_oracle"] > 35.0, rep
+    assert max(v for k, v in rep.items() if k.startswith("running_")) < 2e-2, rep

@@ -277,3 +277,47 @@ def test_transposed_conv_as_four_parity_convolutions():
         for b in range(2):
             out[:, :, a::2, b::2] = F.conv2d(x, filt[a * 2 + b], None, 1, 1)
     assert float((out - ref).abs().max()) < 1e-5
+
+
+_DENSE = (("dense1113", "dehaze1113", "Dense", "bn"), ("dense2_1113", "dehaze1113", "Dense2", "pyramid"), ("dense22", "dehaze22", "Dense", "pyramid"))
+
+
+@pytest.mark.parametrize("nm,mod,cls,tail", _DENSE)
+def test_legacy_dense_matches_golden(golden_dir, manifest, nm, mod, cls, tail):
+    """oracle/legacy_ref.dense_forward (dehaze1113.Dense :431-570, Dense2 :572-699, dehaze22.Dense :531-660)
+    against outputs of the REAL reference, eval and train mode, incl. the running statistics a train-mode forward leaves."""
+    import importlib
+    from oracle import legacy_ref
+    assert manifest["ref_vs_oracle_maxabs"]["legacy_%s_eval" % nm] == 0.0 and manifest["ref_vs_oracle_maxabs"]["legacy_%s_train" % nm] == 0.0
+    net = getattr(importlib.import_module("models." + mod), cls)()          # the product's parameter container
+    assert len(net.state_dict()) == manifest["legacy_%s_keys" % nm]
+    fill_state_dict(net, seed=6)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["refine3.weight"] *= 0.1
+    sd["refine3.bias"] *= 0.1
+    x = det_input((2, 3, 128, 160), seed=31)
+    g = _load(golden_dir, "legacy_%s_2x128.npz" % nm)
+    with torch.no_grad():
+        ye = legacy_ref.dense_forward({k: v.clone() for k, v in sd.items()}, x.clone(), False, tail)
+        sdt = {k: v.clone() for k, v in sd.items()}
+        yt = legacy_ref.dense_forward(sdt, x.clone(), True, tail)
+    assert float((ye[:, :, ::2, ::2] - torch.from_numpy(g["y_eval"])).abs().max()) < 1e-5
+    assert float((yt[:, :, ::2, ::2] - torch.from_numpy(g["y_train"])).abs().max()) < 1e-5
+    assert float((sdt["norm0.running_var"] - torch.from_numpy(g["rv_norm0"])).abs().max()) < 1e-5
+    assert float((sdt["trans_block5.bn1.running_mean"] - torch.from_numpy(g["rm_tb5"])).abs().max()) < 1e-5
+
+
+def test_densenet_stem_as_space_to_depth_convolution():
+    """models/dehaze1113.py runs conv0 (7x7, stride 2, pad 3) as a 4x4 stride-1 convolution over the 2x2 space-to-depth image
+    with two zero block rows / columns in front and one behind: the filter rearrangement against torch's conv2d."""
+    import torch.nn.functional as F
+    import models.dehaze1113 as net
+    torch.manual_seed(4)
+    w7 = torch.randn(8, 3, 7, 7)
+    x = torch.randn(2, 3, 20, 28)
+    ref = F.conv2d(x, w7, None, 2, 3)
+    w4 = net._stem_filter(w7, torch.empty(8, 16, 4, 4))
+    xs = torch.zeros(2, 16, 10 + 3, 14 + 3)
+    xs[:, :12, 2:12, 2:16] = F.pixel_unshuffle(x, 2)
+    out = F.conv2d(xs, w4)
+    assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-4
