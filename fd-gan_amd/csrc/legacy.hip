@@ -7,6 +7,8 @@
 //                         bias, activation, broadcast -- one pass over x, one 8-byte store per pixel, nothing intermediate.
 //   fdgan_maxpool3s2_nhwc MaxPool2d(3, 2, 1) of relu(bn(x)): the DenseNet stem's norm0 / relu0 / pool0, with the statistics of what it
 //                         stores for the first dense layer's norm1.
+//   fdgan_scatter_dehaze  the atmospheric-scattering inversion of `dehaze` (dehaze22.py:699-715): airlight = LeakyReLU of the mean of
+//                         G2's output over H x H windows, J = (I - A) / (|t| + 1e-10) + A.
 //   fdgan_bn_dropout_nhwc y = mask[n][c] * bn(x): train-mode BatchNorm followed by train-mode Dropout2d (a per-(sample,
 //                         channel) mask, dehaze22.py:60-63) on the U-Net's three innermost decoder outputs (at most 8 x 8
 //                         pixels): the consumer then sees finished values.
@@ -196,7 +198,82 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(Mp3Args a) {
   }
 }
 
+struct AtpArgs {
+  const float* atp;      // [N][3][H][W]
+  float* mean;           // [N][3][W / H]: leaky_relu(mean over the H x H window)
+  int H, W, nwin;
+  float slope;
+};
+
+// one workgroup per (image, channel, H x H window): fixed-order tree reduction
+__global__ __launch_bounds__(256) void atp_window_mean_kernel(AtpArgs a) {
+  __shared__ double sh[256];
+  const int win = blockIdx.x % a.nwin, nc = blockIdx.x / a.nwin;
+  const float* p = a.atp + (long long)nc * a.H * a.W + (long long)win * a.H;
+  double acc = 0.0;
+  for (long long i = threadIdx.x; i < (long long)a.H * a.H; i += 256) acc += (double)p[(i / a.H) * a.W + (i % a.H)];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = (float)(sh[0] / ((double)a.H * a.H));
+    a.mean[blockIdx.x] = fmaxf(v, a.slope * v);
+  }
+}
+
+struct ScatterArgs {
+  const float *x, *tran, *mean;
+  float *atp_out, *dehaze2;
+  unsigned short* cat;
+  long long c_sn, c_sh, c_sw;
+  int H, W, nwin;
+  float eps;
+  long long total;   // N * H * W
+};
+
+// J = (I - A) / (|t| + eps) + A per pixel and channel (dehaze22.py:699-715), stored as NCHW fp32 (an output of the network) and,
+// with the hazy image behind it, as the 6 (+2 zero) channel NHWC bf16 input of refine1
+__global__ void scatter_dehaze_kernel(ScatterArgs a) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.total) return;
+  const int px = (int)(u % a.W), py = (int)((u / a.W) % a.H);
+  const long long n = u / ((long long)a.W * a.H), plane = (long long)a.H * a.W;
+  const int wsel = (int)((long long)px * a.nwin / a.W);      // upsample_nearest of the 1 x nwin map to H x W
+  f32x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const long long i = (n * 3 + c) * plane + (long long)py * a.W + px;
+    const float A = a.mean[(n * 3 + c) * a.nwin + wsel];
+    const float xv = a.x[i], t = a.tran[i];
+    const float d = (xv - A) / (fabsf(t) + a.eps) + A;
+    a.atp_out[i] = A;
+    a.dehaze2[i] = d;
+    o[c] = d;
+    o[3 + c] = xv;
+  }
+  *reinterpret_cast<u32x4*>(a.cat + n * a.c_sn + (long long)py * a.c_sh + (long long)px * a.c_sw) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+}
+
 }  // namespace
+
+extern "C" int fdgan_scatter_dehaze(const float* x, const float* tran, const float* atp, int64_t n, int64_t h, int64_t w, float slope, float eps,
+                                    float* window_mean, float* atp_out, float* dehaze2, const FdTensor* cat, FdStream stream) {
+  FD_REQUIRE(x && tran && atp && window_mean && atp_out && dehaze2 && cat && cat->ptr, "scatter_dehaze: NULL pointer");
+  FD_REQUIRE(n > 0 && h > 0 && w >= h, "scatter_dehaze: the reference pools the airlight over H x H windows (dehaze22.py:705): W >= H required");
+  FD_REQUIRE(cat->dtype == FD_BF16 && cat->stride[3] == 1 && cat->n == n && cat->h == h && cat->w == w && cat->c >= 8, "scatter_dehaze: cat must be an N x H x W x 8 NHWC bf16 view");
+  FD_REQUIRE(((uintptr_t)cat->ptr & 15) == 0 && cat->stride[0] % 8 == 0 && cat->stride[1] % 8 == 0 && cat->stride[2] % 8 == 0, "scatter_dehaze: 16-byte alignment");
+  const int nwin = (int)(w / h);
+  AtpArgs r{atp, window_mean, (int)h, (int)w, nwin, slope};
+  if (int rc = fd_launch(&atp_window_mean_kernel, "atp_window_mean", dim3((unsigned)(n * 3 * nwin)), dim3(256), 0, r, static_cast<hipStream_t>(stream))) return rc;
+  ScatterArgs a{x, tran, window_mean, atp_out, dehaze2, static_cast<unsigned short*>(cat->ptr), cat->stride[0], cat->stride[1], cat->stride[2],
+                (int)h, (int)w, nwin, eps, n * h * w};
+  return fd_launch(&scatter_dehaze_kernel, "scatter_dehaze", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int fdgan_maxpool3s2_nhwc(const FdTensor* x, const FdPrologue* pro, const FdTensor* y, float* partial, int64_t capacity_floats,
                                      int64_t* rows_out, FdStream stream) {

@@ -238,6 +238,16 @@ def pyramid_pool4(x, weight, bias, k0, slope, y):
                                          stream_ptr()), "pyramid_pool4")
 
 
+def scatter_dehaze(x, tran, atp, slope, eps, window_mean, atp_out, dehaze2, cat):
+    """dehaze22.py:699-715 on contiguous (N, 3, H, W) fp32 tensors; cat: View of an (N, H, W, 8) buffer."""
+    n, _, h, w = x.shape
+    for t in (x, tran, atp, atp_out, dehaze2):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (n, 3, h, w)
+    L.check(L.load().fdgan_scatter_dehaze(x.data_ptr(), tran.data_ptr(), atp.data_ptr(), n, h, w, float(slope), float(eps),
+                                          window_mean.data_ptr(), atp_out.data_ptr(), dehaze2.data_ptr(), C.byref(cat.fd), stream_ptr()),
+            "scatter_dehaze")
+
+
 def maxpool3s2(x, pro, y, stats_buf=None):
     """y = MaxPool2d(3, 2, 1)(act(bn(x))); returns the number of statistics rows written to stats_buf (0 without one)."""
     rows = C.c_int64(0)

@@ -75,6 +75,8 @@ SIGNATURES = {
                                               C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_nhwc_bf16_to_nchw_f32": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p]),
     "fdgan_copy_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_scatter_dehaze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_maxpool3s2_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor), C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_pyramid_pool4": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(FdTensor), C.c_void_p]),

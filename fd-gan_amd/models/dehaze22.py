@@ -5,7 +5,7 @@ DCPDN-era generators of that file (not on FD-GAN's hot path), 
 ConvTranspose2d(4, 2, 1) as four stride-1 3x3 convolutions (one per output parity, strided output
 views), train- or eval-mode BatchNorm folded into the consumers' prologues, train-mode Dropout2d,
 the multi-scale pooling head as one kernel -- and `Dense` (:531-660, built in models/dehaze1113.py).
-`dehaze` (:662-753) is not provided.
+`dehaze` (:662-753) composes them around `fdgan_scatter_dehaze`.
 
 Dataflow (one recorded plan, NHWC bf16, BatchNorm folded into the consumer's prologue):
     x -> 4x4 s2 -> [LReLU | 4x4 s2 | BN] x2 -> LReLU, 4x4 s1, BN -> LReLU, 4x4 s1 (->1), sigmoid
@@ -415,17 +415,75 @@ class G2(_UNet):
         return out
 
 
-def _legacy(name):
-    def ctor(*a, **k):
-        raise NotImplementedError("models.dehaze22.%s is a legacy DCPDN network outside FD-GAN's hot path "
-                                  "(reference demo.py uses models.dehaze1113.FDGAN); of that family G, G2 and Dense are "
-                                  "provided" % name)
-    ctor.__name__ = name
-    return ctor
-
-
 class Dense(_DensePyramid):
     """dehaze22.py:531-660: the DCPDN transmission network (the same network as dehaze1113.Dense2)."""
 
 
-dehaze = _legacy("dehaze")
+class dehaze(_PlannedModule):
+    """dehaze22.py:662-753, forward only: transmission t = Dense(x), airlight A = G2(x) pooled over H x H windows, the
+    scattering model inverted per pixel, J = (x - A) / (|t| + 1e-10) + A, then refine1 / refine2, the four-scale head and
+    tanh(refine3).  Returns (dehaze, tran, atp, dehaze2) like the reference.  `tran_est` (a G) is registered and never called
+    (:665), as there.  The two sub-networks run their own plans; the plan here is the tail."""
+
+    def __init__(self, input_nc, output_nc, nf):
+        super().__init__()
+        self.tran_est = G(input_nc=3, output_nc=3, nf=64)
+        self.atp_est = G2(input_nc=3, output_nc=3, nf=8)
+        self.tran_dense = Dense()
+        self.relu = nn.LeakyReLU(0.2, inplace=True)
+        self.tanh = nn.Tanh()
+        self.refine1 = nn.Conv2d(6, 20, kernel_size=3, stride=1, padding=1)
+        self.refine2 = nn.Conv2d(20, 20, kernel_size=3, stride=1, padding=1)
+        self.threshold = nn.Threshold(0.1, 0.1)
+        for nm in ("conv1010", "conv1020", "conv1030", "conv1040"):
+            setattr(self, nm, nn.Conv2d(20, 1, kernel_size=1, stride=1, padding=0))
+        self.refine3 = nn.Conv2d(20 + 4, 3, kernel_size=3, stride=1, padding=1)
+        self.upsample = nn.functional.interpolate
+        self.batch1 = nn.BatchNorm2d(20)               # registered, never called (:686)
+
+    def _build_plan(self, shape, dev):
+        n, c, h, w = shape
+        P = NetPlan(dev)
+        P.cat6 = E.new_act(n, h, w, 8, dev, zero=True)            # [J (3) | x (3) | 0 0]
+        P.r1 = E.new_act(n, h, w, 24, dev, zero=True)
+        P.head = E.new_act(n, h, w, 24, dev)                      # [refine2 output (20) | pyramid (4)]
+        P.conv(E.View(P.cat6, 0, 6), P.weight(self.refine1.weight, 20, 6, 3), E.View(P.r1, 0, 20), 3, pad=1, bias=self.refine1.bias,
+               e_act=L.ACT_LEAKY02, label="refine1")
+        P.conv(E.View(P.r1, 0, 20), P.weight(self.refine2.weight, 20, 20, 3), E.View(P.head, 0, 20), 3, pad=1, bias=self.refine2.bias,
+               e_act=L.ACT_LEAKY02, label="refine2")
+        P.pw = torch.zeros((4, 20), dtype=torch.float32, device=dev)
+        P.pb = torch.zeros((4,), dtype=torch.float32, device=dev)
+        x20, y4 = E.View(P.head, 0, 20), E.View(P.head, 20, 4)
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4))
+        P.wfinal = torch.zeros((3, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+        P.conv(E.View(P.head), P.weight(P.wfinal, 3, 24, 3), None, 3, pad=1, bias=self.refine3.bias, e_act=L.ACT_TANH,
+               y_fd=E.nchw_f32_view(P.out), label="refine3")
+        P.wmean = torch.zeros((n * 3 * max(w // h, 1),), dtype=torch.float32, device=dev)
+        P.keep += [x20, y4]
+        return P.finish()
+
+    def forward(self, x):
+        if _wants_grad(self, x):
+            raise NotImplementedError("models.dehaze22.dehaze runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): "
+                                      "call it under torch.no_grad()")
+        if x.shape[3] < x.shape[2]:
+            raise ValueError("dehaze pools the airlight over H x H windows (dehaze22.py:705): W >= H required, got %dx%d" % tuple(x.shape[2:]))
+        with torch.no_grad():
+            xf = x.detach().float().contiguous()
+            tran = self.tran_dense(xf)
+            atp_raw = self.atp_est(xf)
+            P = self._plan_for(xf)
+            for i, nm in enumerate(("conv1010", "conv1020", "conv1030", "conv1040")):
+                conv = getattr(self, nm)
+                P.pw[i].copy_(conv.weight.detach().view(20))
+                P.pb[i:i + 1].copy_(conv.bias.detach())
+            wf = self.refine3.weight
+            if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
+                P.wfinal[:, :20].copy_(wf.detach()[:, 4:])       # reference order: [pyramid 0-3 | features 4-23]
+                P.wfinal[:, 20:].copy_(wf.detach()[:, :4])
+                P.wfinal._src_version = (wf._version, wf.data_ptr())
+            atp, dehaze2 = torch.empty_like(xf), torch.empty_like(xf)
+            E.scatter_dehaze(xf, tran, atp_raw, 0.2, 1e-10, P.wmean, atp, dehaze2, E.View(P.cat6))
+            P.launch()
+            return P.out.clone(), tran, atp, dehaze2

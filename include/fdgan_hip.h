@@ -223,6 +223,12 @@ int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
  * train-mode nn.BatchNorm2d followed by train-mode nn.Dropout2d (dehaze22.py:60-63; the caller draws the (N, C) mask of
  * 0 / 1/(1-p) values).  mean == NULL: no normalisation; gamma / beta == NULL: 1 / 0; mask == NULL: no dropout.  Padding
  * channels of the 8-channel groups are written as zero. */
+/* fdgan_scatter_dehaze: the arithmetic between the sub-networks of `dehaze` (dehaze22.py:699-715), all tensors contiguous
+ * N x 3 x H x W fp32:  A = upsample_nearest(LeakyReLU(slope)(avg_pool2d(atp, H)), (H, W))  (window_mean: scratch of
+ * N * 3 * (W / H) floats),  J = (x - A) / (|tran| + eps) + A.  Outputs: atp_out = A, dehaze2 = J (two of the network's four
+ * return values) and `cat`, an N x H x W x 8 NHWC bf16 view receiving [J (3) | x (3) | 0 0], the input of refine1. */
+int fdgan_scatter_dehaze(const float* x, const float* tran, const float* atp, int64_t n, int64_t h, int64_t w, float slope, float eps,
+                         float* window_mean, float* atp_out, float* dehaze2, const FdTensor* cat, FdStream stream);
 /* fdgan_maxpool3s2_nhwc: y = MaxPool2d(kernel 3, stride 2, padding 1)(act(bn(x))) -- torchvision DenseNet-121's norm0 / relu0 /
  * pool0 as `Dense` uses them (dehaze22.py:540-543, :607).  `pro` as for a convolution (mean == NULL: no normalisation; act NONE or
  * RELU; the running-statistics side effect is NOT applied here).  partial != NULL: one row of per-channel (sum, sum of squares)

@@ -121,3 +121,25 @@ def dense_forward(sd, x, training, tail):
         p = F.conv2d(F.avg_pool2d(x9, k), sd[nm + ".weight"], sd[nm + ".bias"])
         pyr.append(F.interpolate(F.leaky_relu(p, 0.2), size=size, mode="nearest"))
     return torch.tanh(F.conv2d(torch.cat(pyr + [x9], 1), sd["refine3.weight"], sd["refine3.bias"], 1, 1))
+
+
+def dehaze_forward(sd, x, training, masks=None):
+    """/root/reference/models/dehaze22.py `dehaze` :662-753: transmission = Dense(x), airlight = G2(x) pooled over H x H windows,
+    J = (x - A) / (|t| + 1e-10) + A (:699-715), then refine1 / refine2 (LeakyReLU), the four-scale head (32 / 16 / 8 / 4) and
+    tanh(refine3).  `tran_est` (a G) is registered but never called (:665).  Returns (dehaze, tran, atp, dehaze2, masks used)."""
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    tran = dense_forward(sub("tran_dense."), x, training, "pyramid")
+    atp, used = unet_forward(sub("atp_est."), x, training, "G2", masks)
+    zz = torch.abs(tran) + (10 ** -10)
+    size = atp.shape[2:4]
+    atp = F.interpolate(F.leaky_relu(F.avg_pool2d(atp, atp.shape[2]), 0.2), size=size, mode="nearest")
+    dehaze2 = (x - atp) / zz + atp
+    d = torch.cat([dehaze2, x], 1)
+    d = F.leaky_relu(F.conv2d(d, sd["refine1.weight"], sd["refine1.bias"], 1, 1), 0.2)
+    d = F.leaky_relu(F.conv2d(d, sd["refine2.weight"], sd["refine2.bias"], 1, 1), 0.2)
+    pyr = []
+    for k, nm in ((32, "conv1010"), (16, "conv1020"), (8, "conv1030"), (4, "conv1040")):
+        p = F.conv2d(F.avg_pool2d(d, k), sd[nm + ".weight"], sd[nm + ".bias"])
+        pyr.append(F.interpolate(F.leaky_relu(p, 0.2), size=size, mode="nearest"))
+    out = torch.tanh(F.conv2d(torch.cat(pyr + [d], 1), sd["refine3.weight"], sd["refine3.bias"], 1, 1))
+    return out, tran, atp, dehaze2, used

@@ -237,6 +237,34 @@ def main():
         np.savez_compressed(os.path.join(OUT, "legacy_%s_2x128.npz" % nm), **outs)
         man["legacy_%s_keys" % nm] = len(sd0)
 
+    # ---------------- legacy `dehaze` (dehaze22.py:662-753): Dense + G2 + the scattering model, 2x3x256x256 ----------------
+    net = r22.dehaze(3, 3, 64)
+    fill_state_dict(net, seed=8)
+    with torch.no_grad():       # transmission bounded away from zero (J divides by |t|), final tanh unsaturated
+        net.tran_dense.refine3.weight.mul_(0.05), net.tran_dense.refine3.bias.fill_(1.0), net.refine3.weight.mul_(0.02)
+    sd0 = {kk: vv.clone() for kk, vv in net.state_dict().items()}
+    xh = det_input((2, 3, 256, 256), seed=41)
+    outs = {}
+    for mode in (False, True):
+        with torch.no_grad():
+            for kk, vv in net.state_dict().items():     # load_state_dict cannot resolve the dotted child names
+                vv.copy_(sd0[kk])
+        net.train(mode)
+        sdm = {kk: vv.clone() for kk, vv in sd0.items()}
+        with torch.no_grad():
+            torch.manual_seed(3)
+            yr = net(xh.clone())
+            torch.manual_seed(3)
+            yo = legacy_ref.dehaze_forward(sdm, xh.clone(), mode)
+        tag = "train" if mode else "eval"
+        man["ref_vs_oracle_maxabs"]["legacy_dehaze_" + tag] = max(float((a - b).abs().max()) for a, b in zip(yr, yo[:4]))
+        for nm_, t_ in zip(("dehaze", "tran", "atp", "dehaze2"), yr):
+            outs[nm_ + "_" + tag] = t_.numpy()[:, :, ::8, ::8]
+        if mode:
+            outs["masks"] = torch.stack(yo[4]).numpy()
+    np.savez_compressed(os.path.join(OUT, "legacy_dehaze_2x256.npz"), **outs)
+    man["legacy_dehaze_keys"] = len(sd0)
+
     # ---------------- VGG16 features, 1x3x32x32 ----------------
     ov, rv = OVgg(), RVgg()
     fill_state_dict(ov, seed=0)

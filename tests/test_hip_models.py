@@ -307,8 +307,7 @@ def test_dehaze22_d_matches_golden(golden_dir):
     _report("dehaze22_d", rep)
     assert rep["max_abs"] < 2e-2 and rep["rel_rms"] < 2e-2, rep
     assert rep["eval_256_max_abs"] < 2e-2, rep
-    with pytest.raises(NotImplementedError):
-        net22.G(3, 3, 64)
+    assert list(net22.D_tran(6, 64).state_dict().keys()) == list(od2.state_dict().keys())    # dehaze22.py:159-201: the same network
 
 
 def test_fdgan_full_size_properties(nets):
@@ -1150,3 +1149,39 @@ def test_legacy_dense_matches_oracle_and_golden(golden_dir, nm, mod, cls, tail):
     _report("legacy_" + nm, rep)
     assert rep["eval_psnr_vs_oracle"] > 35.0 and rep["train_psnr_vs_oracle"] > 35.0, rep
     assert max(v for k, v in rep.items() if k.startswith("running_")) < 2e-2, rep
+
+
+def test_legacy_dehaze_matches_oracle_and_golden(golden_dir):
+    """models.dehaze22.dehaze (dehaze22.py:662-753) -- Dense + G2 + the scattering-model kernel + the
+    refinement tail -- against the fp32 oracle (0.0 from the real reference) and the reference's own four outputs, eval and
+    train mode (train: with the Dropout2d masks the reference drew).  The fixture keeps |t| >= 0.5: J divides by it."""
+    import models.dehaze22 as net22
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = net22.dehaze(3, 3, 64)
+    fill_state_dict(net, seed=8)
+    with torch.no_grad():
+        net.tran_dense.refine3.weight.mul_(0.05), net.tran_dense.refine3.bias.fill_(1.0), net.refine3.weight.mul_(0.02)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = det_input((2, 3, 256, 256), seed=41)
+    g = np.load(os.path.join(golden_dir, "legacy_dehaze_2x256.npz"))
+    rep = {}
+    for mode in (False, True):
+        net.load_state_dict(sd)
+        net.train(mode)
+        tag = "train" if mode else "eval"
+        masks = list(torch.from_numpy(g["masks"])) if mode else None
+        if mode:
+            net.atp_est.__dict__["_forced_dropout_masks"] = [m.to(DEV) for m in masks]
+        with torch.no_grad():
+            ys = [t.cpu() for t in net(x.to(DEV))]
+            yo = legacy_ref.dehaze_forward({k: v.clone() for k, v in sd.items()}, x.clone(), mode, masks)
+        assert len(ys) == 4 and all(t.shape == (2, 3, 256, 256) for t in ys)
+        for nm, a, b in zip(("dehaze", "tran", "atp", "dehaze2"), ys, yo[:4]):
+            rep["%s_%s_rel_rms_vs_oracle" % (tag, nm)] = rel_rms(a, b)
+            rep["%s_%s_max_abs_vs_reference" % (tag, nm)] = float((a[:, :, ::8, ::8] - torch.from_numpy(g[nm + "_" + tag])).abs().max())
+    _report("legacy_dehaze", rep)
+    for tag in ("eval", "train"):
+        assert rep[tag + "_tran_rel_rms_vs_oracle"] < 2e-2 and rep[tag + "_atp_rel_rms_vs_oracle"] < 2e-2, rep
+        assert rep[tag + "_dehaze2_rel_rms_vs_oracle"] < 4e-2 and rep[tag + "_dehaze_rel_rms_vs_oracle"] < 6e-2, rep

@@ -321,3 +321,24 @@ def test_densenet_stem_as_space_to_depth_convolution():
     xs[:, :12, 2:12, 2:16] = F.pixel_unshuffle(x, 2)
     out = F.conv2d(xs, w4)
     assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-4
+
+
+def test_legacy_dehaze_matches_golden(golden_dir, manifest):
+    """oracle/legacy_ref.dehaze_forward (dehaze22.py:662-753) against the four outputs of the REAL reference, eval mode (the
+    train-mode pass, 0.0 from the reference as well, is left to the manifest: it costs another 20 s of CPU)."""
+    from oracle import legacy_ref
+    import models.dehaze22 as net22
+    assert manifest["ref_vs_oracle_maxabs"]["legacy_dehaze_eval"] == 0.0 and manifest["ref_vs_oracle_maxabs"]["legacy_dehaze_train"] == 0.0
+    net = net22.dehaze(3, 3, 64)
+    assert len(net.state_dict()) == manifest["legacy_dehaze_keys"]
+    fill_state_dict(net, seed=8)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["tran_dense.refine3.weight"] *= 0.05
+    sd["tran_dense.refine3.bias"].fill_(1.0)
+    sd["refine3.weight"] *= 0.02
+    x = det_input((2, 3, 256, 256), seed=41)
+    g = _load(golden_dir, "legacy_dehaze_2x256.npz")
+    with torch.no_grad():
+        yo = legacy_ref.dehaze_forward(sd, x.clone(), False)
+    for nm, t in zip(("dehaze", "tran", "atp", "dehaze2"), yo[:4]):
+        assert float((t[:, :, ::8, ::8] - torch.from_numpy(g[nm + "_eval"])).abs().max()) < 1e-4, nm
