@@ -549,6 +549,220 @@ __global__ __launch_bounds__(512) void conv_wgrad_r3_kernel(WgradRowsArgs a) {
       for (int r = 0; r < 4; ++r) blk[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
 }
 
+// ---- the same scheme for the Fusion-discriminator's MFMA-bound 4x4 (stride 1, pad 1, Cin = 144, /root/reference/models/
+// dehaze1113.py:214): 16 taps, so one B fragment feeds 4 filter rows x 2 cout tiles = 8 MFMAs and the dy fragments of FOUR
+// output rows rotate through registers (6 fragment reads per 32 MFMAs; the first kernel: 10 per 16, two filter rows per
+// workgroup, every input row staged 18 times).  Workgroup = 3 waves = one 48-channel slice of Cin (144 = 3 slices, no
+// padding), 32-pixel column blocks (the 128 accumulator registers of 16 taps leave room for one 32-pixel half only), two
+// workgroups per CU.  Rings of 4 (input rows raw, dy rows), 4 steps unrolled.  dy pixels past the last output column are
+// never fetched: their LDS bytes keep the zeros written once.
+constexpr int R4_PX = 32, R4_XPIX = 35;                   // output pixels per block, staged input pixels
+constexpr int R4_RAW_B = 3456;                            // raw row: 35 px x 96 B = 3360, rounded up to whole 1 KiB DMA pieces + tail
+constexpr int R4_X_B = R4_XPIX * 96 + (R4_XPIX / 8 + 1) * 128;   // transformed row in the odd-tile layout of G3Cfg<.,.,3>
+constexpr int R4_D_B = R4_PX * 64;
+constexpr int R4_LDS = 4 * R4_RAW_B + 2 * R4_X_B + 4 * R4_D_B + 512 + 192 * 32;
+#define R4_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory")
+
+template <bool RELU>
+__global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) {
+  using C = G3Cfg<4, 2, 3>;       // only its layout function xoff() (odd number of tiles: shifted blocks)
+  extern __shared__ __attribute__((aligned(16))) char g3_lds[];
+  char* Raw = g3_lds;                               // 4 raw rows, linear: unit u = pixel u / 6, 8-channel chunk u % 6
+  char* Xs = Raw + 4 * R4_RAW_B;                    // 2 transformed rows
+  char* Ds = Xs + 2 * R4_X_B;                       // 4 dy rows in fragment layout
+  float* sc_s = reinterpret_cast<float*>(Ds + 4 * R4_D_B);
+  float* sh_s = sc_s + 48;
+  // per-thread loop invariants used once per step, as [value][thread] (one record per thread was a 16-way bank conflict per read)
+  unsigned* invb = reinterpret_cast<unsigned*>(Ds + 4 * R4_D_B + 512) + threadIdx.x;
+#define inv(k) invb[(k) * 192]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci0 = blockIdx.x * 48, co0 = (int)blockIdx.z * 32;
+  const int item = blockIdx.y;
+  const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
+  const int y_begin = seg * a.seg_rows, y_end = min(a.Ho, y_begin + a.seg_rows);
+  const int nsteps = y_end - y_begin + 3;          // input rows y_begin - 1 .. y_end + 1
+  const int r0 = y_begin - a.pad, xbase = xb * R4_PX;
+  if (tid < 48) {
+    const int c = ci0 + tid;
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      const float g = a.p_gamma ? a.p_gamma[c] : 1.f, b = a.p_beta ? a.p_beta[c] : 0.f;
+      sc = g / sqrtf(a.p_var[c] + a.eps);
+      sh = b - a.p_mean[c] * sc;
+    }
+    sc_s[tid] = sc;
+    sh_s[tid] = sh;
+  }
+  for (int i = tid; i < 4 * R4_D_B / 16; i += 192) lds_write16(Ds + i * 16, u32x4{0u, 0u, 0u, 0u});   // never-fetched dy pixels stay zero
+  __syncthreads();
+  const float slope = a.pro_mode == 0 ? 1.f : a.p_slope;
+  // units: thread -> input pixel tid / 6 (0 .. 31), chunk tid % 6; pixels 32 .. 34 are threads 0-17's second unit
+  const int xchunk = tid % 6, xpix0 = tid / 6;
+  // scale / shift of the thread's 8 channels stay in LDS (two floats of each per transformed dword): 16 resident registers
+  // more made hipcc spill pointers, and a scratch reload drains the DMA queue
+  const float* scp = sc_s + xchunk * 8;
+  const float* shp = sh_s + xchunk * 8;
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0;
+  // the main unit's addresses stay in registers; the tail unit's and the DMA source offsets are read back from LDS where they
+  // are used (once per step each): in registers they were what hipcc spilled, and a scratch reload is a vmcnt(0)
+  char* xwp0;
+  unsigned xcol0;
+  {
+    const int px = xbase - a.pad + xpix0;
+    xwp0 = Xs + C::xoff(xpix0, xchunk >> 1) + ((xchunk & 1) << 4);
+    xcol0 = px >= 0 && px < a.W ? 0xffffffffu : 0u;
+    const int pix1 = min(xpix0 + 32, R4_XPIX - 1), px1 = xbase - a.pad + xpix0 + 32;
+    inv(0) = (unsigned)(C::xoff(pix1, xchunk >> 1) + ((xchunk & 1) << 4));                       // tail unit: offset in a transformed slot
+    inv(1) = px1 >= 0 && px1 < a.W ? 0xffffffffu : 0u;                                            //            column mask
+    inv(2) = 2u * (unsigned)(min(max(px, 0), a.W - 1) * a.x_sw + xchunk * 8);                     // DMA source offsets (bytes)
+    inv(3) = 2u * (unsigned)(min(max(px1, 0), a.W - 1) * a.x_sw + xchunk * 8);
+  }
+  const bool tail_t = tid < 18;
+  // dy row: waves 1, 2; lane l of wave w fetches position q = 64 (w - 1) + l of the row's fragment layout
+  const int dq = ((wave + 1) & 1) * 64 + lane, dpix = dq >> 2;          // wave 1 -> 0 .. 63, wave 2 -> 64 .. 127
+  const bool d_lane = xbase + dpix < a.Wo;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + co0;
+  inv(4) = 2u * (unsigned)(min(xbase + dpix, a.Wo - 1) * a.dy_sw + ((((dq >> 1) & 1) ^ ((dpix >> 3) & 1)) << 4) + ((dq & 1) << 3));
+  char* dump = reinterpret_cast<char*>(sc_s) + 384;      // 128 bytes behind the 96 floats of scale / shift
+  // group m: input row r0 + m and dy row y_begin + m; exactly two DMA instructions per wave (wave 0: 64 units + the 18-unit
+  // tail, waves 1 and 2: 64 units + half a dy row)
+  auto request = [&](int m, auto SLOT) __attribute__((always_inline)) {
+    constexpr int sl = decltype(SLOT)::value;
+    const unsigned short* rp = ximg + (long long)min(max(r0 + m, 0), a.H - 1) * a.x_sh;
+    const unsigned xsrc0 = inv(2);
+    r3_dma16(rp, xsrc0, Raw + sl * R4_RAW_B + wave * 1024);
+    if (wave == 0) {
+      if (lane < 18) r3_dma16(rp, inv(3), Raw + sl * R4_RAW_B + 3072);
+    } else {
+      char* dslot = Ds + sl * R4_D_B + (wave - 1) * 1024;
+      if (y_begin + m < y_end) {
+        if (d_lane) r3_dma16(dimg + (long long)(y_begin + m) * a.dy_sh, inv(4), dslot);
+      } else {
+        if (lane == 0) r3_dma16(rp, xsrc0, dump + wave * 16);
+        unsigned z;      // materialised here: hoisted out of the loop, the four zero registers were spilled and reloaded every step
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        lds_write16(dslot + lane * 16, u32x4{z, z, z, z});
+      }
+    }
+  };
+  auto rowmask = [&](int m) __attribute__((always_inline)) -> unsigned {
+    const int row = r0 + m;
+    return m < nsteps && row >= 0 && row < a.H ? 0xffffffffu : 0u;
+  };
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  f2_t sv = *reinterpret_cast<const f2_t*>(scp), hv = *reinterpret_cast<const f2_t*>(shp);   // the pair of the next dword to transform,
+                                                                                            // read one MFMA block ahead (wraps to dword 0)
+  auto xf = [&](u32x4& v, int q, unsigned m) __attribute__((always_inline)) {
+    const f2_t sv = *reinterpret_cast<const f2_t*>(scp + 2 * q), hv = *reinterpret_cast<const f2_t*>(shp + 2 * q);
+    v[q] = r3_xform2<RELU>(v[q], sv[0], sv[1], hv[0], hv[1], slope, m);
+  };
+  auto xform_tail = [&](unsigned rm, auto RS, auto XS) __attribute__((always_inline)) {   // pixels 32 .. 34: threads 0-17
+    if (tail_t) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(Raw + decltype(RS)::value * R4_RAW_B + 3072 + tid * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xf(v, q, rm & inv(1));
+      lds_write16(Xs + inv(0) + decltype(XS)::value * R4_X_B, v);
+    }
+  };
+  const int g = lane >> 4, i = lane & 15;
+  const int kpix = 8 * g + (i >> 2), piece = (i & 3) * 8;
+  const char *bp[4][2], *ap[2][2];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx) {
+    bp[kx][0] = Xs + C::xoff(kpix + kx, wave) + piece;
+    bp[kx][1] = Xs + C::xoff(kpix + kx + 4, wave) + piece;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    ap[ct][0] = Ds + g3_doff(kpix, ct) + piece;
+    ap[ct][1] = Ds + g3_doff(kpix + 4, ct) + piece;
+  }
+  const char* rawp = Raw + tid * 16;
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 A[4][2], B[4];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bf16x8 zfrag = __builtin_bit_cast(bf16x8, zero4);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) A[s][0] = A[s][1] = zfrag;
+
+  request(0, IC<0>{});
+  request(1, IC<1>{});
+  request(2, IC<2>{});
+  request(3, IC<3>{});
+  r3_wait_vm<4>();       // groups 0 and 1 have landed (two instructions per group and wave)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned rm = rowmask(j);
+    u32x4 v = *reinterpret_cast<const u32x4*>(rawp + j * R4_RAW_B);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xf(v, q, rm & xcol0);
+    lds_write16(xwp0 + j * R4_X_B, v);
+    if (j == 0) xform_tail(rm, IC<0>{}, IC<0>{}); else xform_tail(rm, IC<1>{}, IC<1>{});
+  }
+  R3_BARRIER();
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx) B[kx] = g3_frag(bp[kx][0], bp[kx][1]);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) A[0][ct] = g3_frag(ap[ct][0], ap[ct][1]);
+
+  // step j (phase P = j mod 4): MFMAs of input row j; dy row j - ky is in A[(j - ky) mod 4]
+  auto step = [&](int j, auto P) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value, p2 = p & 1;
+    constexpr int xn = (p2 ^ 1) * R4_X_B, dn = ((p + 1) & 3) * R4_D_B, xw = p2 * R4_X_B, rw = ((p + 2) & 3) * R4_RAW_B;
+    const unsigned rm = rowmask(j + 2);
+    r3_wait_vm<2>();                                   // group j + 2 has landed (this wave's part)
+    u32x4 u = *reinterpret_cast<const u32x4*>(rawp + rw);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const f2_t svn = *reinterpret_cast<const f2_t*>(scp + 2 * ((kx + 1) & 3)), hvn = *reinterpret_cast<const f2_t*>(shp + 2 * ((kx + 1) & 3));
+#pragma unroll
+      for (int ky = 3; ky >= 0; --ky) {
+        const int s = (p + 4 - ky) & 3;
+        acc[ky * 4 + kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], B[kx], acc[ky * 4 + kx][0], 0, 0, 0);
+        acc[ky * 4 + kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], B[kx], acc[ky * 4 + kx][1], 0, 0, 0);
+      }
+      B[kx] = g3_frag(bp[kx][0] + xn, bp[kx][1] + xn);
+      u[kx] = r3_xform2<RELU>(u[kx], sv[0], sv[1], hv[0], hv[1], slope, rm & xcol0);
+      sv = svn, hv = hvn;
+      if (kx == 3) {
+        lds_write16(xwp0 + xw, u);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) A[(p + 1) & 3][ct] = g3_frag(ap[ct][0] + dn, ap[ct][1] + dn);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kx == 2) {   // before the last block: its refills stay the youngest LDS operations of the step
+        xform_tail(rm, IC<(p + 2) & 3>{}, IC<p2>{});
+        request(j + 4, IC<p>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    R4_STEP_BARRIER();
+  };
+  for (int j = 0; j < nsteps; j += 4) {
+    step(j, IC<0>{});
+    step(j + 1, IC<1>{});
+    step(j + 2, IC<2>{});
+    step(j + 3, IC<3>{});
+  }
+  r3_wait_vm<0>();
+  float* blk = a.part + ((((long long)item * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 3 + wave) * (16 * 512) + lane;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
+}
+#undef inv
+
 // sum over items of the accumulator-order partials -> dw[co][ci][tap] (+= when accumulate): 64 partial-sum columns x 4
 // item lanes per workgroup, fixed summation order.  D layout of the MFMA: lane & 15 = cin, (lane >> 4) * 4 + r = cout.
 struct TrRedArgs {
@@ -682,6 +896,36 @@ int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
 }
 
+template <bool RELU>
+int r4_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, int accumulate, hipStream_t stream,
+              const char* name) {
+  a.xblocks = (a.Wo + R4_PX - 1) / R4_PX;
+  const long long strips = nimg * a.xblocks, ci_tiles = a.Cin / 48, zt = a.Cout / 32;
+  const long long item_stride = ci_tiles * zt * 3 * 16 * 512;
+  if (strips * item_stride > workspace_floats || strips >= 65536) return 1;
+  const long long base = strips * ci_tiles * zt;
+  long long segs = 512 / base;                                   // two resident workgroups per CU
+  if (segs < 1) segs = 1;
+  if (segs > (a.Ho + 7) / 8) segs = (a.Ho + 7) / 8;              // three of a segment's steps see only part of its rows
+  while (segs > 1 && (strips * segs * item_stride > workspace_floats || strips * segs >= 65536)) --segs;
+  a.seg_rows = (int)((a.Ho + segs - 1) / segs);
+  a.segs = (int)((a.Ho + a.seg_rows - 1) / a.seg_rows);
+  a.part = workspace;
+  a.bias_part = nullptr;
+  a.dbg_skip = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_r4_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(%s): %s", name, hipGetErrorString(e));
+    attr_done = true;
+  }
+  const long long items = strips * a.segs;
+  if (int rc = fd_launch(&conv_wgrad_r4_kernel<RELU>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(192), R4_LDS, a, stream))
+    return rc;
+  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 4, 4, 3, 16, a.Cin, a.Cout, accumulate};
+  return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
+}
+
 }  // namespace
 
 // Which instantiation covers a stride-1 conv (0: none, the caller uses the per-tap kernel).  3x3 pad 1: 8, 5 or 3 cin
@@ -736,7 +980,16 @@ int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* w
     }
     case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5");
     case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3");
-    case 9: return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr");
+    case 9: {
+      static const char* r4 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R4");   // tuning aid: '0' first-generation kernel
+      if (dbias == nullptr && a.Cin % 48 == 0 && a.Cout % 32 == 0 && a.pad == 1 && a.Wo == a.W - 1 && a.Ho == a.H - 1 && !(r4 && r4[0] == '0')) {
+        int rc;
+        if (a.pro_mode != 0 && a.p_slope == 0.f) rc = r4_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4");
+        else rc = r4_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4");
+        if (rc != 1) return rc;      // 1: the workspace cannot hold this kernel's partials -- the first-generation kernel may still fit
+      }
+      return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr");
+    }
   }
   FD_FAIL(FD_EINVAL, "conv_wgrad_tr_launch: variant %d", variant);
 }

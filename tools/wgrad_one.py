@@ -13,7 +13,8 @@ ho = hw + 2 * pad - ks + 1
 dy = torch.randn(N, ho, ho, cout, device=dev).bfloat16()
 xv, dv = E.View(x, 0, cin), E.View(dy, 0, cout)
 mean = 0.1 * torch.randn(cin, device=dev); var = 0.5 + torch.rand(cin, device=dev); gamma = 1 + 0.1 * torch.randn(cin, device=dev); beta = 0.1 * torch.randn(cin, device=dev)
-pro = E.make_prologue(mean=mean, var=var, gamma=gamma, beta=beta, act=1)
+ACT = int(os.environ.get('ACT', '1'))     # 1 ReLU, 2 LeakyReLU(0.2)
+pro = E.make_prologue(mean=mean, var=var, gamma=gamma, beta=beta, act=ACT)
 desc = L.FdConvDesc(ks, 1, pad, 0, 0, cout, 0)
 dw = torch.zeros(cout, cin, ks, ks, device=dev)
 ws = torch.empty(64 << 20, device=dev)
@@ -28,7 +29,8 @@ t = e0.elapsed_time(e1) / 10 * 1e3
 fl = 2.0 * N * ho * ho * cin * cout * ks * ks
 # reference: a = relu(bn(x)) rounded to bf16 as the kernel stages it, dW by autograd in fp32 on the GPU
 sc = gamma / torch.sqrt(var + 1e-5); sh = beta - mean * sc
-a = torch.relu(x[..., :cin].float() * sc + sh).bfloat16().float().permute(0, 3, 1, 2)
+pre = x[..., :cin].float() * sc + sh
+a = (torch.relu(pre) if ACT == 1 else torch.nn.functional.leaky_relu(pre, 0.2)).bfloat16().float().permute(0, 3, 1, 2)
 w = torch.zeros(cout, cin, ks, ks, device=dev, requires_grad=True)
 y = torch.nn.functional.conv2d(a, w, padding=pad)
 y.backward(dy.float().permute(0, 3, 1, 2))
