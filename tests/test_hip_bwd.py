@@ -167,7 +167,9 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     (1, 0, 96, 128, "relu", (2, 16, 24)), (1, 0, 224, 128, "relu", (1, 8, 64)), (1, 0, 40, 64, "leaky", (2, 8, 8)),
     (1, 0, 992, 128, "relu", (1, 8, 8)), (3, 1, 128, 32, "relu", (3, 80, 96)),
     # the growth conv's data gradient (32 -> 128): row-streaming kernel (conv3x3_bwd.hip); ragged width, short images
-    (3, 1, 128, 32, "relu", (2, 5, 70)), (3, 1, 128, 32, "leaky", (1, 33, 64))])
+    (3, 1, 128, 32, "relu", (2, 5, 70)), (3, 1, 128, 32, "leaky", (1, 33, 64)),
+    # second-generation kernel (widths that are multiples of 64): several column blocks and row segments, rows % 4 in {0, 1, 2}
+    (3, 1, 128, 32, "relu", (2, 64, 128)), (3, 1, 128, 32, "relu", (1, 42, 256)), (3, 1, 128, 32, "leaky", (3, 17, 64))])
 def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     """fdgan_conv2d_bwd_data: conv^T(dy, W) * act'(bn(x)) stored by the data-gradient kernel itself, with the raw
     moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
@@ -326,7 +328,10 @@ def test_gradient_plumbing_kernels(E):
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 32, 21, 40), (2, 256, 24, 9, 132), (1, 64, 32, 64, 64), (2, 128, 32, 5, 8),
                                              (2, 256, 32, 9, 132), (1, 128, 32, 70, 64), (1, 128, 32, 3, 100),
-                                             (1, 72, 144, 20, 70), (2, 36, 72, 9, 33), (1, 160, 128, 8, 64), (1, 640, 40, 6, 32)])
+                                             (1, 72, 144, 20, 70), (2, 36, 72, 9, 33), (1, 160, 128, 8, 64), (1, 640, 40, 6, 32),
+                                             # row-walking kernel (conv_wgrad_r3: W % 64 == 0, Cin % 128 == 0, Cout % 32 == 0):
+                                             # several column blocks / row segments / cin slices / cout pairs, odd row counts
+                                             (2, 128, 32, 64, 128), (1, 128, 32, 37, 256), (1, 256, 64, 19, 64), (3, 128, 32, 2, 64)])
 def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     """conv_wgrad3x3_tr (32 filters, Cin % 128 == 0: transpose-read kernel) and conv_wgrad3x3 (Cout <= 32,
     Cin % 32 == 0), the growth-conv shape 3x3 s1 p1: ragged column blocks, several
@@ -360,7 +365,8 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     assert rel_rms(db_acc.cpu().double() + 2.0, dy.double().sum(dim=(0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 144, 64, 13, 70), (1, 144, 288, 6, 131), (1, 288, 32, 9, 20), (2, 288, 1, 12, 67)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 144, 64, 13, 70), (1, 144, 288, 6, 131), (1, 288, 32, 9, 20), (2, 288, 1, 12, 67),
+                                             (1, 144, 288, 64, 64), (3, 144, 32, 5, 33), (1, 48, 32, 130, 128)])   # + row-walking kernel shapes
 def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     """conv_wgrad4x4_tr (the Fusion-discriminator's 4x4 stride-1 pad-1 conv behind BatchNorm + LeakyReLU(0.2),
     /root/reference/models/dehaze1113.py:200-207): ragged column blocks, rows outside the image, two cin slices."""
