@@ -27,6 +27,7 @@ names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_
          "conv3x3_bwd_kernel": ("conv3x3_bwd_stream", "train_B16_256"),
          "conv3x3_bwd2_kernel": ("conv3x3_bwd_stream2", "train_B16_256"),
          "conv_wgrad_r3_kernel": ("conv_wgrad3x3_r3", "train_B16_256"),
+         "conv_wgrad_r4_kernel": ("conv_wgrad4x4_r4", "train_B16_256"),
          "affine_acc_kernel": ("affine_accumulate", "train_B16_256"),
          "conv_wgrad1x1_tr_kernel": ("conv_wgrad1x1_tr", "train_B16_256"),
          "conv_wgrad_tr_kernel<3, 3, 8>": ("conv_wgrad3x3_tr8", "train_B16_256"),
