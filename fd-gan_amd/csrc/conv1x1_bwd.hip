@@ -210,6 +210,256 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
   }
 }
 
+// ---- the FUSED form (Cy == 128): data gradient AND weight gradient of the bottleneck in one pass.
+// The weight gradient dW[co][ci] = sum_p dy[p][co] * act(bn(x))[p][ci] needs exactly what the data-gradient kernel has on chip
+// for a pixel tile -- the dy tile in LDS and act(bn(x)) in the row phase's registers -- so the workgroup that owns a
+// 128-channel tile also accumulates its [128 co][128 ci] slice of dW over all its pixel tiles, and conv_wgrad1x1_tr's separate
+// pass over dy and x (P (C + 128) 2 bytes of reads, a quarter of the pair's HBM traffic) disappears.
+// Workgroup = 8 waves, one per CU (the 64 extra accumulator registers of a 4-wave workgroup did not fit beside the two x / G
+// register sets): wave (w & 3, w >> 2) = (16-pixel quarter, 64-channel half).
+//   data gradient     16 pixels x 64 channels per wave (4 accumulator tiles); row phase: a lane owns 8 channels of 2 pixels
+//   weight gradient   wave (w & 1, w >> 1) owns 4 cout tiles x 2 cin tiles (8 accumulator tiles), operands by transpose reads
+//                     from the dy tile and the activated tile (both [pixel][256 B], conv_wgrad1x1_tr's swizzle: conflict-free
+//                     for those reads and for the data gradient's 16-byte B fragments)
+// ONE barrier per 64-pixel step: the dy tile is triple-, the activated tile double-buffered, and the weight gradient of tile
+// t - 1 is issued in step t, right before the row phase -- its 16 MFMAs run in the matrix pipe while the row phase's VALU work
+// issues (first version: single buffers, three barriers, weight gradient after the row phase: 134 us per launch for work the
+// data-gradient kernel alone did in 104).
+constexpr int F1_TBP = 64 * 2 + 16;              // transposition pitch of one pixel (64 channels)
+constexpr int F1_TB = 16 * F1_TBP;               // per wave
+constexpr int F1_TILE = B1_PX * 256;             // a [64 px][128 ch] bf16 tile
+constexpr int F1_LDS = 3 * F1_TILE + 4 * 8 * 1024 + 8 * F1_TB + 2 * F1_TILE;   // dy tiles, filter, transposition, activated tiles
+
+typedef short f1_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 f1_trfrag(const char* p0, const char* p1) {
+  const f1_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f1_s16x4*)(p0));
+  const f1_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f1_s16x4*)(p1));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ int f1_off(int pix, int c16g) {   // 32-byte (16-channel) group c16g of pixel pix in a [pixel][256 B] tile
+  return pix * 256 + ((c16g ^ ((pix & 3) | (((pix >> 3) & 1) << 2))) << 5);
+}
+
+struct Bwdw1Args {
+  Bwd1Args b;
+  float* wpart;               // [pixel slots][128 filters][C] partial weight gradients
+};
+
+__global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
+  const Bwd1Args& a = aa.b;
+  extern __shared__ __attribute__((aligned(16))) char b1_lds[];
+  char* dyt0 = b1_lds;                                        // 3 x [64 px][256 B]: tile t lives in t mod 3
+  char* wt = dyt0 + 3 * F1_TILE;                              // [4 k chunks][8 tiles][1 KB] A fragments of this channel tile
+  char* tb0 = wt + 4 * 8 * 1024;                              // 8 x transposition areas
+  char* at0 = tb0 + 8 * F1_TB;                                // 2 x activated tile [64 px][256 B]: tile t lives in t mod 2
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kgl = lane >> 4;
+  const int pq = wave & 3, chh = wave >> 2;                   // 16-pixel quarter, 64-channel half
+  char* tb = tb0 + wave * F1_TB;
+  int item = blockIdx.x;
+  {
+    const int per_xcd = gridDim.x >> 3;
+    if (item < per_xcd * 8) item = (item & 7) * per_xcd + (item >> 3);
+  }
+  const int ct = item % a.nct, slot = item / a.nct, nslots = (int)gridDim.x / a.nct;
+  const int c0 = ct * B1_CT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  // row phase: lane -> 8-channel piece lane & 7 of the wave's 64 channels, pixels lane >> 3 and 8 + (lane >> 3) of its 16
+  const int piece = lane & 7, ql0 = lane >> 3;
+  const int cg = c0 + chh * 64 + piece * 8;
+  const bool ch_ok = cg < a.C;
+  float sc8[8], sh8[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cg + e;
+    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
+    if (a.mode == 2 && c < a.C) {
+      const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
+      sh8[e] = bt - a.mean[c] * sc8[e];
+    }
+  }
+  for (int f = tid; f < 4 * 512; f += 512) {                  // this channel tile's filter fragments: once
+    const int kc = f >> 9, t8 = (f >> 6) & 7, ln = f & 63;
+    const int tile16 = ct * 8 + t8;
+    lds_write16(wt + f * 16, tile16 < a.ntile_total ? *reinterpret_cast<const u32x4*>(a.w + ((long long)kc * a.ntile_total + tile16) * 512 + ln * 8) : zero4);
+  }
+  const int my_tiles = slot < a.ntiles ? (a.ntiles - slot + nslots - 1) / nslots : 0;
+  // weight-gradient side: lane (g, i) of a transpose read: k rows (pixels) 8 g + (i >> 2) (+ 4), 4-channel piece i & 3
+  const int tg = lane >> 4, ti = lane & 15;
+  const int kpix = 8 * tg + (ti >> 2), piece8 = (ti & 3) * 8;
+  const int wco = (wave & 1) * 4, wci = (wave >> 1) * 2;      // first cout / cin 16-channel tile of this wave
+  f32x4 wacc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) wacc[c][0] = wacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // dy rows (2 units per thread), x / G rows (2 units) of a pixel tile: requested one whole tile ahead, two register sets
+  u32x4 dyr[2];
+  auto request_dy = [&](int tl) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * 512;                            // (pixel u / 16, 16-byte column u % 16)
+      dyr[i] = zero4;
+      if (tl < my_tiles) dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
+    }
+  };
+  auto request = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    const bool live = tl < my_tiles;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long p = p0 + pq * 16 + i * 8 + ql0;
+      xv[i] = gv[i] = zero4;
+      if (live && ch_ok) {
+        xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg);
+        if (a.acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg);
+      }
+    }
+  };
+  // weight gradient of one tile: dW[128 co][128 ci tile] += dy^T (64 px x 128 co) * act (64 px x 128 ci)
+  auto wgrad_tile = [&](const char* dyt, const char* at) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int pa = 32 * sub + kpix;
+      bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) af[c] = f1_trfrag(dyt + f1_off(pa, wco + c) + piece8, dyt + f1_off(pa + 4, wco + c) + piece8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = f1_trfrag(at + f1_off(pa, wci + j) + piece8, at + f1_off(pa + 4, wci + j) + piece8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wacc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf[j], wacc[c][j], 0, 0, 0);
+    }
+  };
+  int d3 = 0;                                                  // tl mod 3
+  auto step = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2]) __attribute__((always_inline)) {
+    const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    char* dyt = dyt0 + d3 * F1_TILE;
+    char* at = at0 + (tl & 1) * F1_TILE;
+    const char* dyp = dyt0 + (d3 == 0 ? 2 : d3 - 1) * F1_TILE;   // the previous tile's
+    const char* atp = at0 + ((tl & 1) ^ 1) * F1_TILE;
+    d3 = d3 == 2 ? 0 : d3 + 1;
+    // no barrier here: slot t mod 3 was last read by the weight gradient of tile t - 3, issued in step t - 2 -- every wave
+    // is past that once it has passed the barrier of step t - 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * 512, q = u >> 4, c16 = u & 15;
+      lds_write16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4), dyr[i]);
+    }
+    B1_BARRIER();                                             // this tile's dy rows and the previous tile's activated rows are in place
+    request_dy(tl + 1);                                       // next tile: in flight during this tile's MFMAs and row phase
+    request(tl + 1, xn, gn);
+    // ---- data gradient MFMA: wave = 16 pixels x 64 channels
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = pq * 16 + m;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int c16 = kc * 4 + kgl;
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 afr = __builtin_bit_cast(bf16x8, lds_read16(wt + ((kc * 8 + chh * 4 + j) * 64 + lane) * 16));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr, acc[j], 0, 0, 0);
+      }
+    }
+    // ---- row phase: transpose through the wave's staging area, mask, sums, G (+)= gamma*rstd*v (or store v); keep act(bn(x))
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){acc[j][0], acc[j][1], acc[j][2], acc[j][3]}, bf16x4_t));
+      *reinterpret_cast<u32x2*>(tb + m * F1_TBP + j * 32 + kgl * 8) = bits;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (tl > 0 && !(a.dbg & 32)) wgrad_tile(dyp, atp);        // its MFMAs execute while the row phase below issues
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ql = i * 8 + ql0;
+      const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, lds_read16(tb + ql * F1_TBP + piece * 16)), f32x8);
+      const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+      f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
+      f32x8 act;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pre = fmaf(fx[e], sc8[e], sh8[e]);
+        const bool in = cg + e < a.C;
+        const float v = in ? da[e] * (pre > 0.f ? 1.f : a.slope) : 0.f;
+        s1[e] += v;
+        s2[e] += v * fx[e];
+        o[e] = a.acc ? fmaf(sc8[e], v, o[e]) : v;
+        act[e] = in ? (pre > 0.f ? pre : a.slope * pre) : 0.f;        // what the forward conv saw
+      }
+      const int pix = pq * 16 + ql, c16 = chh * 8 + piece;            // 16-byte column of the 128-channel tile
+      if (!(a.dbg & 64)) lds_write16(at + f1_off(pix, c16 >> 1) + ((c16 & 1) << 4), __builtin_bit_cast(u32x4, __builtin_convertvector(act, bf16x8)));
+      if (ch_ok) *reinterpret_cast<u32x4*>(a.g + (p0 + pq * 16 + ql) * a.g_pitch + cg) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  u32x4 xa[2], ga[2], xb[2], gb[2];
+  request_dy(0);
+  request(0, xa, ga);
+  for (int tl = 0; tl < my_tiles; tl += 2) {
+    step(tl, xa, ga, xb, gb);
+    if (tl + 1 < my_tiles) step(tl + 1, xb, gb, xa, ga);
+  }
+  B1_BARRIER();                                               // the last tile's activated rows are in place
+  if (my_tiles > 0) wgrad_tile(dyt0 + ((my_tiles - 1) % 3) * F1_TILE, at0 + ((my_tiles - 1) & 1) * F1_TILE);
+  B1_BARRIER();                                               // every wave is through its last fragment reads
+  if (a.partial != nullptr) {   // lanes 8 apart own the same channels; then the four pixel quarters in a fixed order
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int d = 8; d < 64; d <<= 1) {
+        s1[e] += __shfl_xor(s1[e], d, 64);
+        s2[e] += __shfl_xor(s2[e], d, 64);
+      }
+    float* red = reinterpret_cast<float*>(tb0);               // [8 waves][64][2]
+    if (ql0 == 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 64 + piece * 8 + e) * 2] = s1[e];
+        red[(wave * 64 + piece * 8 + e) * 2 + 1] = s2[e];
+      }
+    B1_BARRIER();
+    if (tid < 256) {
+      const int c = tid >> 1, which = tid & 1, h = c >> 6, cl = c & 63;   // channel half h: waves 4 h .. 4 h + 3
+      const float t = (red[((4 * h + 0) * 64 + cl) * 2 + which] + red[((4 * h + 1) * 64 + cl) * 2 + which]) +
+                      (red[((4 * h + 2) * 64 + cl) * 2 + which] + red[((4 * h + 3) * 64 + cl) * 2 + which]);
+      a.partial[((long long)slot * a.nct * B1_CT + c0 + c) * 2 + which] = t;
+    }
+    B1_BARRIER();
+  }
+  // ---- weight-gradient partial: D layout column (lane & 15) = cin, rows (lane >> 4) * 4 + r = cout -> LDS [128][128] fp32 -> rows
+  float* out = reinterpret_cast<float*>(b1_lds);              // 64 KB: dy tile, filter image and transposition areas are dead
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((wco + c) * 16 + tg * 4 + r) * 128 + (wci + j) * 16 + ti] = wacc[c][j][r];
+  __syncthreads();
+  float* dwp = aa.wpart + (long long)slot * 128 * a.C;
+  for (int u = tid; u < 128 * 32; u += 512) {                 // 16-byte pieces of the [128][128] tile
+    const int co = u >> 5, c4 = (u & 31) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(out + co * 128 + c4);
+    float* d = dwp + (long long)co * a.C + c0 + c4;
+    if (c0 + c4 + 4 <= a.C && (a.C & 3) == 0) {
+      *reinterpret_cast<f32x4*>(d) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + c4 + e < a.C) d[e] = v[e];
+    }
+  }
+}
+
 }  // namespace
 
 bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre) {
@@ -226,7 +476,7 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
 /* rows_out / cpad_out: shape of the partial-sum block written when `partial` is given. */
 int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
                        int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
-                       hipStream_t stream) {
+                       hipStream_t stream, float* wpart, long long wpart_floats, long long* wsplit_out) {
   Bwd1Args a{};
   a.dy = static_cast<const unsigned short*>(dy->ptr), a.dy_pitch = (int)dy->stride[2], a.Cy = (int)dy->c;
   a.w = static_cast<const unsigned short*>(w_packed);
@@ -239,7 +489,9 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   a.mode = norm ? 2 : 1, a.acc = accumulate;
   a.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
   if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
-  long long nslots = 512 / a.nct;                              // two resident workgroups per CU in all
+  const bool fused = wpart != nullptr;                         // one 8-wave workgroup per CU instead of two 4-wave ones
+  if (fused && a.Cy != 128) return 1;
+  long long nslots = (fused ? 256 : 512) / a.nct;
   if (nslots < 1) nslots = 1;
   if (nslots > a.ntiles) nslots = a.ntiles;
   const long long grid = nslots * a.nct;
@@ -255,6 +507,18 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_bwd): %s", hipGetErrorString(e));
     attr_done = true;
+  }
+  if (fused) {   // 1: the caller runs the two separate kernels instead
+    if (nslots * 128 * a.C > wpart_floats) return 1;
+    if (wsplit_out) *wsplit_out = nslots;
+    static bool attr_f = false;
+    if (!attr_f) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwdw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_bwdw): %s", hipGetErrorString(e));
+      attr_f = true;
+    }
+    Bwdw1Args aa{a, wpart};
+    return fd_launch(&conv1x1_bwdw_kernel, "conv1x1_bwd_wgrad_stream", dim3((unsigned)grid), dim3(512), F1_LDS, aa, stream);
   }
   return fd_launch(&conv1x1_bwd_kernel, "conv1x1_bwd_stream", dim3((unsigned)grid), dim3(256), lds, a, stream);
 }

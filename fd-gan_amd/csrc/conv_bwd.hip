@@ -448,6 +448,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
   }
 }
 
+}  // namespace
+int fd_wgrad_reduce(const float* part, float* out, long long numel, int nsplit, int accumulate, hipStream_t stream) {
+  WredArgs r{part, out, numel, nsplit, accumulate};
+  return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, stream);
+}
+namespace {
+
 // ------------------------------------------------------------------------------------------
 // prologue backward, pass 1: dpre = da * act'(scale*x + shift) in place (bf16), and per-workgroup
 // partial sums (sum dpre, sum dpre * xhat) per channel for BatchNorm's dbeta / dgamma.

@@ -181,6 +181,33 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
   return FD_OK;
 }
 
+/* Data AND weight gradient of the dense-layer bottleneck (1x1, 128 filters) in one pass over dy and x (include/fdgan_hip.h). */
+extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
+                                             const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
+                                             int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw,
+                                             int dw_accumulate, FdStream stream) {
+  FD_REQUIRE(dy && w_packed_flipped && fwd_x && dpre && wgrad_workspace && dw, "conv1x1_bwd_data_weight: NULL argument");
+  FD_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv1x1_bwd_data_weight: accumulate %d", accumulate);
+  FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv1x1_bwd_data_weight: packed weights must be 16-byte aligned");
+  FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv1x1_bwd_data_weight: pooled prologues are not fused");
+  const int act0 = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
+  FD_REQUIRE(act0 == FD_ACT_NONE || act0 == FD_ACT_RELU || act0 == FD_ACT_LEAKY02, "conv1x1_bwd_data_weight: prologue activation %d", act0);
+  const bool fits = dy->dtype == FD_BF16 && dpre->dtype == FD_BF16 && fwd_x->dtype == FD_BF16 && dy->c == 128 && dy->n == dpre->n &&
+                    dy->h == dpre->h && dy->w == dpre->w && fwd_x->n == dpre->n && fwd_x->h == dpre->h && fwd_x->w == dpre->w &&
+                    fwd_x->c >= dpre->c && conv1x1_bwd_fits(dy, fwd_x, dpre);
+  if (!fits) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_bwd_data_weight: shape outside the fused kernel (use fdgan_conv2d_bwd_data + fdgan_conv2d_bwd_weight)");
+  FD_REQUIRE(!(fwd_pro && fwd_pro->mean) || (fwd_pro->var && partial), "conv1x1_bwd_data_weight: a BatchNorm prologue needs var and the partial-sum workspace");
+  long long rows = 0, cpad = 0, nsplit = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = conv1x1_bwd_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, partial, capacity_floats, &rows, &cpad, st,
+                                    wgrad_workspace, wgrad_workspace_floats, &nsplit);
+  if (rc == 1) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_bwd_data_weight: the weight-gradient workspace cannot hold one partial per pixel slot");
+  if (rc != FD_OK) return rc;
+  if (rows_out) *rows_out = rows;
+  if (cpad_out) *cpad_out = cpad;
+  return fd_wgrad_reduce(wgrad_workspace, dw, 128LL * dpre->c, (int)nsplit, dw_accumulate, st);
+}
+
 /* Data gradient of a stride-1 conv fused with the backward of the conv's input-side prologue (include/fdgan_hip.h). */
 extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x,
                                      const FdPrologue* fwd_pro, const FdTensor* dpre, int accumulate, float* partial,

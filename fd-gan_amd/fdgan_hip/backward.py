@@ -156,6 +156,7 @@ class PlanBackward:
         self.ws_fin = torch.empty(64 * 4096, dtype=torch.float32, device=dev)  # second level of the BatchNorm-sum reduction
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
+        self.fuse_wgrad = os.environ.get("FDGAN_NO_FUSED_WGRAD") is None        # tuning aid: separate 1x1 weight-gradient kernel
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
         # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
@@ -251,7 +252,11 @@ class PlanBackward:
         desc = E.conv_desc(k, r["stride"], pad, cout=w.cout)
         # ---- parameters
         p = w.param
-        if p.requires_grad:
+        # the dense-layer bottleneck (1x1, 128 filters): data and weight gradient in one pass over dy and x (fused below)
+        fuse_w = (self.fuse_wgrad and p.requires_grad and need_dx and self.checks is None and k == 1 and r["stride"] == 1 and
+                  not w.transposed and r["bias"] is None and w.cout == 128 and dy_view.c == 128 and not meta["pool"] and
+                  x.c0 % 8 == 0 and self.fuse_mask and self.defer_affine)
+        if p.requires_grad and not fuse_w:
             if w.transposed:                      # ConvTranspose2d 1x1: weight is (cin, cout, 1, 1)
                 tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
                 E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
@@ -311,8 +316,16 @@ class PlanBackward:
             # them (dense blocks).  dpre is never stored.
             gx = self.G(x)
             store = r.get("_sole", False) and self.checks is None and id(self.gbuf[x.buf.data_ptr()]) in self.nozero
-            rows, cpad = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
-                                         accumulate=2 if store else 1)
+            res = None
+            if fuse_w:
+                res = E.conv1x1_bwd_data_weight(dy_view.fd, pw, x.fd, act_pro, gx.fd, self.ws_bn if bn is not None else None,
+                                                2 if store else 1, self.ws, grad_target(grads, p).view(w.cout, w.cin), True)
+                if res is None:     # outside the fused kernel's shapes: the two separate kernels
+                    E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grad_target(grads, p), None, self.ws, True)
+            if res is None:
+                res = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
+                                      accumulate=2 if store else 1)
+            rows, cpad = res
             if bn is not None:
                 train_bn = bn.weight is not None and bn.weight.requires_grad
                 d = self._deferred(x)

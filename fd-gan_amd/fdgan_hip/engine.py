@@ -411,6 +411,22 @@ def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None, 
     return rows.value, cpad.value
 
 
+def conv1x1_bwd_data_weight(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, ws_bn, accumulate, wgrad_ws, dw, dw_accumulate=True):
+    """The bottleneck's data gradient (as conv_bwd_data) and weight gradient in one pass; returns (rows, cpad), or None when
+    the shape is outside the fused kernel (nothing launched)."""
+    rows, cpad = C.c_int64(0), C.c_int64(0)
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    rc = L.load().fdgan_conv1x1_bwd_data_weight(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
+                                                C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd), int(accumulate),
+                                                ws_bn.data_ptr() if ws_bn is not None else None, ws_bn.numel() if ws_bn is not None else 0,
+                                                C.byref(rows), C.byref(cpad), wgrad_ws.data_ptr(), wgrad_ws.numel(), dw.data_ptr(),
+                                                int(bool(dw_accumulate)), stream_ptr())
+    if rc == L.FD_EUNSUPPORTED:
+        return None
+    L.check(rc, "conv1x1_bwd_data_weight")
+    return rows.value, cpad.value
+
+
 def bn_bwd_coef(dgamma, dbeta, pro, channels, count, bsum, csum):
     """bsum / csum (fp32 views) += this layer's (B, C) of dx = A*dpre + B*x + C."""
     L.check(L.load().fdgan_bn_bwd_coef(dgamma.data_ptr(), dbeta.data_ptr(), C.byref(pro), channels, count, bsum.data_ptr(),

@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FdganLibraryError(RuntimeError):
@@ -136,6 +136,9 @@ SIGNATURES = {
     "fdgan_conv2d_bwd_data": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdPrologue),
                                         C.POINTER(FdTensor), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int64), C.POINTER(FdConvDesc), C.c_void_p]),
+    "fdgan_conv1x1_bwd_data_weight": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdPrologue),
+                                      C.POINTER(FdTensor), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "fdgan_bn_bwd_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FdPrologue), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fdgan_affine_accumulate": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),

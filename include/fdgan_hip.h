@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 4
+#define FDGAN_ABI_VERSION 5
 
 enum FdStatus {
   FD_OK = 0,
@@ -329,6 +329,18 @@ int fdgan_bn_bwd_finalize_coef(const float* partial, int64_t rows, int64_t cpad,
 int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
                           const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                           int64_t* cpad_out, const FdConvDesc* d, FdStream stream);
+
+/* The dense-layer bottleneck (1x1 conv, 128 filters, torchvision _DenseLayer.conv1 behind norm1 / relu1, as used at
+ * /root/reference/models/dehaze1113.py:713-724) backward in ONE pass: fdgan_conv2d_bwd_data's result (same arguments, same
+ * partial sums for BatchNorm) AND the weight gradient dw[128][C] (+= when dw_accumulate) of the same conv, whose operands --
+ * the dy tile and act(bn(x)) -- are on chip anyway.  Saves the weight-gradient kernel's read of dy and x (a quarter of the
+ * pair's HBM traffic).  wgrad_workspace: fp32 scratch for one [128][C] partial per pixel slot (<= 512 / ceil(C / 128)
+ * slots), summed in a fixed order.  dy must have 128 channels, N*H*W a multiple of 64, views dense; FD_EUNSUPPORTED
+ * otherwise (nothing launched: call the two separate entry points). */
+int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
+                                  const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
+                                  int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw, int dw_accumulate,
+                                  FdStream stream);
 /* bsum[c] += B, csum[c] += C of dx = A*dpre + B*x + C for channels [0, channels): B = -gamma*rstd^2*dgamma/count,
  * C = -gamma*rstd*dbeta/count - B*mean (pro: the forward prologue's mean / var / gamma / eps). */
 int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,

@@ -24,6 +24,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
 names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
          "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256"),
          "conv1x1_bwd_kernel": ("conv1x1_bwd_stream", "train_B16_256"),
+         "conv1x1_bwdw_kernel": ("conv1x1_bwd_wgrad_stream", "train_B16_256"),
          "conv3x3_bwd_kernel": ("conv3x3_bwd_stream", "train_B16_256"),
          "conv3x3_bwd2_kernel": ("conv3x3_bwd_stream2", "train_B16_256"),
          "conv_wgrad_r3_kernel": ("conv_wgrad3x3_r3", "train_B16_256"),
