@@ -173,11 +173,12 @@ def _model_conv_bwd_data(args, kw):
 
 def _model_conv1x1_bwd_data_weight(args, kw):
     """fdgan_conv1x1_bwd_data_weight (the dense-layer bottleneck, data + weight gradient in one pass): the data gradient's
-    bytes -- read dy and x, read + write the gradient buffer -- and nothing more: the weight gradient's operands are on chip.
+    bytes -- read dy and x, read + write the gradient buffer -- plus, when the pending BatchNorm remainder of dy is applied on
+    the fly (dy_affine), the 128-channel activation it multiplies; nothing for the weight gradient, whose operands are on chip.
     (Its [128][C] fp32 partial per workgroup, 64 KB against ~3 MB of activations, is left out like every filter.)  Flops of both."""
     dy_fd, fwd_x_fd, dpre_fd, accumulate = args[0], args[2], args[4], args[6]
     px = dpre_fd.n * dpre_fd.h * dpre_fd.w
-    byts = px * dy_fd.c * 2 + px * dpre_fd.c * 2 * (3 if accumulate == 1 else 2)
+    byts = px * dy_fd.c * 2 * (2 if kw.get("dy_affine") is not None else 1) + px * dpre_fd.c * 2 * (3 if accumulate == 1 else 2)
     return "conv1x1_bwd_wgrad_stream", byts, 2 * 2.0 * px * dpre_fd.c * dy_fd.c
 
 

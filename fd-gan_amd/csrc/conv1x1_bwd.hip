@@ -243,6 +243,12 @@ __device__ __forceinline__ int f1_off(int pix, int c16g) {   // 32-byte (16-chan
 struct Bwdw1Args {
   Bwd1Args b;
   float* wpart;               // [pixel slots][128 filters][C] partial weight gradients
+  // pending linear part of the BatchNorm backward of dy's OWN producer (the growth conv's norm2): dy' = dy + cB * yb + cC per
+  // channel, yb = that norm's input (the bottleneck activation).  Applied while the dy tile is staged, so the separate
+  // read-read-write pass over the 128-channel gradient buffer (affine_accumulate) is not needed.  NULL: dy is final.
+  const unsigned short* yb;   // [P][yb_pitch], 128 channels
+  int yb_pitch;
+  const float *cB, *cC;       // [128]
 };
 
 __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
@@ -297,14 +303,24 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   for (int c = 0; c < 4; ++c) wacc[c][0] = wacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // dy rows (2 units per thread), x / G rows (2 units) of a pixel tile: requested one whole tile ahead, two register sets
-  u32x4 dyr[2];
+  u32x4 dyr[2], ybr[2];
+  const bool affine = aa.yb != nullptr;
+  f32x8 cb8, cc8;                                              // the thread's dy column (tid & 15) is the same for both units
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    cb8[e] = affine ? aa.cB[(tid & 15) * 8 + e] : 0.f;
+    cc8[e] = affine ? aa.cC[(tid & 15) * 8 + e] : 0.f;
+  }
   auto request_dy = [&](int tl) __attribute__((always_inline)) {
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + i * 512;                            // (pixel u / 16, 16-byte column u % 16)
-      dyr[i] = zero4;
-      if (tl < my_tiles) dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
+      dyr[i] = ybr[i] = zero4;
+      if (tl < my_tiles) {
+        dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
+        if (affine) ybr[i] = *reinterpret_cast<const u32x4*>(aa.yb + (p0 + (u >> 4)) * aa.yb_pitch + (u & 15) * 8);
+      }
     }
   };
   auto request = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {
@@ -349,7 +365,14 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + i * 512, q = u >> 4, c16 = u & 15;
-      lds_write16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4), dyr[i]);
+      u32x4 v = dyr[i];
+      if (affine) {     // (uniform) dy' = dy + cB * yb + cC, rounded to bf16 exactly as the separate pass stored it
+        f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
+        const f32x8 y8 = __builtin_convertvector(__builtin_bit_cast(bf16x8, ybr[i]), f32x8);
+        f = __builtin_elementwise_fma(cb8, y8, f + cc8);        // packed fp32: 8 instructions
+        v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+      }
+      lds_write16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4), v);
     }
     B1_BARRIER();                                             // this tile's dy rows and the previous tile's activated rows are in place
     request_dy(tl + 1);                                       // next tile: in flight during this tile's MFMAs and row phase
@@ -476,7 +499,8 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
 /* rows_out / cpad_out: shape of the partial-sum block written when `partial` is given. */
 int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
                        int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
-                       hipStream_t stream, float* wpart, long long wpart_floats, long long* wsplit_out) {
+                       hipStream_t stream, float* wpart, long long wpart_floats, long long* wsplit_out, const FdTensor* dy_affine_x,
+                       const float* dy_affine_b, const float* dy_affine_c) {
   Bwd1Args a{};
   a.dy = static_cast<const unsigned short*>(dy->ptr), a.dy_pitch = (int)dy->stride[2], a.Cy = (int)dy->c;
   a.w = static_cast<const unsigned short*>(w_packed);
@@ -517,7 +541,11 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
       if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_bwdw): %s", hipGetErrorString(e));
       attr_f = true;
     }
-    Bwdw1Args aa{a, wpart};
+    Bwdw1Args aa{a, wpart, nullptr, 0, nullptr, nullptr};
+    if (dy_affine_x != nullptr) {
+      aa.yb = static_cast<const unsigned short*>(dy_affine_x->ptr), aa.yb_pitch = (int)dy_affine_x->stride[2];
+      aa.cB = dy_affine_b, aa.cC = dy_affine_c;
+    }
     return fd_launch(&conv1x1_bwdw_kernel, "conv1x1_bwd_wgrad_stream", dim3((unsigned)grid), dim3(512), F1_LDS, aa, stream);
   }
   return fd_launch(&conv1x1_bwd_kernel, "conv1x1_bwd_stream", dim3((unsigned)grid), dim3(256), lds, a, stream);

@@ -918,7 +918,8 @@ struct WgradRowsArgs {
 bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre);
 int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
                        int accumulate, float* partial, long long capacity_floats, long long* rows_out, long long* cpad_out,
-                       hipStream_t stream, float* wpart = nullptr, long long wpart_floats = 0, long long* wsplit_out = nullptr);
+                       hipStream_t stream, float* wpart = nullptr, long long wpart_floats = 0, long long* wsplit_out = nullptr,
+                       const FdTensor* dy_affine_x = nullptr, const float* dy_affine_b = nullptr, const float* dy_affine_c = nullptr);
 // [nsplit][numel] partial weight gradients -> out (+= when accumulate), fixed summation order (conv_bwd.hip)
 int fd_wgrad_reduce(const float* part, float* out, long long numel, int nsplit, int accumulate, hipStream_t stream);
 // row-streaming 3x3 data gradient of the growth conv + prologue backward (conv3x3_bwd.hip)

@@ -185,7 +185,8 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
 extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
                                              const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                                              int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw,
-                                             int dw_accumulate, FdStream stream) {
+                                             int dw_accumulate, const FdTensor* dy_affine_x, const float* dy_affine_b, const float* dy_affine_c,
+                                             FdStream stream) {
   FD_REQUIRE(dy && w_packed_flipped && fwd_x && dpre && wgrad_workspace && dw, "conv1x1_bwd_data_weight: NULL argument");
   FD_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv1x1_bwd_data_weight: accumulate %d", accumulate);
   FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv1x1_bwd_data_weight: packed weights must be 16-byte aligned");
@@ -199,8 +200,18 @@ extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_p
   FD_REQUIRE(!(fwd_pro && fwd_pro->mean) || (fwd_pro->var && partial), "conv1x1_bwd_data_weight: a BatchNorm prologue needs var and the partial-sum workspace");
   long long rows = 0, cpad = 0, nsplit = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dy_affine_x != nullptr) {
+    auto dense = [](const FdTensor* t) {
+      return t->stride[3] == 1 && t->stride[1] == t->w * t->stride[2] && t->stride[0] == t->h * t->stride[1] && t->stride[2] % 8 == 0 &&
+             ((uintptr_t)t->ptr & 15) == 0;
+    };
+    FD_REQUIRE(dy_affine_b && dy_affine_c, "conv1x1_bwd_data_weight: dy_affine_x without its coefficients");
+    FD_REQUIRE(dy_affine_x->dtype == FD_BF16 && dy_affine_x->c == 128 && dy_affine_x->n == dy->n && dy_affine_x->h == dy->h &&
+                   dy_affine_x->w == dy->w && dense(dy_affine_x),
+               "conv1x1_bwd_data_weight: dy_affine_x must be a dense 128-channel NHWC bf16 view shaped like dy");
+  }
   const int rc = conv1x1_bwd_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, partial, capacity_floats, &rows, &cpad, st,
-                                    wgrad_workspace, wgrad_workspace_floats, &nsplit);
+                                    wgrad_workspace, wgrad_workspace_floats, &nsplit, dy_affine_x, dy_affine_b, dy_affine_c);
   if (rc == 1) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_bwd_data_weight: the weight-gradient workspace cannot hold one partial per pixel slot");
   if (rc != FD_OK) return rc;
   if (rows_out) *rows_out = rows;

@@ -157,6 +157,7 @@ class PlanBackward:
         self.fuse_mask = os.environ.get("FDGAN_NO_FUSED_MASK") is None        # tuning aid: separate bn_act_bwd pass
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
         self.fuse_wgrad = os.environ.get("FDGAN_NO_FUSED_WGRAD") is None        # tuning aid: separate 1x1 weight-gradient kernel
+        self.fold_flush = os.environ.get("FDGAN_NO_FOLDED_FLUSH") is None       # tuning aid: separate affine_accumulate pass
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
         # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
@@ -243,8 +244,28 @@ class PlanBackward:
                 d["dirty"].clear()
 
     # ---- one fused convolution ---------------------------------------------------------------
-    def conv_backward(self, r, dy_view, grads, need_dx=True):
-        """dy_view: gradient of the op's stored output (already sum-pooled / masked by the caller if needed)."""
+    def _fuse_w(self, r, need_dx):
+        """The dense-layer bottleneck (1x1, 128 filters): data and weight gradient in one pass over dy and x."""
+        x, w, pro = r["x"], r["w"], r["pro"]
+        pool = pro._meta["pool"] if pro is not None else False
+        return (self.fuse_wgrad and w.param.requires_grad and need_dx and self.checks is None and r["k"] == 1 and r["stride"] == 1 and
+                not w.transposed and r["bias"] is None and w.cout == 128 and r["y"] is not None and r["y"].c == 128 and not pool and
+                x.c0 % 8 == 0 and self.fuse_mask and self.defer_affine)
+
+    def _pending_for_fused(self, r, need_dx):
+        """The deferred coefficient record of r's output buffer when the fused bottleneck kernel can apply it itself (the
+        whole 128-channel buffer is r's output and nothing else reads its gradient): no flush pass then."""
+        if not (self.fold_flush and self._fuse_w(r, need_dx)) or r["upsample"] or r["e_act"] != L.ACT_NONE:
+            return None
+        y = r["y"]
+        d = self.deferred.get(y.buf.data_ptr())
+        if d is None or not d["dirty"] or y.c0 != 0 or d["buf"].shape[-1] != 128:
+            return None
+        return d
+
+    def conv_backward(self, r, dy_view, grads, need_dx=True, dy_pending=None):
+        """dy_view: gradient of the op's stored output (already sum-pooled / masked by the caller if needed).  dy_pending:
+        _pending_for_fused's record -- dy still lacks B * y + C, which the fused kernel adds on the fly."""
         x, w, k, pad, pro = r["x"], r["w"], r["k"], r["pad"], r["pro"]
         meta = pro._meta if pro is not None else dict(act=L.ACT_NONE, pool=False, bn=None)
         if r["stride"] != 1 and need_dx and (w.transposed or (pro is not None and pro._meta["pool"])):
@@ -252,10 +273,8 @@ class PlanBackward:
         desc = E.conv_desc(k, r["stride"], pad, cout=w.cout)
         # ---- parameters
         p = w.param
-        # the dense-layer bottleneck (1x1, 128 filters): data and weight gradient in one pass over dy and x (fused below)
-        fuse_w = (self.fuse_wgrad and p.requires_grad and need_dx and self.checks is None and k == 1 and r["stride"] == 1 and
-                  not w.transposed and r["bias"] is None and w.cout == 128 and dy_view.c == 128 and not meta["pool"] and
-                  x.c0 % 8 == 0 and self.fuse_mask and self.defer_affine)
+        fuse_w = self._fuse_w(r, need_dx) and dy_view.c == 128      # fused below
+        assert dy_pending is None or fuse_w
         if p.requires_grad and not fuse_w:
             if w.transposed:                      # ConvTranspose2d 1x1: weight is (cin, cout, 1, 1)
                 tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
@@ -318,9 +337,18 @@ class PlanBackward:
             store = r.get("_sole", False) and self.checks is None and id(self.gbuf[x.buf.data_ptr()]) in self.nozero
             res = None
             if fuse_w:
+                aff = None
+                if dy_pending is not None:
+                    aff = (E.View(dy_pending["buf"], 0, 128).fd, dy_pending["coef"][0], dy_pending["coef"][1])
                 res = E.conv1x1_bwd_data_weight(dy_view.fd, pw, x.fd, act_pro, gx.fd, self.ws_bn if bn is not None else None,
-                                                2 if store else 1, self.ws, grad_target(grads, p).view(w.cout, w.cin), True)
+                                                2 if store else 1, self.ws, grad_target(grads, p).view(w.cout, w.cin), True,
+                                                dy_affine=aff)
+                if res is not None and dy_pending is not None:
+                    dy_pending["coef"].zero_()
+                    dy_pending["dirty"].clear()
                 if res is None:     # outside the fused kernel's shapes: the two separate kernels
+                    if dy_pending is not None:
+                        self.flush(r["y"])
                     E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grad_target(grads, p), None, self.ws, True)
             if res is None:
                 res = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, gx.fd, ddesc, self.ws_bn if bn is not None else None,
@@ -460,7 +488,10 @@ class PlanBackward:
             if i in self.recompute:
                 self.recs[self.recompute[i]]["rerun"]()
             y = r["y"]
-            self.flush(y)
+            need_dx = id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of
+            pending = self._pending_for_fused(r, need_dx)
+            if pending is None:
+                self.flush(y)
             gy = self.G(y)
             dyv = gy
             if r["upsample"]:
@@ -474,7 +505,7 @@ class PlanBackward:
                     E.grad_ew(E.GRAD_RELU_MASK, dyv, dyv, ref=y)
             elif r["e_act"] != L.ACT_NONE:
                 raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
-            self.conv_backward(r, dyv, grads, need_dx=(id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of))
+            self.conv_backward(r, dyv, grads, need_dx=need_dx, dy_pending=pending)
             if y.buf.data_ptr() in self.multi_version and (self.checks is not None or id(self.gbuf[y.buf.data_ptr()]) not in self.nozero):
                 self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer accumulates a fresh gradient here
             if PROGRESS_HOOK is not None:

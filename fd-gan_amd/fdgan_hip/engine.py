@@ -411,16 +411,20 @@ def conv_bwd_data(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, desc, ws=None, 
     return rows.value, cpad.value
 
 
-def conv1x1_bwd_data_weight(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, ws_bn, accumulate, wgrad_ws, dw, dw_accumulate=True):
+def conv1x1_bwd_data_weight(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, ws_bn, accumulate, wgrad_ws, dw, dw_accumulate=True,
+                            dy_affine=None):
     """The bottleneck's data gradient (as conv_bwd_data) and weight gradient in one pass; returns (rows, cpad), or None when
-    the shape is outside the fused kernel (nothing launched)."""
+    the shape is outside the fused kernel (nothing launched).  dy_affine = (x_fd, B, C): dy + B * x + C is used instead of dy
+    (the pending linear part of the BatchNorm backward of dy's producer)."""
     rows, cpad = C.c_int64(0), C.c_int64(0)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     rc = L.load().fdgan_conv1x1_bwd_data_weight(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
                                                 C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd), int(accumulate),
                                                 ws_bn.data_ptr() if ws_bn is not None else None, ws_bn.numel() if ws_bn is not None else 0,
                                                 C.byref(rows), C.byref(cpad), wgrad_ws.data_ptr(), wgrad_ws.numel(), dw.data_ptr(),
-                                                int(bool(dw_accumulate)), stream_ptr())
+                                                int(bool(dw_accumulate)), C.byref(dy_affine[0]) if dy_affine is not None else None,
+                                                dy_affine[1].data_ptr() if dy_affine is not None else None,
+                                                dy_affine[2].data_ptr() if dy_affine is not None else None, stream_ptr())
     if rc == L.FD_EUNSUPPORTED:
         return None
     L.check(rc, "conv1x1_bwd_data_weight")

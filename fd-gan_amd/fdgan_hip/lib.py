@@ -138,7 +138,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int64), C.POINTER(FdConvDesc), C.c_void_p]),
     "fdgan_conv1x1_bwd_data_weight": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdPrologue),
                                       C.POINTER(FdTensor), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_bn_bwd_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FdPrologue), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fdgan_affine_accumulate": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),

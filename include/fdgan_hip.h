@@ -336,11 +336,15 @@ int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, cons
  * the dy tile and act(bn(x)) -- are on chip anyway.  Saves the weight-gradient kernel's read of dy and x (a quarter of the
  * pair's HBM traffic).  wgrad_workspace: fp32 scratch for one [128][C] partial per pixel slot (<= 512 / ceil(C / 128)
  * slots), summed in a fixed order.  dy must have 128 channels, N*H*W a multiple of 64, views dense; FD_EUNSUPPORTED
- * otherwise (nothing launched: call the two separate entry points). */
+ * otherwise (nothing launched: call the two separate entry points).
+ * dy_affine_x != NULL: dy is not final yet -- the linear remainder of the BatchNorm backward of dy's own producer (norm2 of the
+ * dense layer, fdgan_bn_bwd_finalize_coef's B and C) is still pending: the kernel uses dy + dy_affine_b[c] * dy_affine_x + dy_affine_c[c]
+ * (dy_affine_x: that norm's input, the 128-channel bottleneck activation; rounded to bf16 as fdgan_affine_accumulate would have
+ * stored it), which replaces that read-read-write pass over the gradient buffer.  dy itself is left as it is. */
 int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
                                   const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                                   int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw, int dw_accumulate,
-                                  FdStream stream);
+                                  const FdTensor* dy_affine_x, const float* dy_affine_b, const float* dy_affine_c, FdStream stream);
 /* bsum[c] += B, csum[c] += C of dx = A*dpre + B*x + C for channels [0, channels): B = -gamma*rstd^2*dgamma/count,
  * C = -gamma*rstd*dbeta/count - B*mean (pro: the forward prologue's mean / var / gamma / eps). */
 int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,
