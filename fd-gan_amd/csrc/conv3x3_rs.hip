@@ -42,6 +42,11 @@
 // against 179 us for conv3x3_pw.  An iteration still takes ~3100 cycles for 1152 cycles of MFMA: LDS
 // (~1300 cycles of traffic per iteration, 40 % of it the K-partial exchange) and the VALU issue slots
 // shared by the three waves of a SIMD (~330 VALU + 72 MFMA per iteration) are the next limits.
+// The generator's own growth convs (the fast path) now run conv3x3_rs2, at the end of this file, built from
+// these timings; this kernel keeps every other shape (ragged strips and rows, fewer filters, bias, epilogue
+// activations).
+#include <type_traits>
+
 #include "conv_igemm.h"
 
 namespace {
@@ -485,6 +490,420 @@ __global__ __launch_bounds__(RS_NT) void conv3x3_rs_kernel(ConvArgs a) {
   }
 }
 
+// =====================================================================================================================
+// conv3x3_rs2 -- the same strips, ring layout and K split, rebuilt around what the phase timers of the kernel above showed
+// (128->32 @256^2, cold: loaders alone 62 us, compute + finishers alone 96 us, together 126 us).  It takes the growth convs
+// of the generator (32 filters, no bias, no epilogue activation, whole 16-pixel strips and 4-row groups); anything else runs
+// the kernel above.
+//   * COMPUTE waves: everything static (step t mod 4 fixes the ring rows: immediate offsets, no address arithmetic), the six
+//     B reads of a 24-MFMA block are those of the NEXT block -- the third block reads the first column shift of the next
+//     step, whose rows were published a barrier ago -- one read per 4 MFMAs, and the partial sums of an output row go to LDS
+//     under the next row's MFMAs.  The matrix pipe used to idle for read latency + accumulator drain + 8 stores + barrier
+//     skew per iteration (1150 busy cycles of 2500).  With the helpers switched off (FDGAN_DEBUG_PHASES=8) the loop now
+//     does the launch's 77 GFLOP in 54-59 us (1.3-1.4 PFLOP/s) at 2400 MHz and 1025 W.
+//   * HELPER waves, two per SIMD, each doing what a loader and a finisher did, on every other step: the input row goes
+//     global -> registers -> prologue -> ring (no LDS-DMA: 120 cycles of issue per instruction, and the in-place transform
+//     read the row back through LDS), everything below the item loop is straight-line code so that hipcc's vmcnt counts
+//     stay exact across the register ring, and a wave's two steps are split so that ONLY the five ring writes (plus the
+//     fetch and the epilogue of one output row) sit between the barrier that frees the ring rows and the one that publishes
+//     them; the prologue arithmetic runs a step earlier, in place, on a row fetched three steps before.
+// Measured, 128->32 @256^2 B=16: 92-95 us in the network (3.6 TB/s, 0.45 of the HBM peak, 835 TFLOP/s) against 103-106 us
+// for the kernel above; 117-120 us cold against 123-126.  What is left is not an issue limit any more: replayed back to
+// back the launch holds the board at its 1400 W limit (rocm-smi: 1380 W, sclk down from 2400 to 2050 MHz;
+// tools/power_probe.py), and every restructuring that only removed stall cycles -- 8 waves with 256 registers, deeper fetch
+// rings, the transform moved off the critical step -- left the time where it was while the per-step cycle count fell by a
+// third.  The remaining levers are joules, not cycles: the LDS traffic (162 KB per step: 72 KB of B fragments, 64 KB of
+// K-partials) and the fp32 prologue arithmetic.
+// Step t of an item (n iterations, steps 0 .. n): compute = MFMAs of iteration t, its partial sums -> LDS; helper (h, t & 1),
+// phase A = ring rows of group t+2 <- its registers, fetch of group t+6 into them, epilogue of output row 4(t-1)+h; in step
+// t+1, phase B = store of that output row, prologue on the registers of group t+4.  One s_barrier per step.
+constexpr int R2_NT = 768, R2_NR = 16, R2_NH = 8;   // threads, ring rows, helper waves
+constexpr int R2_RING_B = R2_NR * RS_ROW_B;   // 73728
+__host__ __device__ inline unsigned r2_lds_bytes() {
+  return R2_RING_B + 2 * RS_RED_B + 128 * 8 + R2_NH * 32 * 2 * 4 + R2_NH * RowStore<RS_CT>::BYTES;
+}
+template <int N>
+__device__ __forceinline__ void r2_barrier() {   // all LDS operations of this wave but the youngest N are complete
+  asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---- compute wave w: input channels [32w, 32w+32).  TM = t mod 4.
+template <int TM>
+__device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], char* red_lane, const bf16x8 (&wf)[9][RS_CT],
+                                                bf16x8 (&X)[2][RS_R + 2], RsTimer& tm) {
+  constexpr int PAR = TM & 1, S0 = (4 * TM) & (R2_NR - 1);
+  const f32x4 fzero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[RS_R][RS_CT];
+  auto xread = [&](int dx, int r) __attribute__((always_inline)) {   // B fragment of ring row S0 + r, column shift dx
+    const int s = (S0 + r) & (R2_NR - 1);
+    return __builtin_bit_cast(bf16x8, lds_read16(xb[dx][s >> 3] + (s & 7) * RS_ROW_B));
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  // block 0 (dx = 0, fragments X[PAR]) while the dx = 1 fragments arrive
+#pragma unroll
+  for (int r = 0; r < RS_R + 2; ++r) X[PAR ^ 1][r] = xread(1, r);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int pp = 0; pp < RS_R; ++pp)
+#pragma unroll
+      for (int c = 0; c < RS_CT; ++c)
+        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3][c], X[PAR][pp + dy], dy == 0 ? fzero : acc[pp][c], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // block 1 (dx = 1) while the dx = 2 fragments arrive
+#pragma unroll
+  for (int r = 0; r < RS_R + 2; ++r) X[PAR][r] = xread(2, r);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int pp = 0; pp < RS_R; ++pp)
+#pragma unroll
+      for (int c = 0; c < RS_CT; ++c)
+        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + 1][c], X[PAR ^ 1][pp + dy], acc[pp][c], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // block 2 (dx = 2), output row by output row, while the dx = 0 fragments of the next step arrive (garbage after the last
+  // step); a finished row's K-quarter goes to LDS under the next row's MFMAs: the helpers add the quarters up
+#pragma unroll
+  for (int r = 0; r < RS_R + 2; ++r) X[PAR ^ 1][r] = xread(0, RS_R + r);
+#pragma unroll
+  for (int pp = 0; pp < RS_R; ++pp) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int c = 0; c < RS_CT; ++c)
+        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + 2][c], X[PAR][pp + dy], acc[pp][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < RS_CT; ++c)
+      *reinterpret_cast<f32x4*>(red_lane + PAR * RS_RED_B + pp * (RS_R * RS_CT * 1024) + c * 1024) = acc[pp][c];
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);   // row 0: 6 MFMAs, 2 reads
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 2);
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+  __builtin_amdgcn_sched_group_barrier(0x008, 3, 2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {                        // rows 1 .. 3: 6 MFMAs, the previous row's 2 stores, 4 reads in all
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 2);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 2);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 2);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+  __builtin_amdgcn_sched_group_barrier(0x200, 2, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  tm.stamp(0);
+  r2_barrier<0>();
+  tm.stamp(2);
+}
+
+__device__ __forceinline__ void r2_compute(const ConvArgs& a, const char* ring, char* red, int w, int lane, int bid, int nwg, RsTimer& tm) {
+  const int m = lane & 15, g = lane >> 4;
+  bf16x8 wf[9][RS_CT];   // this wave's quarter of the filter: channels [32w, 32w+32), all taps
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < RS_CT; ++c)
+      wf[t][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.w + ((long long)(w * 9 + t) * RS_CT + c) * 512 + lane * 8));
+  const char* xb[3][2];   // B fragment: pixel m + dx, 16-byte chunk 4w + g, of ring rows 0 / 8
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    xb[dx][0] = ring + (m + dx) * 256 + (((4 * w + g) ^ ((2 * (m + dx)) & 15)) * 16);
+    xb[dx][1] = xb[dx][0] + 8 * RS_ROW_B;
+  }
+  char* red_lane = red + w * (RS_CT * 1024) + lane * 16;
+  bf16x8 X[2][RS_R + 2];
+  r2_barrier<0>();   // F
+
+  for (int item = bid; item < a.ntiles; item += nwg) {
+    const int n = rs_item(a, item).n_iter;
+    r2_barrier<0>();   // P: groups 0 and 1 are in the ring
+#pragma unroll
+    for (int r = 0; r < RS_R + 2; ++r) X[0][r] = __builtin_bit_cast(bf16x8, lds_read16(xb[0][0] + r * RS_ROW_B));
+    int t = 0;
+    for (; t + 4 <= n; t += 4) {
+      r2_compute_step<0>(xb, red_lane, wf, X, tm);
+      r2_compute_step<1>(xb, red_lane, wf, X, tm);
+      r2_compute_step<2>(xb, red_lane, wf, X, tm);
+      r2_compute_step<3>(xb, red_lane, wf, X, tm);
+    }
+    if (t < n) r2_compute_step<0>(xb, red_lane, wf, X, tm);
+    if (t + 1 < n) r2_compute_step<1>(xb, red_lane, wf, X, tm);
+    if (t + 2 < n) r2_compute_step<2>(xb, red_lane, wf, X, tm);
+    r2_barrier<0>();   // step n: the helpers finish the last row group
+  }
+}
+
+// ---- helper wave (h, par): input row h of the groups = par (mod 2), output row h of the iterations != par (mod 2).
+// Everything below the item loop is straight-line code (selects instead of branches, harmless duplicate or L2-hot fetches
+// and ring writes instead of skipped ones): the compiler's s_waitcnt vmcnt counts stay exact across the register ring only
+// without control flow between a fetch and its use -- with uniform branches around the fetches every wait degraded to
+// vmcnt(0), which serialised each step with the memory latency of the row fetched IN it.
+template <int XMODE>
+__device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const char* red, const float* sc_lds, const float* sh_lds,
+                                          float* stat_red, char* rowstage, int hw, int lane, int bid, int nwg, RsTimer& tm) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  const int h = hw & 3, par = hw >> 2;
+  const int tc = lane & 15, tp = lane >> 4;   // fetch / prologue: 16-byte channel chunk, pixel within a group of 4
+  const int m = lane & 15, g = lane >> 4;     // epilogue (MFMA result layout): pixel m, couts g*4.. of tile c
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, h0 = s0, h1 = s0;
+  bool first = true;
+  // unit `it` of a lane = (pixel it*4 + lane/16, channel chunk lane%16) of the 18-pixel ring row; unit 4 exists for pixels
+  // 16, 17 only: lanes 32..63 repeat lanes 0..31 (same address, same value, same ring slot)
+  // byte offset inside a ring row: [18 px][16 slots], slot = chunk ^ (2 px & 15); units 2, 3 = units 0, 1 + 8 pixels (same slot)
+  auto xf_of = [&](int it) __attribute__((always_inline)) {
+    const int p = it * 4 + (it == 4 ? (tp & 1) : tp);
+    return p * 256 + ((tc ^ ((2 * p) & 15)) * 16);
+  };
+  const int xf0 = xf_of(0), xf1 = xf_of(1), xf4 = xf_of(4);
+  auto xf_off = [&](int it) __attribute__((always_inline)) { return it == 4 ? xf4 : ((it & 1) ? xf1 : xf0) + (it >> 1) * 2048; };
+  const unsigned row_pitch_b = (unsigned)a.x_sh * 2u;
+  f32x2_t st1[RS_CT][2], st2[RS_CT][2];   // (no bias: the dispatcher sends biased convs to the kernel above)
+#pragma unroll
+  for (int c = 0; c < RS_CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) st1[c][r] = st2[c][r] = (f32x2_t){0.f, 0.f};
+  char* tb = rowstage + hw * RowStore<RS_CT>::BYTES;
+  char* tb_w = tb + m * RowStore<RS_CT>::PITCH + g * 8;                              // staging: MFMA layout in ...
+  const char* tb_r = tb + (lane >> 2) * RowStore<RS_CT>::PITCH + (lane & 3) * 16;   // ... one pixel quarter per lane out
+  const unsigned y_lane = (unsigned)((lane >> 2) * a.y_sw + (lane & 3) * 8);
+  const char* red_lane = red + h * (RS_R * RS_CT * 1024) + lane * 16;
+
+  for (int item = bid; item < a.ntiles; item += nwg) {
+    const RsItem I = rs_item(a, item);
+    const int n = I.n_iter;
+    if (a.dbg_skip & 8) {   // measurement aid: the compute waves alone
+      if (first) r2_barrier<0>();
+      first = false;
+      for (int t = 0; t < n + 2; ++t) r2_barrier<0>();
+      continue;
+    }
+    const int x0 = I.sx * RS_TW - 1, y0 = I.sg * a.seg_rows - 1;   // image coords of ring pixel 0 / ring row 0
+    const char* img = reinterpret_cast<const char*>(a.x + (long long)I.n * a.x_sn);
+    unsigned src_off[5], keepbits = 0;   // columns outside the image: fetched from the clamped column, zeroed after the prologue
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int px = x0 + it * 4 + (it == 4 ? (tp & 1) : tp);
+      src_off[it] = (unsigned)(min(max(px, 0), a.Ws - 1) * a.x_sw + tc * 8) * 2u;
+      keepbits |= (px >= 0 && px < a.Ws) ? (1u << it) : 0u;
+    }
+    auto keep = [&](int it) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_sbfe((int)keepbits, it, 1); };
+    // first row this wave stores: iteration 0 for par = 1 (step 1), iteration 1 for par = 0 (step 2); then every other one
+    unsigned short* yrow = reinterpret_cast<unsigned short*>(a.y) + (long long)I.n * a.y_sn + (long long)(I.sx * RS_TW) * a.y_sw +
+                           (long long)(I.sg * a.seg_rows + h + (par ? 0 : RS_R)) * a.y_sh;
+
+    // Two register sets.  In its k-th cycle (steps t = par + 2k and t+1) the wave
+    //   A (step t):    writes S[k % 2] -- group t+2, transformed a step ago -- to the ring, refills it with the fetch of group
+    //                  t+6, and finishes output row 4(t-1)+h (partials -> sum, statistics -> staging tile);
+    //   B (step t+1):  stores the staged row and applies the prologue IN PLACE to S[(k+1) % 2], group t+4, fetched three steps ago.
+    // Only the five ring writes sit between the barrier that frees the ring rows and the one that publishes them: with the
+    // transform in the same step the helpers' step was 3000 cycles against 1600 of the compute waves, however many of them
+    // shared the work.  A fetch has three steps to arrive.
+    u32x4 S[2][5], tmp[5];
+    auto issue_row = [&](int q, bool wanted, u32x4 (&dst)[5]) __attribute__((always_inline)) {
+      // ring row q of the item; `wanted` false (a group past the item's last): the item's first row again (L2-hot, never used)
+      const int gy = min(max(y0 + (wanted ? q : 0), 0), a.Hs - 1);
+      const char* rowp = img + (unsigned long long)gy * row_pitch_b;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) dst[it] = *reinterpret_cast<const u32x4*>(rowp + src_off[it]);
+    };
+    auto transform_row = [&](int q, const u32x4 (&src)[5], u32x4 (&dst)[5]) __attribute__((always_inline)) {
+      const unsigned rowmask = (y0 + q >= 0 && y0 + q < a.Hs) ? 0xffffffffu : 0u;   // zero padding is post-activation
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        u32x4 v = XMODE == 0 ? src[it] : fd_xform8_r(src[it], s0, s1, h0, h1, XMODE == 1 ? 0.f : a.p_slope);
+        dst[it] = v & (keep(it) & rowmask);
+      }
+    };
+    auto write_row = [&](int q, const u32x4 (&src)[5]) __attribute__((always_inline)) {
+      char* row = ring + (q & (R2_NR - 1)) * RS_ROW_B;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) lds_write16(row + xf_off(it), src[it]);
+    };
+    const char* rbuf = red_lane;
+    // sum of the four K-partials, statistics; the row goes to the wave's staging tile as bf16 [pixel][32 channels] and is read
+    // back one pixel quarter per lane and stored in phase B
+    auto epilogue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < RS_CT; ++c) {
+        f32x4 part[RS_R];
+#pragma unroll
+        for (int k = 0; k < RS_R; ++k) part[k] = *reinterpret_cast<const f32x4*>(rbuf + (k * RS_CT + c) * 1024);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          f32x2_t t = ((f32x2_t){part[0][2 * r], part[0][2 * r + 1]} + (f32x2_t){part[1][2 * r], part[1][2 * r + 1]}) +
+                      ((f32x2_t){part[2][2 * r], part[2][2 * r + 1]} + (f32x2_t){part[3][2 * r], part[3][2 * r + 1]});
+          st1[c][r] += t;
+          st2[c][r] = __builtin_elementwise_fma(t, t, st2[c][r]);
+          v[2 * r] = t[0];
+          v[2 * r + 1] = t[1];
+        }
+        *reinterpret_cast<u32x2*>(tb_w + c * 32) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4_t));
+      }
+    };
+    auto flush_staged = [&]() __attribute__((always_inline)) {
+      *reinterpret_cast<u32x4*>(yrow + y_lane) = *reinterpret_cast<const u32x4*>(tb_r);
+      yrow += (long long)(2 * RS_R) * a.y_sh;
+    };
+
+    // Before the first step: groups 0 (par 0: rows h and, for h < 2, 4 + h) and 1 (par 1: row 6 + h) into the ring, this wave's
+    // first group (2 + par) transformed in S[0], its second (4 + par) in flight in S[1]
+    const int g0 = 2 + par;
+    issue_row(par ? 6 + h : h, true, S[0]);
+    issue_row(par ? 6 + h : (h < 2 ? 4 + h : h), true, S[1]);   // (where there is no second row: the first once more, same ring row)
+    issue_row(4 * g0 + 2 + h, g0 < n, tmp);
+    if (first) {   // barrier F: the compute waves have folded BatchNorm into (scale, shift) meanwhile
+      first = false;
+      r2_barrier<0>();
+      s0 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8);
+      s1 = *reinterpret_cast<const f32x4*>(sc_lds + tc * 8 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8);
+      h1 = *reinterpret_cast<const f32x4*>(sh_lds + tc * 8 + 4);
+    }
+    transform_row(par ? 6 + h : h, S[0], S[0]);
+    write_row(par ? 6 + h : h, S[0]);
+    transform_row(par ? 6 + h : (h < 2 ? 4 + h : h), S[1], S[1]);
+    write_row(par ? 6 + h : (h < 2 ? 4 + h : h), S[1]);
+    issue_row(4 * (g0 + 2) + 2 + h, g0 + 2 < n, S[1]);
+    transform_row(4 * g0 + 2 + h, tmp, S[0]);
+    r2_barrier<0>();   // P
+
+    // phase A of the cycle starting at step t (set `cur`), phase B (set `nxt`)
+    auto phase_a = [&](int t, u32x4 (&cur)[5], auto epi) __attribute__((always_inline)) {
+      write_row(4 * (t + 2) + 2 + h, cur);
+      const int qf = 4 * (t + 6) + 2 + h;
+      const char* rowp = img + (unsigned long long)min(max(y0 + (t + 6 < n ? qf : 0), 0), a.Hs - 1) * row_pitch_b;
+#pragma unroll
+      for (int it = 0; it < 5; ++it) cur[it] = *reinterpret_cast<const u32x4*>(rowp + src_off[it]);
+      if (decltype(epi)::value) {
+        rbuf = red_lane + ((t - 1) & 1) * RS_RED_B;
+        epilogue();
+      }
+      tm.stamp(0);
+      r2_barrier<0>();
+      tm.stamp(1);
+    };
+    auto phase_b = [&](int t, u32x4 (&nxt)[5], auto epi) __attribute__((always_inline)) {   // step t + 1
+      if (decltype(epi)::value) flush_staged();
+      transform_row(4 * (t + 4) + 2 + h, nxt, nxt);
+      tm.stamp(2);
+      r2_barrier<0>();
+      tm.stamp(3);
+    };
+    const std::integral_constant<bool, true> YES;
+    const std::integral_constant<bool, false> NO;
+    // steps 0 .. n; cycles at t = par, par + 2, ...: the first cycle of par 0 (t = 0) has nothing to finish
+    int t = par;
+    if (par) r2_barrier<0>();   // step 0 belongs to the other parity
+    if (par == 0) {
+      phase_a(0, S[0], NO);
+      if (1 <= n) phase_b(0, S[1], NO);
+    } else if (1 <= n) {
+      phase_a(1, S[0], YES);
+      if (2 <= n)
+        phase_b(1, S[1], YES);
+      else
+        flush_staged();
+    }
+    t += 2;
+    for (; t + 3 <= n; t += 4) {   // two cycles: sets S[1], S[0]
+      phase_a(t, S[1], YES);
+      phase_b(t, S[0], YES);
+      phase_a(t + 2, S[0], YES);
+      phase_b(t + 2, S[1], YES);
+    }
+    if (t <= n) {
+      phase_a(t, S[1], YES);
+      if (t + 1 <= n) {
+        phase_b(t, S[0], YES);
+        if (t + 2 <= n) {
+          phase_a(t + 2, S[0], YES);
+          if (t + 3 <= n)
+            phase_b(t + 2, S[1], YES);
+          else
+            flush_staged();
+        }
+      } else {
+        flush_staged();
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int c = 0; c < RS_CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1v = fd_row_sum16(st1[c][r >> 1][r & 1]), s2v = fd_row_sum16(st2[c][r >> 1][r & 1]);
+        if (m == 0) {
+          const int idx = (hw * RS_CT * 16 + c * 16 + g * 4 + r) * 2;
+          stat_red[idx] = s1v;
+          stat_red[idx + 1] = s2v;
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(R2_NT) void conv3x3_rs2_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  char* red = smem + R2_RING_B;                                    // [2][row][k-quarter][ct][lane] f32x4
+  float* sc_lds = reinterpret_cast<float*>(red + 2 * RS_RED_B);    // [128]
+  float* sh_lds = sc_lds + 128;
+  float* stat_red = sh_lds + 128;                                  // [helper][32][2]
+  char* rowstage = reinterpret_cast<char*>(stat_red + R2_NH * 32 * 2);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The BatchNorm fold (four dependent global loads per channel) is done by the compute waves while the helpers already
+  // issue the first row fetches; barrier F publishes scale / shift.
+  const int nwg = (int)gridDim.x;
+  const int bid = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;   // XCD-aware, as above
+  RsTimer tm;   // measurement aid (tools/conv_bench.py FDGAN_TIMING=1)
+  tm.start(a.dbg != nullptr && blockIdx.x == 0);
+  if (wave < RS_R) {
+    fd_fold_bn(a, sc_lds, sh_lds, 128, tid, 64 * RS_R);
+    r2_compute(a, ring, red, wave, lane, bid, nwg, tm);
+  } else {
+    const int hw = wave - RS_R;
+    if (a.pro_mode == 0)
+      r2_helper<0>(a, ring, red, sc_lds, sh_lds, stat_red, rowstage, hw, lane, bid, nwg, tm);
+    else if (a.p_slope == 0.f)
+      r2_helper<1>(a, ring, red, sc_lds, sh_lds, stat_red, rowstage, hw, lane, bid, nwg, tm);
+    else
+      r2_helper<2>(a, ring, red, sc_lds, sh_lds, stat_red, rowstage, hw, lane, bid, nwg, tm);
+  }
+  if (tm.on && lane == 0 && wave < 8)
+    for (int k = 0; k < 6; ++k) a.dbg[wave * 8 + k] = tm.t[k];
+  // ---- common tail: one partial row of statistics per workgroup
+  if (a.stats != nullptr) {
+    __syncthreads();
+    for (int cl = tid; cl < RS_CT * 16; cl += R2_NT) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < R2_NH; ++w_) {
+        t1 += stat_red[(w_ * RS_CT * 16 + cl) * 2];
+        t2 += stat_red[(w_ * RS_CT * 16 + cl) * 2 + 1];
+      }
+      float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + cl) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+    if (a.fin_mean != nullptr) fd_finalize_last_block(a, RS_CT * 16, tid, ring);
+  }
+}
+
 int rs_num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -518,7 +937,12 @@ int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
   a.ntiles = (int)nt;
   dim3 grid((unsigned)(nt < ncu ? nt : ncu), 1, 1), block(RS_NT, 1, 1);
   a.stats_cpad = RS_CT * 16;
-  const unsigned lds = rs_lds_bytes();
+  // the second-generation kernel: 32 stored channels, full-width strips, whole row groups, no bias, no epilogue activation
+  bool gen2 = a.CoutW == RS_CT * 16 && a.ntile_total == RS_CT && a.Cout >= RS_CT * 16 && a.y_vec16 && a.Wo % RS_TW == 0 && a.Ho % RS_R == 0 &&
+              seg % RS_R == 0 && a.e_slope == 1.f && a.Ws == a.Wo && a.Hs == a.Ho && a.bias == nullptr;
+  if (const char* e = FD_TUNE_GETENV("FDGAN_DEBUG_RS2")) gen2 = gen2 && e[0] != '0';
+  const unsigned lds = gen2 ? r2_lds_bytes() : rs_lds_bytes();
+  if (gen2) block = dim3(R2_NT, 1, 1);
   if (info) {
     info->stats_rows = grid.x;
     info->stats_cpad = a.stats_cpad;
@@ -532,11 +956,14 @@ int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rs_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rs2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv3x3_rs): %s", hipGetErrorString(e));
     attr_done = true;
   }
   if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)
     FD_FAIL(FD_EINVAL, "stats workspace too small: need %lld floats, have %lld", (long long)grid.x * a.stats_cpad * 2,
             stats_cap);
+  if (gen2) return fd_launch(&conv3x3_rs2_kernel, "conv3x3_rs_bn32", grid, block, lds, a, stream);
   return fd_launch(&conv3x3_rs_kernel, "conv3x3_rs_bn32", grid, block, lds, a, stream);
 }

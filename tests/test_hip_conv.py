@@ -149,6 +149,24 @@ def test_conv3x3_row_streaming_kernel(E):
     _run(E, 1, 24, 16, 128, 32, 3, pad=1, stats=True, seed=56)
 
 
+def test_conv3x3_row_streaming_second_generation(E):
+    """conv3x3_rs2 (the fast path of the growth convs: 32 filters, no bias, widths of whole 16-pixel strips, whole row groups):
+    every iteration count 1 .. 13 per work item -- the pipeline's first steps, its 4-step compute loop and 4-step helper loop
+    and all their remainders, for both helper parities -- with the three prologue kinds, an image-edge strip in every item
+    (16-pixel-wide images: both zero columns), a sliced output, and items with different lengths in one launch."""
+    from fdgan_hip import engine
+    for i, h in enumerate((4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52)):
+        info = engine.conv_info(engine.View(torch.empty((256, h, 16, 128), dtype=torch.bfloat16, device="cuda:0")).fd,
+                                engine.View(torch.empty((256, h, 16, 32), dtype=torch.bfloat16, device="cuda:0")).fd, 32,
+                                engine.conv_desc(3, 1, 1))
+        assert info.grid_x == 256 and info.lds_bytes > 140 * 1024      # one whole-height item per workgroup, the 12-wave kernel
+        kind = i % 3
+        _run(E, 256, h, 16, 128, 32, 3, pad=1, bn=kind != 2, p_act=(ACT_RELU, ACT_LEAKY02, ACT_NONE)[kind], stats=True,
+             pitch_out=64 if i % 2 else None, c0_out=32 if i % 2 else 0, seed=60 + i)
+    _run(E, 3, 52, 48, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, seed=80)        # segments of 8 rows and one of 4
+    _run(E, 40, 20, 32, 128, 32, 3, pad=1, bn=True, p_act=ACT_LEAKY02, stats=True, pitch_in=192, c0_in=64, seed=81)
+
+
 # dense-layer bottleneck: 1x1 over a channel prefix of a wider concat buffer
 def test_conv1x1_prefix_to_128_bn_relu_stats(E):
     _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3)

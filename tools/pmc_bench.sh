@@ -21,7 +21,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernel symbol -> (launcher name, workload key): the forward kernels are keyed on the forward-only workload, the
 # BatchNorm-backward pass on the training step (both run in the default bench.py)
-names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
+names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs2_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
          "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256"),
          "conv1x1_bwd_kernel": ("conv1x1_bwd_stream", "train_B16_256"),
          "conv1x1_bwdw_kernel": ("conv1x1_bwd_wgrad_stream", "train_B16_256"),
