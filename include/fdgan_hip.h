@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 5
+#define FDGAN_ABI_VERSION 6
 
 enum FdStatus {
   FD_OK = 0,
