@@ -289,8 +289,8 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
         t2 += red[(w_ * 128 + cl) * 2 + 1];
       }
       float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + cl) * 2;
-      dst[0] = t1;
-      dst[1] = t2;
+      fd_stats_store(a, dst, t1);
+      fd_stats_store(a, dst + 1, t2);
     }
     if (a.fin_mean != nullptr) fd_finalize_last_block(a, 128, tid, stage0);
   }

@@ -483,8 +483,8 @@ __global__ __launch_bounds__(RS_NT) void conv3x3_rs_kernel(ConvArgs a) {
         t2 += stat_red[(w_ * RS_CT * 16 + cl) * 2 + 1];
       }
       float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + cl) * 2;
-      dst[0] = t1;
-      dst[1] = t2;
+      fd_stats_store(a, dst, t1);
+      fd_stats_store(a, dst + 1, t2);
     }
     if (a.fin_mean != nullptr) fd_finalize_last_block(a, a.CoutW < RS_CT * 16 ? a.CoutW : RS_CT * 16, tid, ring);
   }
@@ -897,8 +897,8 @@ __global__ __launch_bounds__(R2_NT) void conv3x3_rs2_kernel(ConvArgs a) {
         t2 += stat_red[(w_ * RS_CT * 16 + cl) * 2 + 1];
       }
       float* dst = a.stats + ((long long)blockIdx.x * a.stats_cpad + cl) * 2;
-      dst[0] = t1;
-      dst[1] = t2;
+      fd_stats_store(a, dst, t1);
+      fd_stats_store(a, dst + 1, t2);
     }
     if (a.fin_mean != nullptr) fd_finalize_last_block(a, RS_CT * 16, tid, ring);
   }

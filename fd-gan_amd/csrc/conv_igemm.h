@@ -183,31 +183,42 @@ __device__ __forceinline__ void fd_fold_bn(const ConvArgs& a, float* sc_lds, flo
   if (a.pro_mode == 2 && a.nbt != nullptr && first && tid == 0) *a.nbt += 1;
 }
 
-// In-kernel finalize of the batch statistics (opt-in: FdStats.mean; measured SLOWER than the separate launch on
-// MI355X -- the device-scope fences below cost an L2 write-back / invalidate per workgroup, 2x on the whole
-// forward -- kept for hardware where that is cheap).  Every workgroup has just written its partial row; the last one
-// to arrive (device-scope counter) reduces all rows in fp64 and writes mean / biased variance, saving the
-// fdgan_bn_finalize launch that would otherwise sit between this conv and its consumer.  Call from ALL threads
-// of the workgroup after the partial row is stored.  Rows are blockIdx.x-indexed with pitch a.stats_cpad.
-// `scratch`: >= 4.5 KiB of LDS that is free at this point (8-byte aligned).
+// In-kernel finalize of the batch statistics (opt-in: FdStats.mean != NULL; measured SLOWER than the separate launch on
+// MI355X in both forms, see fdgan_hip/netplan.py -- kept for hardware where one workgroup's reduction is cheap).  Every
+// workgroup has just written its partial row; the last one to arrive (agent-scope counter) reduces all rows in fp64 and writes
+// mean / biased variance, saving the fdgan_bn_finalize launch that would otherwise sit between this conv and its consumer.
+// Coherence WITHOUT fences: a device-scope release / acquire pair is an L2 write-back + invalidate on MI355X (8 XCDs, 8 L2s)
+// -- in every workgroup, right after a kernel that has just written its whole output: measured 2x on the whole forward.
+// Instead the partial rows are written and read with RELAXED agent-scope atomic stores / loads (sc1: they go through to the
+// memory side and never sit dirty in, or are served stale from, an XCD's L2), the counter is a relaxed agent-scope RMW, and
+// the only ordering needed -- a workgroup's row before its increment -- is "the stores have been acknowledged"
+// (s_waitcnt vmcnt(0)) ahead of the atomic's issue.  Partial rows: fd_stats_store() below, from the kernels' tails.
+// Call from ALL threads of the workgroup after the partial row is stored.  Rows are blockIdx.x-indexed with pitch
+// a.stats_cpad.  `scratch`: >= 4.5 KiB of LDS that is free at this point (8-byte aligned).
+__device__ __forceinline__ void fd_stats_store(const ConvArgs& a, float* dst, float v) {
+  if (a.fin_mean != nullptr)
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *dst = v;
+}
 __device__ __forceinline__ void fd_finalize_last_block(const ConvArgs& a, int channels, int tid, char* scratch) {
   double(*fd_red)[8][33] = reinterpret_cast<double(*)[8][33]>(scratch);
   volatile unsigned* fd_is_last = reinterpret_cast<volatile unsigned*>(scratch + 2 * 8 * 33 * 8);
-  __threadfence();   // release this workgroup's partial row at device scope
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's part of the row is at the memory side
   __syncthreads();
-  if (tid == 0) *fd_is_last = atomicAdd(a.fin_counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  if (tid == 0)
+    *fd_is_last = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!*fd_is_last) return;
-  __threadfence();   // acquire the other workgroups' rows
   const int rows = (int)gridDim.x;
   for (int c0 = 0; c0 < channels; c0 += 32) {
     const int cl = tid & 31, rg = tid >> 5;   // 32 channels x 8 row groups (first 256 threads)
     double s1 = 0.0, s2 = 0.0;
     if (tid < 256 && c0 + cl < channels)
       for (int r = rg; r < rows; r += 8) {
-        const volatile float* pr = a.stats + ((long long)r * a.stats_cpad + c0 + cl) * 2;
-        s1 += pr[0];
-        s2 += pr[1];
+        float* pr = a.stats + ((long long)r * a.stats_cpad + c0 + cl) * 2;
+        s1 += __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2 += __hip_atomic_load(pr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     if (tid < 256) {
       fd_red[0][rg][cl] = s1;
@@ -228,7 +239,7 @@ __device__ __forceinline__ void fd_finalize_last_block(const ConvArgs& a, int ch
     }
     __syncthreads();
   }
-  if (tid == 0) *a.fin_counter = 0u;   // ready for the next launch on this stream
+  if (tid == 0) __hip_atomic_store(a.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
 }
 
 // Sum over the 16 lanes of a DPP row (the 16 pixels of an MFMA result row): 4 VALU adds with

@@ -41,9 +41,13 @@ class NetPlan:
         self._param_versions = None
         self.records = []          # per op, in forward order: what the backward pass needs (fdgan_hip/backward.py)
         import os
-        # Measured (netG fwd B=16 @256^2): letting the producer's last workgroup finalize the statistics removes 86
-        # launches but needs a device-scope release / acquire in EVERY workgroup, and on MI355X that is an L2
-        # write-back + invalidate per XCD: 10.7 ms per step against 5.25 ms with the separate 5 us launches.  Off.
+        # Opt-in: the producer's last workgroup finalizes the batch statistics (86 fdgan_bn_finalize launches less per netG
+        # forward).  Measured twice, slower both times.  With device-scope release / acquire fences in every workgroup (an L2
+        # write-back + invalidate per XCD on MI355X): 10.7 ms per forward against 5.25.  With relaxed agent-scope atomics
+        # instead of fences (csrc/conv_igemm.h: fd_finalize_last_block, what is there now): 6.4 ms against 4.84, the step 32.7
+        # against 31.2 -- +33 us per conv1x1_ds launch, +8 us per conv3x3_rs launch: ONE workgroup pulling 256 rows x 128
+        # channels of partials through one CU's address unit costs more than the separate 32-workgroup launch does in the
+        # stream (~3 us).  Off.
         self.fuse_finalize = os.environ.get("FDGAN_FUSED_FINALIZE") is not None
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)   # last-workgroup counter of the fused finalize
 
@@ -86,7 +90,7 @@ class NetPlan:
             count = n * h * ww // (4 if upsample else 1)
 
         fused = None
-        if stats is not None and info.fused_finalize and self.fuse_finalize:
+        if stats is not None and info.fused_finalize and self.fuse_finalize and not stats_also:
             fused = (stats.mean.data_ptr() + 4 * stats_c0, stats.var.data_ptr() + 4 * stats_c0, self.counter.data_ptr(), count)
 
         def run():

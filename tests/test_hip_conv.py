@@ -167,6 +167,39 @@ def test_conv3x3_row_streaming_second_generation(E):
     _run(E, 40, 20, 32, 128, 32, 3, pad=1, bn=True, p_act=ACT_LEAKY02, stats=True, pitch_in=192, c0_in=64, seed=81)
 
 
+def test_last_workgroup_finalizes_the_statistics(E):
+    """The in-kernel finalize (FdStats.mean: the last workgroup to arrive reduces every workgroup's partial row; relaxed
+    agent-scope atomics instead of device-scope fences) of the three kernels that have it against the separate
+    fdgan_bn_finalize launch on the same partial rows: 300 back-to-back launches each, every one must give the same mean /
+    variance (a row read before its writer's store had landed, or a stale counter, shows up as a different sum)."""
+    dev = torch.device("cuda:0")
+    for k, cin, hw in ((3, 128, 128), (3, 128, 19), (1, 224, 128)):       # conv3x3_rs2, conv3x3_rs, conv1x1_ds
+        cout = 32 if k == 3 else 128
+        x = (torch.randn(16, hw, hw, cin, device=dev) * 0.7).to(torch.bfloat16)
+        y = torch.empty(16, hw, hw, cout, dtype=torch.bfloat16, device=dev)
+        pw = E.PackedWeight(torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5, cout, cin, k)
+        pw.pack()
+        pro = E.make_prologue(act=ACT_RELU, mean=torch.randn(cin, device=dev) * 0.1, var=torch.rand(cin, device=dev) + 0.5,
+                              gamma=torch.rand(cin, device=dev) + 0.5, beta=torch.randn(cin, device=dev) * 0.1)
+        desc = E.conv_desc(k, 1, k // 2, cout=cout, w_layout=pw.layout)
+        xv, yv = E.View(x, 0, cin), E.View(y, 0, cout)
+        ws = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+        count = 16 * hw * hw
+        info = E.conv2d(xv.fd, pw, None, pro, yv.fd, desc, ws)
+        assert info.fused_finalize == 1
+        mean0, var0 = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+        E.bn_finalize(ws, info, cout, count, mean0, var0)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        means, vars_ = torch.zeros(300, cout, device=dev), torch.zeros(300, cout, device=dev)
+        for i in range(300):
+            E.conv2d(xv.fd, pw, None, pro, yv.fd, desc, ws, (means[i].data_ptr(), vars_[i].data_ptr(), counter.data_ptr(), count))
+        torch.cuda.synchronize()
+        assert int(counter.item()) == 0
+        assert bool((means == means[0]).all()) and bool((vars_ == vars_[0]).all()), "launches disagree (k=%d)" % k
+        assert float((means[0] - mean0).abs().max()) <= 1e-6 * max(1.0, float(mean0.abs().max()))
+        assert float(((vars_[0] - var0).abs() / (var0 + 1e-12)).max()) <= 1e-5
+
+
 # dense-layer bottleneck: 1x1 over a channel prefix of a wider concat buffer
 def test_conv1x1_prefix_to_128_bn_relu_stats(E):
     _run(E, 2, 32, 32, 96, 128, 1, pitch_in=256, bn=True, p_act=ACT_RELU, stats=True, seed=3)
