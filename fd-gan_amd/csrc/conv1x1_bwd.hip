@@ -22,6 +22,8 @@
 // /root/reference/models/dehaze1113.py:713-724.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_igemm.h"
 
 namespace {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
 constexpr int F1_TBP = 64 * 2 + 16;              // transposition pitch of one pixel (64 channels)
 constexpr int F1_TB = 16 * F1_TBP;               // per wave
 constexpr int F1_TILE = B1_PX * 256;             // a [64 px][128 ch] bf16 tile
-constexpr int F1_LDS = 3 * F1_TILE + 4 * 8 * 1024 + 8 * F1_TB + 2 * F1_TILE;   // dy tiles, filter, transposition, activated tiles
+constexpr int F1_LDS = 3 * F1_TILE + 4 * 8 * 1024 + 8 * F1_TB + 2 * F1_TILE + 1024;   // dy tiles, filter, transposition, activated tiles, dy_affine coefficients
 
 typedef short f1_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 f1_trfrag(const char* p0, const char* p1) {
@@ -251,6 +253,12 @@ struct Bwdw1Args {
   const float *cB, *cC;       // [128]
 };
 
+// AFFINE: dy_affine given; ACC: 0 G = v, 1 G += sc * v (G is read), 2 G = sc * v.  Template parameters, and no branch around a
+// global load in the steady-state loop (clamped addresses and a peeled last tile instead): with the uniform `if`s the first
+// version had there, hipcc's s_waitcnt vmcnt counts degraded to vmcnt(0) -- the dy rows of the NEXT tile could not be waited
+// for without also waiting for its x and G rows, requested in the same breath for the END of that step, so every step
+// began by draining the whole prefetch.
+template <bool AFFINE, int ACC>
 __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   const Bwd1Args& a = aa.b;
   extern __shared__ __attribute__((aligned(16))) char b1_lds[];
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   char* wt = dyt0 + 3 * F1_TILE;                              // [4 k chunks][8 tiles][1 KB] A fragments of this channel tile
   char* tb0 = wt + 4 * 8 * 1024;                              // 8 x transposition areas
   char* at0 = tb0 + 8 * F1_TB;                                // 2 x activated tile [64 px][256 B]: tile t lives in t mod 2
+  float* cf = reinterpret_cast<float*>(at0 + 2 * F1_TILE);    // dy_affine: cB[128], cC[128] (read per step: 16 registers less)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kgl = lane >> 4;
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   const int piece = lane & 7, ql0 = lane >> 3;
   const int cg = c0 + chh * 64 + piece * 8;
   const bool ch_ok = cg < a.C;
+  const int cg_ld = ch_ok ? cg : 0;                           // lanes past the last channel read channel 0 (ignored below)
   float sc8[8], sh8[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -304,36 +314,26 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
 
   // dy rows (2 units per thread), x / G rows (2 units) of a pixel tile: requested one whole tile ahead, two register sets
   u32x4 dyr[2], ybr[2];
-  const bool affine = aa.yb != nullptr;
-  f32x8 cb8, cc8;                                              // the thread's dy column (tid & 15) is the same for both units
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    cb8[e] = affine ? aa.cB[(tid & 15) * 8 + e] : 0.f;
-    cc8[e] = affine ? aa.cC[(tid & 15) * 8 + e] : 0.f;
-  }
-  auto request_dy = [&](int tl) __attribute__((always_inline)) {
+  if (AFFINE && tid < 256) cf[tid] = tid < 128 ? aa.cB[tid] : aa.cC[tid - 128];   // (published by the first step's barrier ... of the
+  if (AFFINE) __syncthreads();                                                     // previous line: it is read BEFORE that barrier)
+  const float* cfl = cf + (tid & 15) * 8;                     // the thread's dy column is the same for both units
+  auto request_dy = [&](int tl) __attribute__((always_inline)) {   // tl < my_tiles
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + i * 512;                            // (pixel u / 16, 16-byte column u % 16)
-      dyr[i] = ybr[i] = zero4;
-      if (tl < my_tiles) {
-        dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
-        if (affine) ybr[i] = *reinterpret_cast<const u32x4*>(aa.yb + (p0 + (u >> 4)) * aa.yb_pitch + (u & 15) * 8);
-      }
+      dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
+      if (AFFINE) ybr[i] = *reinterpret_cast<const u32x4*>(aa.yb + (p0 + (u >> 4)) * aa.yb_pitch + (u & 15) * 8);
     }
   };
-  auto request = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {
+  auto request = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {   // tl < my_tiles
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
-    const bool live = tl < my_tiles;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const long long p = p0 + pq * 16 + i * 8 + ql0;
-      xv[i] = gv[i] = zero4;
-      if (live && ch_ok) {
-        xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg);
-        if (a.acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg);
-      }
+      xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg_ld);
+      gv[i] = zero4;
+      if (ACC == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg_ld);
     }
   };
   // weight gradient of one tile: dW[128 co][128 ci tile] += dy^T (64 px x 128 co) * act (64 px x 128 ci)
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     }
   };
   int d3 = 0;                                                  // tl mod 3
-  auto step = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2]) __attribute__((always_inline)) {
+  auto step = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2], auto last) __attribute__((always_inline)) {
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
     char* dyt = dyt0 + d3 * F1_TILE;
     char* at = at0 + (tl & 1) * F1_TILE;
@@ -362,11 +362,16 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     d3 = d3 == 2 ? 0 : d3 + 1;
     // no barrier here: slot t mod 3 was last read by the weight gradient of tile t - 3, issued in step t - 2 -- every wave
     // is past that once it has passed the barrier of step t - 1
+    f32x8 cb8, cc8;
+    if (AFFINE) {
+      cb8 = *reinterpret_cast<const f32x8*>(cfl);
+      cc8 = *reinterpret_cast<const f32x8*>(cfl + 128);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = tid + i * 512, q = u >> 4, c16 = u & 15;
       u32x4 v = dyr[i];
-      if (affine) {     // (uniform) dy' = dy + cB * yb + cC, rounded to bf16 exactly as the separate pass stored it
+      if (AFFINE) {     // dy' = dy + cB * yb + cC, rounded to bf16 exactly as the separate pass stored it
         f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
         const f32x8 y8 = __builtin_convertvector(__builtin_bit_cast(bf16x8, ybr[i]), f32x8);
         f = __builtin_elementwise_fma(cb8, y8, f + cc8);        // packed fp32: 8 instructions
@@ -375,8 +380,10 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
       lds_write16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4), v);
     }
     B1_BARRIER();                                             // this tile's dy rows and the previous tile's activated rows are in place
-    request_dy(tl + 1);                                       // next tile: in flight during this tile's MFMAs and row phase
-    request(tl + 1, xn, gn);
+    if (!decltype(last)::value) {
+      request_dy(tl + 1);                                     // next tile: in flight during this tile's MFMAs and row phase
+      request(tl + 1, xn, gn);
+    }
     // ---- data gradient MFMA: wave = 16 pixels x 64 channels
     f32x4 acc[4];
 #pragma unroll
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
         const float v = in ? da[e] * (pre > 0.f ? 1.f : a.slope) : 0.f;
         s1[e] += v;
         s2[e] += v * fx[e];
-        o[e] = a.acc ? fmaf(sc8[e], v, o[e]) : v;
+        o[e] = ACC ? fmaf(sc8[e], v, o[e]) : v;
         act[e] = in ? (pre > 0.f ? pre : a.slope * pre) : 0.f;        // what the forward conv saw
       }
       const int pix = pq * 16 + ql, c16 = chh * 8 + piece;            // 16-byte column of the 128-channel tile
@@ -426,11 +433,20 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   };
 
   u32x4 xa[2], ga[2], xb[2], gb[2];
-  request_dy(0);
+  const std::integral_constant<bool, false> MORE;
+  const std::integral_constant<bool, true> LAST;
+  request_dy(0);                                              // my_tiles >= 1: there are never more pixel slots than tiles
   request(0, xa, ga);
-  for (int tl = 0; tl < my_tiles; tl += 2) {
-    step(tl, xa, ga, xb, gb);
-    if (tl + 1 < my_tiles) step(tl + 1, xb, gb, xa, ga);
+  int tl = 0;
+  for (; tl + 2 < my_tiles; tl += 2) {                        // steady state: both steps have a next tile to request
+    step(tl, xa, ga, xb, gb, MORE);
+    step(tl + 1, xb, gb, xa, ga, MORE);
+  }
+  if (tl + 2 == my_tiles) {
+    step(tl, xa, ga, xb, gb, MORE);
+    step(tl + 1, xb, gb, xa, ga, LAST);
+  } else {
+    step(tl, xa, ga, xb, gb, LAST);
   }
   B1_BARRIER();                                               // the last tile's activated rows are in place
   if (my_tiles > 0) wgrad_tile(dyt0 + ((my_tiles - 1) % 3) * F1_TILE, at0 + ((my_tiles - 1) & 1) * F1_TILE);
@@ -535,18 +551,26 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   if (fused) {   // 1: the caller runs the two separate kernels instead
     if (nslots * 128 * a.C > wpart_floats) return 1;
     if (wsplit_out) *wsplit_out = nslots;
-    static bool attr_f = false;
-    if (!attr_f) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bwdw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_bwdw): %s", hipGetErrorString(e));
-      attr_f = true;
-    }
     Bwdw1Args aa{a, wpart, nullptr, 0, nullptr, nullptr};
     if (dy_affine_x != nullptr) {
       aa.yb = static_cast<const unsigned short*>(dy_affine_x->ptr), aa.yb_pitch = (int)dy_affine_x->stride[2];
       aa.cB = dy_affine_b, aa.cC = dy_affine_c;
     }
-    return fd_launch(&conv1x1_bwdw_kernel, "conv1x1_bwd_wgrad_stream", dim3((unsigned)grid), dim3(512), F1_LDS, aa, stream);
+    void (*kern)(Bwdw1Args) = nullptr;
+    const bool aff = aa.yb != nullptr;
+    switch (a.acc) {
+      case 0: kern = aff ? &conv1x1_bwdw_kernel<true, 0> : &conv1x1_bwdw_kernel<false, 0>; break;
+      case 1: kern = aff ? &conv1x1_bwdw_kernel<true, 1> : &conv1x1_bwdw_kernel<false, 1>; break;
+      default: kern = aff ? &conv1x1_bwdw_kernel<true, 2> : &conv1x1_bwdw_kernel<false, 2>; break;
+    }
+    static bool attr_f[6] = {false, false, false, false, false, false};
+    const int ki = (a.acc == 0 ? 0 : (a.acc == 1 ? 1 : 2)) * 2 + (aff ? 1 : 0);
+    if (!attr_f[ki]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv1x1_bwdw): %s", hipGetErrorString(e));
+      attr_f[ki] = true;
+    }
+    return fd_launch(kern, "conv1x1_bwd_wgrad_stream", dim3((unsigned)grid), dim3(512), F1_LDS, aa, stream);
   }
   return fd_launch(&conv1x1_bwd_kernel, "conv1x1_bwd_stream", dim3((unsigned)grid), dim3(256), lds, a, stream);
 }
