@@ -282,21 +282,20 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   unsigned dym[2];
   auto request_dy = [&](int rr, auto S) __attribute__((always_inline)) {
     constexpr int s_ = decltype(S)::value;
-    if (d_wave) {
-      const int row = y_begin - 1 + rr;
-      const bool rok = row >= 0 && row < a.H && rr <= rows + 1;
-      dyr[s_] = *(b4_g16)(b4_uniform(dimg + (long long)min(max(row, 0), a.H - 1) * a.dy_sh) + dvo);
-      dym[s_] = rok && dcol ? 0xffffffffu : 0u;
-    }
+    // every wave, not only the five that stage the row (the others fetch the row's first 16 bytes, all lanes the same line):
+    // a wave-uniform `if` around this load is control flow between a load and its use, and hipcc's vmcnt counts go
+    // conservative for the whole step
+    const int row = y_begin - 1 + rr;
+    const bool rok = row >= 0 && row < a.H && rr <= rows + 1;
+    dyr[s_] = *(b4_g16)(b4_uniform(dimg + (long long)min(max(row, 0), a.H - 1) * a.dy_sh) + dvo);
+    dym[s_] = rok && dcol ? 0xffffffffu : 0u;
   };
   auto store_dy = [&](auto S, auto SLOT) __attribute__((always_inline)) {
     constexpr int s_ = decltype(S)::value, sl = decltype(SLOT)::value;
-    if (d_wave) {
-      u32x4 v = dyr[s_];
+    u32x4 v = dyr[s_];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] &= dym[s_];
-      if (d_thr) lds_write16(dwp + sl * B4_DROW, v);
-    }
+    for (int q = 0; q < 4; ++q) v[q] &= dym[s_];
+    if (d_thr) lds_write16(dwp + sl * B4_DROW, v);
   };
   // ---- x / G rows: two 16-byte units per lane (pixels pl0, pl0 + 16), wave-uniform row pointer + 32-bit lane offset
   const unsigned short* ximg = a.x + (long long)n * a.x_sn;
@@ -359,13 +358,14 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
 
   // step j (phase P = j mod 4): MFMAs of output row y_begin + j from the dy rows rr = j, j + 1, j + 2, interleaved with the
   // row phase of output row y_begin + j - 1
-  auto step = [&](int j, auto P) __attribute__((always_inline)) {
-    constexpr int p = decltype(P)::value, p2 = p & 1;
+  // RP: 1 the step has a row to finish (1 <= j <= rows: the steady state, no branch around its stores), 0 it has not, 2 decide at run time
+  auto step = [&](int j, auto P, auto RP) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value, p2 = p & 1, rpc = decltype(RP)::value;
     // dy: row rr = j + 3 (requested a step ago) into the slot row rr = j - 1 left; then request rr = j + 4
     store_dy(IC3<0>{}, IC3<(p + 3) & 3>{});
     request_dy(j + 4, IC3<0>{});
     const int yr = y_begin + j - 1;
-    const bool rp_ok = j >= 1 && j <= rows;
+    const bool rp_ok = rpc == 2 ? (j >= 1 && j <= rows) : rpc == 1;
     const float w1 = rp_ok ? 1.f : 0.f, w0 = rp_ok ? a.slope : 0.f;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
@@ -419,11 +419,24 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
     B3_BARRIER();
   };
   const int nloop = (rows + 3) & ~3;
-  for (int j = 0; j < nloop; j += 4) {
-    step(j, IC3<0>{});
-    step(j + 1, IC3<1>{});
-    step(j + 2, IC3<2>{});
-    step(j + 3, IC3<3>{});
+  int j = 0;
+  if (rows >= 3) {
+    step(0, IC3<0>{}, IC3<0>{});
+    step(1, IC3<1>{}, IC3<1>{});
+    step(2, IC3<2>{}, IC3<1>{});
+    step(3, IC3<3>{}, IC3<1>{});
+    for (j = 4; j + 3 <= rows; j += 4) {   // steady state
+      step(j, IC3<0>{}, IC3<1>{});
+      step(j + 1, IC3<1>{}, IC3<1>{});
+      step(j + 2, IC3<2>{}, IC3<1>{});
+      step(j + 3, IC3<3>{}, IC3<1>{});
+    }
+  }
+  for (; j < nloop; j += 4) {
+    step(j, IC3<0>{}, IC3<2>{});
+    step(j + 1, IC3<1>{}, IC3<2>{});
+    step(j + 2, IC3<2>{}, IC3<2>{});
+    step(j + 3, IC3<3>{}, IC3<2>{});
   }
   if (nloop == rows) {   // the last row's phase (otherwise it ran inside one of the padding steps)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
