@@ -5,8 +5,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "fd-gan_amd")]
 import torch
 import train as T
 dev = torch.device("cuda:0")
-ts = T.TrainStep(dev)
 for (B, S, n) in ((16, 256, 60), (4, 512, 6), (2, 96, 6), (1, 1024, 3), (16, 256, 3)):
+    ts = T.TrainStep(dev)      # (the image pool of a step object keeps images of ONE size, as the reference's does)
     gt = torch.rand(B, 3, S, S, device=dev); haze = (gt * 0.6 + 0.3).clamp(0, 1)
     ts.step(haze, gt); torch.cuda.synchronize()
     m0 = torch.cuda.memory_allocated(); t0 = time.time()
