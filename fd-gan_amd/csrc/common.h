@@ -10,10 +10,76 @@
 #include "../../include/fdgan_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- the two 16-bit element formats ------------------------------------------------
+// FmtA ("activation"): everything the FORWARD pass stores or multiplies -- activations, the forward filter images -- is
+//   IEEE fp16 (11-bit significand).  Measured on the CPU oracle (tools/precision_study.py): with bf16 storage the
+//   generator's output sits 46.8 dB from the fp32 reference whatever the kernels do, with fp16 at 64.4 dB; the
+//   north-star's 0.02 dB metric budget needs >= 54 dB.  Normalised activations never come near fp16's 65504.
+// FmtG ("gradient"): activation gradients and the flipped filter images the data-gradient kernels multiply them with
+//   stay bf16 -- unscaled loss gradients (1e-7 per pixel for a mean over 16 x 3 x 256 x 256) need fp32's exponent range.
+// Both are 2 bytes: layouts, strides and byte counts are identical; v_mfma_f32_16x16x32_{f16,bf16} run at the same rate.
+struct FmtA {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  typedef f16x2 v2;
+  typedef _Float16 T;
+  static constexpr int DT = FD_F16;
+};
+struct FmtG {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  typedef bf16x2 v2;
+  typedef __bf16 T;
+  static constexpr int DT = FD_BF16;
+};
+template <bool GRAD> struct FmtSel { typedef FmtA type; };
+template <> struct FmtSel<true> { typedef FmtG type; };
+
+template <class F> __device__ __forceinline__ f32x8 fd_cvt8(u32x4 raw) {
+  return __builtin_convertvector(__builtin_bit_cast(typename F::v8, raw), f32x8);
+}
+template <class F> __device__ __forceinline__ f32x4 fd_cvt4(u32x2 raw) {
+  return __builtin_convertvector(__builtin_bit_cast(typename F::v4, raw), f32x4);
+}
+template <class F> __device__ __forceinline__ f32x2 fd_cvt2(unsigned raw) {
+  return __builtin_convertvector(__builtin_bit_cast(typename F::v2, raw), f32x2);
+}
+template <class F> __device__ __forceinline__ float fd_cvt1(unsigned short raw) {
+  return (float)__builtin_bit_cast(typename F::T, raw);
+}
+template <class F> __device__ __forceinline__ u32x4 fd_pk8(f32x8 f) {
+  return __builtin_bit_cast(u32x4, __builtin_convertvector(f, typename F::v8));
+}
+template <class F> __device__ __forceinline__ u32x2 fd_pk4(f32x4 f) {
+  return __builtin_bit_cast(u32x2, __builtin_convertvector(f, typename F::v4));
+}
+template <class F> __device__ __forceinline__ unsigned fd_pk2(f32x2 f) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, typename F::v2));
+}
+template <class F> __device__ __forceinline__ unsigned short fd_pk1(float f) {
+  return __builtin_bit_cast(unsigned short, (typename F::T)f);
+}
+// D = A x B + C on one 16 x 16 x 32 tile; operands as raw 16-byte fragments
+template <class F> __device__ __forceinline__ f32x4 fd_mfma(u32x4 a, u32x4 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 fd_mfma<FmtA>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 fd_mfma<FmtG>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 fd_mfma_a(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 fd_mfma_g(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // ---- tuning switches ------------------------------------------------------------
 // Kernel-selection / phase-skipping switches used by tools/ while tuning.  They exist only in builds made with

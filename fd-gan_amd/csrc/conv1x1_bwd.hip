@@ -41,7 +41,7 @@ struct Bwd1Args {
   int dy_pitch, Cy;
   const unsigned short* w;    // chunk32 filter image of the (flipped = same for 1x1) forward filter: A fragments
   int ntile_total;            // ceil(C / 16)
-  const unsigned short* x;    // forward input, [P][x_pitch]
+  const unsigned short* x;    // forward input (fp16), [P][x_pitch]
   int x_pitch;
   unsigned short* g;          // gradient buffer (accumulate) or dpre
   int g_pitch;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
     for (int i = 0; i < 4; ++i) {
       const int ql = i * 4 + q0;
       const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, lds_read16(tb + ql * B1_TBP + piece * 16)), f32x8);
-      const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+      const f32x8 fx = fd_cvt8<FmtA>(xv[i]);                  // the forward input: fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -248,7 +248,7 @@ struct Bwdw1Args {
   // pending linear part of the BatchNorm backward of dy's OWN producer (the growth conv's norm2): dy' = dy + cB * yb + cC per
   // channel, yb = that norm's input (the bottleneck activation).  Applied while the dy tile is staged, so the separate
   // read-read-write pass over the 128-channel gradient buffer (affine_accumulate) is not needed.  NULL: dy is final.
-  const unsigned short* yb;   // [P][yb_pitch], 128 channels
+  const unsigned short* yb;   // [P][yb_pitch], 128 channels, fp16
   int yb_pitch;
   const float *cB, *cC;       // [128]
 };
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
       u32x4 v = dyr[i];
       if (AFFINE) {     // dy' = dy + cB * yb + cC, rounded to bf16 exactly as the separate pass stored it
         f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
-        const f32x8 y8 = __builtin_convertvector(__builtin_bit_cast(bf16x8, ybr[i]), f32x8);
+        const f32x8 y8 = fd_cvt8<FmtA>(ybr[i]);               // the bottleneck activation: fp16
         f = __builtin_elementwise_fma(cb8, y8, f + cc8);        // packed fp32: 8 instructions
         v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
       }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     for (int i = 0; i < 2; ++i) {
       const int ql = i * 8 + ql0;
       const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, lds_read16(tb + ql * F1_TBP + piece * 16)), f32x8);
-      const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+      const f32x8 fx = fd_cvt8<FmtA>(xv[i]);                  // the forward input: fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
       f32x8 act;
 #pragma unroll

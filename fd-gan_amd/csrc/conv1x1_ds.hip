@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
     for (int j = 0; j < 2; ++j) {
       const int cb = ks * 64 + g * 16 + j * 8;
       const bool cok = cb < cmax;
-      bf16x8 xf[DS_PT];
+      f16x8 xf[DS_PT];
       u32x4 raw[DS_PT];
 #pragma unroll
       for (int p = 0; p < DS_PT; ++p) raw[p] = lds_read16(act + boff[p][j]);
@@ -208,18 +208,18 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
       for (int p = 0; p < DS_PT; ++p) {
         // a pixel past the end / a channel group past Cin must contribute exactly zero
         const bool ok = cok && (full || (unsigned)tile * DS_PX + wave * C::WPX + p * 16 + m < a.P);
-        xf[p] = __builtin_bit_cast(bf16x8, ok ? raw[p] : zero4);
+        xf[p] = __builtin_bit_cast(f16x8, ok ? raw[p] : zero4);
       }
 #pragma unroll
       for (int c0 = 0; c0 < DS_CT; c0 += 4) {
-        bf16x8 wf[4];
+        f16x8 wf[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + (j * DS_CT + c0 + c) * 1024));
+        for (int c = 0; c < 4; ++c) wf[c] = __builtin_bit_cast(f16x8, lds_read16(wfrag + (j * DS_CT + c0 + c) * 1024));
 #pragma unroll
         for (int p = 0; p < DS_PT; ++p)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            acc[p][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[p][c0 + c], 0, 0, 0);
+            acc[p][c0 + c] = fd_mfma_a(wf[c], xf[p], acc[p][c0 + c]);
       }
     }
 

@@ -146,9 +146,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        // registers -> activated bf16 fragments; the freed registers take the next loads (next k-step,
+        // registers -> activated fp16 fragments; the freed registers take the next loads (next k-step,
         // or the next tile's first k-step), which stay in flight while the MFMAs / the epilogue run
-        bf16x8 xf[PT];
+        f16x8 xf[PT];
         const int cb = ks * 64 + g * 16 + j * 8;
         const bool cok = cb < cmax;
         const float* sc = sc_lds + cb;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
           }
           // a pixel past the end / a channel group past Cin must contribute exactly zero
           const bool ok = cok && (full || px0 + p * 16 < a.P);
-          xf[p] = __builtin_bit_cast(bf16x8, ok ? v : zero4);
+          xf[p] = __builtin_bit_cast(f16x8, ok ? v : zero4);
         }
         if (!last) {
           load(ks + 1, j);
@@ -183,15 +183,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
         constexpr int CH = CT > 4 ? 4 : CT;  // filter fragments live at a time
 #pragma unroll
         for (int c0 = 0; c0 < CT; c0 += CH) {
-          bf16x8 wf[CH];
+          f16x8 wf[CH];
 #pragma unroll
           for (int c = 0; c < CH; ++c)
-            wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wfrag + ((kl * 2 + j) * CT + c0 + c) * 1024));
+            wf[c] = __builtin_bit_cast(f16x8, lds_read16(wfrag + ((kl * 2 + j) * CT + c0 + c) * 1024));
 #pragma unroll
           for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int c = 0; c < CH; ++c)
-              acc[p][c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[p][c0 + c], 0, 0, 0);
+              acc[p][c0 + c] = fd_mfma_a(wf[c], xf[p], acc[p][c0 + c]);
         }
       }
     }

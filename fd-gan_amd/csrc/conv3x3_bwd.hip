@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd_kernel(Bwd3Args a) {
     for (int i = 0; i < 2; ++i) {
       const int pl = i * 8 + ql, px = xbase + pxq * 16 + pl;
       const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, lds_read16(tb + pl * B3_TBP + piece * 16)), f32x8);
-      const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
+      const f32x8 fx = fd_cvt8<FmtA>(xv[i]);      // the forward input: fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
       const bool ok = px < a.W;
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   // (w1, w0): the activation's two slopes, or (0, 0) when the step has no row to finish -- uniform VALUES, not a branch
   auto row_unit = [&](u32x4 dat, u32x4 xv, u32x4 gv, float w1, float w0) __attribute__((always_inline)) -> u32x4 {
     const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dat), f32x8);
-    const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv), f32x8);
+    const f32x8 fx = fd_cvt8<FmtA>(xv);         // the forward input: fp16
     f32x8 o;
     if constexpr (ACC == 1) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv), f32x8);
 #pragma unroll

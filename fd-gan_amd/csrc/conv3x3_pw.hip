@@ -223,21 +223,21 @@ __global__ __launch_bounds__(PW_NT, 2) void conv3x3_pw_kernel(ConvArgs a) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         // the 10 input rows of this wave, read once per column shift and shared by the three row taps
-        bf16x8 xr[PW_PT + 2];
+        f16x8 xr[PW_PT + 2];
 #pragma unroll
         for (int r = 0; r < PW_PT + 2; ++r)
-          xr[r] = __builtin_bit_cast(bf16x8, lds_read16(xb + (r * PW_IW + dx) * 16));
+          xr[r] = __builtin_bit_cast(f16x8, lds_read16(xb + (r * PW_IW + dx) * 16));
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          bf16x8 wf[PW_CT];
+          f16x8 wf[PW_CT];
 #pragma unroll
           for (int c = 0; c < PW_CT; ++c)
-            wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wb + ((dy * 3 + dx) * PW_CT + c) * 1024));
+            wf[c] = __builtin_bit_cast(f16x8, lds_read16(wb + ((dy * 3 + dx) * PW_CT + c) * 1024));
 #pragma unroll
           for (int p = 0; p < PW_PT; ++p)
 #pragma unroll
             for (int c = 0; c < PW_CT; ++c)
-              acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xr[p + dy], acc[p][c], 0, 0, 0);
+              acc[p][c] = fd_mfma_a(wf[c], xr[p + dy], acc[p][c]);
         }
       }
       __syncthreads();

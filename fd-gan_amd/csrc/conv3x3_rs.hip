@@ -363,7 +363,7 @@ __device__ __forceinline__ void rs_compute(const ConvArgs& a, const char* ring, 
                                            int nwg, RsTimer& tm) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int m = lane & 15, g = lane >> 4;
-  bf16x8 wf[9][RS_CT];   // this wave's quarter of the filter: channels [32w, 32w+32), all taps
+  f16x8 wf[9][RS_CT];   // this wave's quarter of the filter: channels [32w, 32w+32), all taps
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -371,7 +371,7 @@ __device__ __forceinline__ void rs_compute(const ConvArgs& a, const char* ring, 
       const bool ok = c < a.ntile_total;
       const u32x4 v = *reinterpret_cast<const u32x4*>(
           a.w + (ok ? ((long long)(w * 9 + t) * a.ntile_total + c) * 512 + lane * 8 : 0));
-      wf[t][c] = __builtin_bit_cast(bf16x8, ok ? v : zero4);
+      wf[t][c] = __builtin_bit_cast(f16x8, ok ? v : zero4);
     }
   int boff[3];   // B fragment: pixel m + dx, 16-byte chunk 4w + g
 #pragma unroll
@@ -398,17 +398,17 @@ __device__ __forceinline__ void rs_compute(const ConvArgs& a, const char* ring, 
       if (!(a.dbg_skip & 4)) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          bf16x8 xr[RS_R + 2];
+          f16x8 xr[RS_R + 2];
 #pragma unroll
-          for (int r = 0; r < RS_R + 2; ++r) xr[r] = __builtin_bit_cast(bf16x8, lds_read16(rb[r] + boff[dx]));
+          for (int r = 0; r < RS_R + 2; ++r) xr[r] = __builtin_bit_cast(f16x8, lds_read16(rb[r] + boff[dx]));
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int p = 0; p < RS_R; ++p)
 #pragma unroll
               for (int c = 0; c < RS_CT; ++c)
-                acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + dx][c], xr[p + dy],
-                                                                   (dx == 0 && dy == 0) ? fzero : acc[p][c], 0, 0, 0);
+                acc[p][c] = fd_mfma_a(wf[dy * 3 + dx][c], xr[p + dy],
+                                                                   (dx == 0 && dy == 0) ? fzero : acc[p][c]);
         }
       } else {
 #pragma unroll
@@ -529,14 +529,14 @@ __device__ __forceinline__ void r2_barrier() {   // all LDS operations of this w
 
 // ---- compute wave w: input channels [32w, 32w+32).  TM = t mod 4.
 template <int TM>
-__device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], char* red_lane, const bf16x8 (&wf)[9][RS_CT],
-                                                bf16x8 (&X)[2][RS_R + 2], RsTimer& tm) {
+__device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], char* red_lane, const f16x8 (&wf)[9][RS_CT],
+                                                f16x8 (&X)[2][RS_R + 2], RsTimer& tm) {
   constexpr int PAR = TM & 1, S0 = (4 * TM) & (R2_NR - 1);
   const f32x4 fzero = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[RS_R][RS_CT];
   auto xread = [&](int dx, int r) __attribute__((always_inline)) {   // B fragment of ring row S0 + r, column shift dx
     const int s = (S0 + r) & (R2_NR - 1);
-    return __builtin_bit_cast(bf16x8, lds_read16(xb[dx][s >> 3] + (s & 7) * RS_ROW_B));
+    return __builtin_bit_cast(f16x8, lds_read16(xb[dx][s >> 3] + (s & 7) * RS_ROW_B));
   };
   __builtin_amdgcn_sched_barrier(0);
   // block 0 (dx = 0, fragments X[PAR]) while the dx = 1 fragments arrive
@@ -548,7 +548,7 @@ __device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], c
     for (int pp = 0; pp < RS_R; ++pp)
 #pragma unroll
       for (int c = 0; c < RS_CT; ++c)
-        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3][c], X[PAR][pp + dy], dy == 0 ? fzero : acc[pp][c], 0, 0, 0);
+        acc[pp][c] = fd_mfma_a(wf[dy * 3][c], X[PAR][pp + dy], dy == 0 ? fzero : acc[pp][c]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -564,7 +564,7 @@ __device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], c
     for (int pp = 0; pp < RS_R; ++pp)
 #pragma unroll
       for (int c = 0; c < RS_CT; ++c)
-        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + 1][c], X[PAR ^ 1][pp + dy], acc[pp][c], 0, 0, 0);
+        acc[pp][c] = fd_mfma_a(wf[dy * 3 + 1][c], X[PAR ^ 1][pp + dy], acc[pp][c]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
@@ -581,7 +581,7 @@ __device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], c
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int c = 0; c < RS_CT; ++c)
-        acc[pp][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[dy * 3 + 2][c], X[PAR][pp + dy], acc[pp][c], 0, 0, 0);
+        acc[pp][c] = fd_mfma_a(wf[dy * 3 + 2][c], X[PAR][pp + dy], acc[pp][c]);
 #pragma unroll
     for (int c = 0; c < RS_CT; ++c)
       *reinterpret_cast<f32x4*>(red_lane + PAR * RS_RED_B + pp * (RS_R * RS_CT * 1024) + c * 1024) = acc[pp][c];
@@ -609,12 +609,12 @@ __device__ __forceinline__ void r2_compute_step(const char* const (&xb)[3][2], c
 
 __device__ __forceinline__ void r2_compute(const ConvArgs& a, const char* ring, char* red, int w, int lane, int bid, int nwg, RsTimer& tm) {
   const int m = lane & 15, g = lane >> 4;
-  bf16x8 wf[9][RS_CT];   // this wave's quarter of the filter: channels [32w, 32w+32), all taps
+  f16x8 wf[9][RS_CT];   // this wave's quarter of the filter: channels [32w, 32w+32), all taps
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int c = 0; c < RS_CT; ++c)
-      wf[t][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.w + ((long long)(w * 9 + t) * RS_CT + c) * 512 + lane * 8));
+      wf[t][c] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a.w + ((long long)(w * 9 + t) * RS_CT + c) * 512 + lane * 8));
   const char* xb[3][2];   // B fragment: pixel m + dx, 16-byte chunk 4w + g, of ring rows 0 / 8
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
@@ -622,14 +622,14 @@ __device__ __forceinline__ void r2_compute(const ConvArgs& a, const char* ring, 
     xb[dx][1] = xb[dx][0] + 8 * RS_ROW_B;
   }
   char* red_lane = red + w * (RS_CT * 1024) + lane * 16;
-  bf16x8 X[2][RS_R + 2];
+  f16x8 X[2][RS_R + 2];
   r2_barrier<0>();   // F
 
   for (int item = bid; item < a.ntiles; item += nwg) {
     const int n = rs_item(a, item).n_iter;
     r2_barrier<0>();   // P: groups 0 and 1 are in the ring
 #pragma unroll
-    for (int r = 0; r < RS_R + 2; ++r) X[0][r] = __builtin_bit_cast(bf16x8, lds_read16(xb[0][0] + r * RS_ROW_B));
+    for (int r = 0; r < RS_R + 2; ++r) X[0][r] = __builtin_bit_cast(f16x8, lds_read16(xb[0][0] + r * RS_ROW_B));
     int t = 0;
     for (; t + 4 <= n; t += 4) {
       r2_compute_step<0>(xb, red_lane, wf, X, tm);
@@ -653,7 +653,6 @@ template <int XMODE>
 __device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const char* red, const float* sc_lds, const float* sh_lds,
                                           float* stat_red, char* rowstage, int hw, int lane, int bid, int nwg, RsTimer& tm) {
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
   const int h = hw & 3, par = hw >> 2;
   const int tc = lane & 15, tp = lane >> 4;   // fetch / prologue: 16-byte channel chunk, pixel within a group of 4
   const int m = lane & 15, g = lane >> 4;     // epilogue (MFMA result layout): pixel m, couts g*4.. of tile c
@@ -732,7 +731,7 @@ __device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const c
       for (int it = 0; it < 5; ++it) lds_write16(row + xf_off(it), src[it]);
     };
     const char* rbuf = red_lane;
-    // sum of the four K-partials, statistics; the row goes to the wave's staging tile as bf16 [pixel][32 channels] and is read
+    // sum of the four K-partials, statistics; the row goes to the wave's staging tile as fp16 [pixel][32 channels] and is read
     // back one pixel quarter per lane and stored in phase B
     auto epilogue = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -750,7 +749,7 @@ __device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const c
           v[2 * r] = t[0];
           v[2 * r + 1] = t[1];
         }
-        *reinterpret_cast<u32x2*>(tb_w + c * 32) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4_t));
+        *reinterpret_cast<u32x2*>(tb_w + c * 32) = fd_pk4<FmtA>(v);
       }
     };
     auto flush_staged = [&]() __attribute__((always_inline)) {

@@ -41,7 +41,7 @@ constexpr int WG_ROWB = WG_KPX * 2 + 16;    // bytes per channel row (16-byte al
 constexpr int WG_TILE_B = 64 * WG_ROWB;     // one operand tile
 
 struct WgradArgs {
-  const unsigned short* x;    // raw forward input (NHWC bf16)
+  const unsigned short* x;    // raw forward input (NHWC fp16)
   long long x_sn;
   int x_sh, x_sw;
   int Hs, Ws, Cin, Cin8;
@@ -76,10 +76,10 @@ __device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s
     f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sw), sc_s, sh_s, a.p_slope);
     f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh), sc_s, sh_s, a.p_slope);
     f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw), sc_s, sh_s, a.p_slope);
-    return fd_pack8(f * 0.25f);
+    return fd_pack8<FmtG>(f * 0.25f);   // fp16 in, the bf16 operand out
   }
   if (iy < 0 || iy >= a.Hs || ix < 0 || ix >= a.Ws) return zero4;   // zero padding of the activated input
-  raw = a.pro_mode != 0;   // transformed by the caller just before the LDS store (keeps the load in flight over the MFMAs)
+  raw = true;   // fp16 -> (prologue) -> bf16 by the caller just before the LDS store (keeps the load in flight over the MFMAs)
   return *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci_off);
 }
 
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
     for (int u = 0; u < UPT; ++u) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (xraw & (1u << (u * 4 + j))) xv[u][j] = fd_xform8(xv[u][j], sc_s + (chunk0 + CHUNK_STEP * u) * 8, sh_s + (chunk0 + CHUNK_STEP * u) * 8, a.p_slope);
+        if (xraw & (1u << (u * 4 + j)))
+          xv[u][j] = fd_xform8<FmtA, FmtG>(xv[u][j], sc_s + (chunk0 + CHUNK_STEP * u) * 8, sh_s + (chunk0 + CHUNK_STEP * u) * 8, a.pro_mode != 0 ? a.p_slope : 1.f);
       wg_store_transposed(At, (chunk0 + CHUNK_STEP * u) * 8, px4, xv[u]);
       wg_store_transposed(Dt, (chunk0 + CHUNK_STEP * u) * 8, px4, dv[u]);
     }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3Args a) {
       sv[j] = zero4;
       if (rok && px >= 0 && px < a.W) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + (long long)row * a.x_sh + (long long)px * a.x_sw);
-        sv[j] = a.pro_mode != 0 ? fd_xform8(v, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope) : v;   // padding stays zero
+        sv[j] = fd_xform8<FmtA, FmtG>(v, sc_s + chunk * 8, sh_s + chunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);   // fp16 x -> bf16 operand; padding stays zero
       }
     }
 #pragma unroll
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
       for (int k = 0; k < 4; ++k) {
         if (dp[k] == nullptr) continue;
         const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dvv[k]), f32x8);
-        const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xvv[k]), f32x8);
+        const f32x8 xf = fd_cvt8<FmtA>(xvv[k]);     // the forward input: fp16
         f32x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
       for (int k = 0; k < 4; ++k) {
         if (op[k] == nullptr) continue;
         const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dv[k]), f32x8);
-        const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[k]), f32x8);
+        const f32x8 xf = fd_cvt8<FmtA>(xv[k]);      // the forward input: fp16
         f32x8 o;
         if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
       const unsigned short* dp = a.dy + (long long)n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw;
       for (int co = 0; co < a.Cout; ++co)
         s = fmaf(__uint_as_float((unsigned)dp[co] << 16),
-                 (float)(__bf16)a.w[(((long long)co * a.Cin + ci) * a.ks + ky) * a.ks + kx], s);   // the forward's bf16 filter
+                 (float)(_Float16)a.w[(((long long)co * a.Cin + ci) * a.ks + ky) * a.ks + kx], s);   // the forward's fp16 filter
     }
   }
   if (a.dx != nullptr)
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256) void dgrad_direct_kernel(DgradDirectArgs a) {
 
 // Same gradient, one thread per input PIXEL with all CIN channels in registers (network inputs have 3 / 9 / 16
 // channels): every dy vector is loaded once per tap instead of once per (tap, channel, filter), and the filter --
-// rounded to bf16 as the forward used it -- sits in LDS as [tap][ci][co].  (The per-element kernel above took 2.4 ms
+// rounded to fp16 as the forward used it -- sits in LDS as [tap][ci][co].  (The per-element kernel above took 2.4 ms
 // for the discriminator's 9-channel 256x256 input.)
 template <int CIN>
 __global__ __launch_bounds__(256) void dgrad_direct_px_kernel(DgradDirectArgs a) {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256) void dgrad_direct_px_kernel(DgradDirectArgs a)
   const int co8 = (a.Cout + 7) / 8, cop = co8 * 8, kk = a.ks * a.ks;
   for (int i = threadIdx.x; i < kk * CIN * cop; i += 256) {
     const int co = i % cop, ci = (i / cop) % CIN, tap = i / (cop * CIN);
-    w_s[i] = co < a.Cout ? (float)(__bf16)a.w[((long long)co * CIN + ci) * kk + tap] : 0.f;
+    w_s[i] = co < a.Cout ? (float)(_Float16)a.w[((long long)co * CIN + ci) * kk + tap] : 0.f;
   }
   __syncthreads();
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -889,18 +890,21 @@ __global__ __launch_bounds__(256) void grad_ew_kernel(GradEwArgs a) {
     o = (ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y, 2 * x) + ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y, 2 * x + 1)) +
         (ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y + 1, 2 * x) + ld(a.src, a.s_sn, a.s_sh, a.s_sw, 2 * y + 1, 2 * x + 1));
   } else {
-    const f32x8 s_ = ld(a.src, a.s_sn, a.s_sh, a.s_sw, y, x), rf = ld(a.ref, a.r_sn, a.r_sh, a.r_sw, y, x);
+    const f32x8 s_ = ld(a.src, a.s_sn, a.s_sh, a.s_sw, y, x);
+    const f32x8 rf = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(a.ref + n * a.r_sn + (long long)y * a.r_sh + (long long)x * a.r_sw + c8 * 8));   // a stored activation: fp16
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = rf[e] > 0.f ? s_[e] : 0.f;
   }
   *reinterpret_cast<u32x4*>(dp) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
 }
 
-int check_view(const FdTensor* t, const char* what) {
+// dtype: FD_F16 for a forward activation, FD_BF16 for a gradient
+int check_view(const FdTensor* t, const char* what, int dtype = FD_BF16) {
   FD_REQUIRE(t && t->ptr, "%s: NULL tensor", what);
-  FD_REQUIRE(t->dtype == FD_BF16 && t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 &&
+  FD_REQUIRE(t->dtype == dtype, "%s: %s view expected (dtype %d)", what, dtype == FD_F16 ? "an NHWC fp16 activation" : "an NHWC bf16 gradient", t->dtype);
+  FD_REQUIRE(t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 &&
                  ((uintptr_t)t->ptr & 15) == 0,
-             "%s: NHWC bf16 view with 8-element aligned strides expected", what);
+             "%s: NHWC 16-bit view with 8-element aligned strides expected", what);
   return FD_OK;
 }
 
@@ -919,7 +923,7 @@ void fill_pro(const FdPrologue* pro, int& mode, float& slope, float& eps, const 
 extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
                                        float* dw, float* dbias, float* workspace, int64_t workspace_floats,
                                        int accumulate, FdStream stream) {
-  if (int rc = check_view(x, "conv2d_bwd_weight(x)")) return rc;
+  if (int rc = check_view(x, "conv2d_bwd_weight(x)", FD_F16)) return rc;
   if (int rc = check_view(dy, "conv2d_bwd_weight(dy)")) return rc;
   FD_REQUIRE(d && dw, "conv2d_bwd_weight: NULL descriptor / dw");
   FD_REQUIRE(!d->upsample2, "conv2d_bwd_weight: pass the gradient of the PRE-upsample output (fdgan_grad_ew mode 2)");
@@ -1071,7 +1075,7 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
 extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
                                 int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
   if (int rc = check_view(da, "bn_act_bwd(da)")) return rc;
-  if (int rc = check_view(x, "bn_act_bwd(x)")) return rc;
+  if (int rc = check_view(x, "bn_act_bwd(x)", FD_F16)) return rc;
   const bool pooled = pro && pro->pool2;
   FD_REQUIRE(da->n == x->n && da->c == x->c && (pooled ? (da->h == x->h / 2 && da->w == x->w / 2 && x->h % 2 == 0 && x->w % 2 == 0)
                                                        : (da->h == x->h && da->w == x->w)),
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (op[k] == nullptr) continue;
-      const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[k]), f32x8);
+      const f32x8 xf = fd_cvt8<FmtA>(xv[k]);      // the normalised tensor: a forward activation, fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += fmaf(B[e], xf[e], Cc[e]);
@@ -1228,7 +1232,7 @@ extern "C" int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const 
 }
 
 extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream) {
-  if (int rc = check_view(x, "affine_accumulate(x)")) return rc;
+  if (int rc = check_view(x, "affine_accumulate(x)", FD_F16)) return rc;
   if (int rc = check_view(dx, "affine_accumulate(dx)")) return rc;
   FD_REQUIRE(bsum && csum && dx->n == x->n && dx->h == x->h && dx->w == x->w && dx->c == x->c, "affine_accumulate: shape mismatch");
   AffineAccArgs a{};
@@ -1250,7 +1254,7 @@ extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, con
 extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const FdPrologue* pro, const float* dgamma,
                                   const float* dbeta, const FdTensor* dx, int accumulate, FdStream stream) {
   if (int rc = check_view(dpre, "bn_bwd_apply(dpre)")) return rc;
-  if (int rc = check_view(x, "bn_bwd_apply(x)")) return rc;
+  if (int rc = check_view(x, "bn_bwd_apply(x)", FD_F16)) return rc;
   if (int rc = check_view(dx, "bn_bwd_apply(dx)")) return rc;
   FD_REQUIRE(pro && pro->mean && pro->var && dgamma && dbeta, "bn_bwd_apply: needs the forward batch statistics and dgamma/dbeta");
   const bool pooled = pro->pool2 != 0;
@@ -1335,7 +1339,7 @@ extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref,
   a.src = static_cast<const unsigned short*>(src->ptr);
   a.s_sn = src->stride[0], a.s_sh = (int)src->stride[1], a.s_sw = (int)src->stride[2];
   if (mode == 3) {
-    if (int rc = check_view(ref, "grad_ew(ref)")) return rc;
+    if (int rc = check_view(ref, "grad_ew(ref)", FD_F16)) return rc;
     FD_REQUIRE(ref->n == dst->n && ref->h == dst->h && ref->w == dst->w && ref->c == dst->c, "grad_ew: ref shape mismatch");
     a.ref = static_cast<const unsigned short*>(ref->ptr);
     a.r_sn = ref->stride[0], a.r_sh = (int)ref->stride[1], a.r_sw = (int)ref->stride[2];

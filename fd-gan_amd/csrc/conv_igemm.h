@@ -1,10 +1,10 @@
-// conv_igemm.h -- NHWC bf16 implicit-GEMM convolution on gfx950 MFMA.
+// conv_igemm.h -- NHWC fp16 (forward) / bf16 (gradients) implicit-GEMM convolution on gfx950 MFMA.
 //
 //   y = act_e( conv( pool?( act_p( bn?(x) ) ) ) + bias )  [nearest x2]  (+ batch statistics)
 //
 // GEMM view: D[cout][pixel] = sum_k W[cout][k] * A[k][pixel], k = (tap, cin).
 // The filter is the MFMA "A" operand and the pixels the "B" operand, so that a lane
-// of the v_mfma_f32_16x16x32_bf16 result holds 4 CONSECUTIVE output channels of one
+// of the v_mfma_f32_16x16x32_{f16,bf16} result holds 4 CONSECUTIVE output channels of one
 // pixel (an 8-byte NHWC store) instead of 4 pixels of one channel.
 //
 // One workgroup = TH x 16 output pixels of one image x BN output channels:
@@ -58,8 +58,9 @@ struct ConvArgs {
   int stats_cpad;
   // backward-data epilogue (generic kernel only): the stored value is acc * act'(bn(fx)) with fx the FORWARD conv's raw
   // input at the output position, and the statistics are (sum v, sum v * fx) instead of (sum y, sum y^2)
-  int mk_mode;                  // 0 off, 1 activation only, 2 BatchNorm + activation
-  const unsigned short* mk_x;   // NHWC bf16, same n/h/w as y, >= Cout channels
+  int grad_io;                  // x, the filter image and a 16-bit y are bf16 gradients (the MK instantiations); else fp16 activations
+  int mk_mode;                  // 0 off (plain store), 1 activation only, 2 BatchNorm + activation
+  const unsigned short* mk_x;   // NHWC fp16 (a forward activation), same n/h/w as y, >= Cout channels
   long long mk_sn;
   int mk_sh, mk_sw;
   float mk_slope, mk_eps;
@@ -79,7 +80,7 @@ struct ConvArgs {
   int kgroup;   // k-steps of the filter resident in LDS at a time (>= nks: whole filter)
   int x_dense;  // x offset of pixel p is p * x_sw (no pooling, contiguous n/h/w)
   int y_dense;  // y offset of pixel p is p * y_sw (no upsample, contiguous n/h/w, NHWC)
-  int y_vec16;  // NHWC bf16 output, 16-byte aligned rows, no upsample: row stores allowed
+  int y_vec16;  // NHWC 16-bit output, 16-byte aligned rows, no upsample: row stores allowed
   int dbg_skip;             // measurement aid: phases to skip (FDGAN_DEBUG_PHASES), 0 in production
   unsigned long long* dbg;  // measurement aid: per-wave phase cycle totals of workgroup 0 (or NULL)
 };
@@ -87,9 +88,11 @@ struct ConvArgs {
 __device__ __forceinline__ u32x4 lds_read16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void lds_write16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-// bf16x8 (as 4 dwords) -> max(t, slope*t), t = x*sc+sh.  sc/sh point at 8 floats in LDS.
+// 8 x 16-bit (as 4 dwords) -> max(t, slope*t), t = x*sc+sh.  sc/sh point at 8 floats in LDS.  F: element format of x (and of
+// what the transform packs): FmtA in every forward kernel.
+template <class F = FmtA>
 __device__ __forceinline__ f32x8 fd_affine_act(u32x4 raw, const float* sc, const float* sh, float slope) {
-  f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, raw), f32x8);
+  f32x8 f = fd_cvt8<F>(raw);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
   const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
 #pragma unroll
@@ -101,16 +104,17 @@ __device__ __forceinline__ f32x8 fd_affine_act(u32x4 raw, const float* sc, const
   for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], slope * f[e]);
   return f;
 }
+template <class F = FmtA>
 __device__ __forceinline__ u32x4 fd_pack8(f32x8 f) {
-  return __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+  return fd_pk8<F>(f);
 }
 
-// BatchNorm + ReLU on 8 bf16 channels in 20 VALU ops: 8 widening shifts/ands, 4 v_pk_fma_f32,
-// 4 v_cvt_pk_bf16_f32 and the ReLU as 4 v_pk_max_i16 on the packed result (a negative bf16 is a
+// BatchNorm + ReLU on 8 channels in 20 VALU ops: 8 widening conversions, 4 v_pk_fma_f32,
+// 4 v_cvt_pk_{f16,bf16}_f32 and the ReLU as 4 v_pk_max_i16 on the packed result (a negative fp16 / bf16 is a
 // negative int16; rounding is monotone, so relu(round(t)) == round(relu(t))).
+template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const float* sh) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef f32x2 f32x2_t;
   typedef __attribute__((ext_vector_type(2))) short s16x2_t;
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
   const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
@@ -119,9 +123,9 @@ __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const f
   u32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f32x2_t f = {__uint_as_float(raw[i] << 16), __uint_as_float(raw[i] & 0xffff0000u)};
+    f32x2_t f = fd_cvt2<F>(raw[i]);
     f = __builtin_elementwise_fma(f, sv[i], hv[i]);
-    const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+    const s16x2_t pk = __builtin_bit_cast(s16x2_t, fd_pk2<FO>(f));
     out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
   }
   return out;
@@ -129,32 +133,36 @@ __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const f
 
 // Register-operand forms (scale/shift already fetched from LDS): used where one lane applies the
 // same 8 channels to several units, so the 4 LDS reads are paid once instead of per unit.
+template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_xform8_r(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 h0, f32x4 h1, float slope) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef f32x2 f32x2_t;
   typedef __attribute__((ext_vector_type(2))) short s16x2_t;
   const f32x2_t sv[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
   const f32x2_t hv[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
   u32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f32x2_t f = {__uint_as_float(raw[i] << 16), __uint_as_float(raw[i] & 0xffff0000u)};
+    f32x2_t f = fd_cvt2<F>(raw[i]);
     f = __builtin_elementwise_fma(f, sv[i], hv[i]);
     if (slope == 0.f) {   // uniform: ReLU on the packed result
-      const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+      const s16x2_t pk = __builtin_bit_cast(s16x2_t, fd_pk2<FO>(f));
       out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
     } else {
       f = __builtin_elementwise_max(f, f * slope);
-      out[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+      out[i] = fd_pk2<FO>(f);
     }
   }
   return out;
 }
 
 // prologue transform of one 8-channel unit (no pooling): uniform dispatch on the activation
+// F: format of the raw input, FO: format of the result.  <FmtA, FmtG> is what the weight-gradient kernels use: the fp16
+// forward input becomes the bf16 operand multiplied with the bf16 dy (always applied there -- with scale 1, shift 0,
+// slope 1 it is the plain format conversion).
+template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_xform8(u32x4 raw, const float* sc, const float* sh, float slope) {
-  if (slope == 0.f) return fd_bn_relu8(raw, sc, sh);
-  return fd_pack8(fd_affine_act(raw, sc, sh, slope));
+  if (slope == 0.f) return fd_bn_relu8<F, FO>(raw, sc, sh);
+  return fd_pack8<FO>(fd_affine_act<F>(raw, sc, sh, slope));
 }
 
 // Once per workgroup: BatchNorm -> per-channel (scale, shift) in LDS for channels [0, nch);
@@ -257,19 +265,18 @@ __device__ __forceinline__ float fd_row_sum16(float v) {
 }
 
 // Store 4 consecutive output channels (cout0 .. cout0+3) of one pixel; `off` is the element
-// offset of the pixel (n, up*oy, up*ox) in y.  Handles NCHW fp32 / NHWC bf16, the 2x2
-// replication of the nearest upsample and the ragged last channel group.
-template <bool ACC = false>
+// offset of the pixel (n, up*oy, up*ox) in y.  Handles NCHW fp32 / NHWC 16-bit, the 2x2
+// replication of the nearest upsample and the ragged last channel group.  F: element format of a 16-bit y.
+template <bool ACC = false, class F = FmtA>
 __device__ __forceinline__ void fd_store4(const ConvArgs& a, long long off, int cout0, const float (&v)[4]) {
   if (!a.out_nchw_f32) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-    typedef __attribute__((ext_vector_type(4))) float f4_t;
+    typedef f32x4 f4_t;
     unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + off + cout0;
     f4_t fv = {v[0], v[1], v[2], v[3]};
     if constexpr (ACC) {   // backward data into a gradient buffer (no upsample, Cout % 4 == 0 checked by the host)
-      fv += __builtin_convertvector(__builtin_bit_cast(bf16x4_t, *reinterpret_cast<const u32x2*>(yp)), f4_t);
+      fv += fd_cvt4<F>(*reinterpret_cast<const u32x2*>(yp));
     }
-    const u32x2 bits = __builtin_bit_cast(u32x2, __builtin_convertvector(fv, bf16x4_t));
+    const u32x2 bits = fd_pk4<F>(fv);
     if (cout0 + 4 <= a.Cout && !a.upsample) {  // the common case
       *reinterpret_cast<u32x2*>(yp) = bits;
       return;
@@ -315,18 +322,16 @@ struct RowStore {
   static constexpr int NIT = (16 + PPI - 1) / PPI;   // store instructions per 16-pixel tile
   static constexpr bool POW2 = (LPP & (LPP - 1)) == 0;
 };
-template <int CT, bool ACC = false, typename F>
+template <int CT, bool ACC = false, class FM = FmtA, typename F>
 __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, const float (&v)[CT][4], int lane,
                                               int cout_base, F pixoff) {
   using R = RowStore<CT>;
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  typedef f32x4 f4_t;
   const int m = lane & 15, g = lane >> 4;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const u32x2 bits =
-        __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]}, bf16x4_t));
+    const u32x2 bits = fd_pk4<FM>((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]});
     *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + g * 8) = bits;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -340,9 +345,8 @@ __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, cons
     if (off >= 0) {
       u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(a.y) + off + cout_base + piece * 8);
       if constexpr (ACC) {   // y += row (the gradient buffer of the forward input), whole 16-byte pieces of a pixel row
-        const f32x8 sum = __builtin_convertvector(__builtin_bit_cast(bf16x8, *dst), f32x8) +
-                          __builtin_convertvector(__builtin_bit_cast(bf16x8, row), f32x8);
-        row = __builtin_bit_cast(u32x4, __builtin_convertvector(sum, bf16x8));
+        const f32x8 sum = fd_cvt8<FM>(*dst) + fd_cvt8<FM>(row);
+        row = fd_pk8<FM>(sum);
       }
       *dst = row;
     }
@@ -352,18 +356,16 @@ __device__ __forceinline__ void fd_store_row16(const ConvArgs& a, char* tb, cons
 
 // Same transposition for a caller that already holds the (uniform) address of pixel 0 of the row:
 // pixel q lives at yrow + q * y_sw, pixels [0, npix) are stored.  32-bit per-lane offsets only.
-template <int CT>
+template <int CT, class FM = FmtA>
 __device__ __forceinline__ void fd_store_row16_ptr(unsigned short* yrow, int y_sw, char* tb, const float (&v)[CT][4],
                                                   int lane, int npix) {
   using R = RowStore<CT>;
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-  typedef __attribute__((ext_vector_type(4))) float f4_t;
+  typedef f32x4 f4_t;
   const int m = lane & 15, g = lane >> 4;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const u32x2 bits =
-        __builtin_bit_cast(u32x2, __builtin_convertvector((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]}, bf16x4_t));
+    const u32x2 bits = fd_pk4<FM>((f4_t){v[c][0], v[c][1], v[c][2], v[c][3]});
     *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + g * 8) = bits;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -412,6 +414,9 @@ struct ConvCfg {
 template <int KS, int STRIDE, int POOL, int PT, int CT, int WM, int WN, int TPS, int MK = 0, int WD = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void conv_igemm_kernel(ConvArgs a) {
   using C = ConvCfg<KS, STRIDE, POOL, PT, CT, WM, WN, TPS, WD>;
+  // element format of x, the filter image and a 16-bit y: forward launches move fp16 activations, the backward-data
+  // instantiation moves bf16 gradients (its mk_x, the forward conv's input, is fp16 again)
+  using FX = typename FmtSel<MK != 0>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* in_lds = smem;                      // [2][IN_BYTES]
   char* w_lds = smem + 2 * C::IN_BYTES;     // [2][W_BYTES]
@@ -498,13 +503,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       if (a.pro_mode == 0 && !POOL) {  // uniform: plain copy
         v = rin[i][0];
       } else if (!POOL) {
-        v = fd_xform8(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
+        v = fd_xform8<FX>(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
       } else {
-        f32x8 f = fd_affine_act(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
-        f += fd_affine_act(rin[i][1], sc_lds + cb, sh_lds + cb, a.p_slope);
-        f += fd_affine_act(rin[i][2], sc_lds + cb, sh_lds + cb, a.p_slope);
-        f += fd_affine_act(rin[i][3], sc_lds + cb, sh_lds + cb, a.p_slope);
-        v = fd_pack8(f * 0.25f);
+        f32x8 f = fd_affine_act<FX>(rin[i][0], sc_lds + cb, sh_lds + cb, a.p_slope);
+        f += fd_affine_act<FX>(rin[i][1], sc_lds + cb, sh_lds + cb, a.p_slope);
+        f += fd_affine_act<FX>(rin[i][2], sc_lds + cb, sh_lds + cb, a.p_slope);
+        f += fd_affine_act<FX>(rin[i][3], sc_lds + cb, sh_lds + cb, a.p_slope);
+        v = fd_pack8<FX>(f * 0.25f);
       }
       lds_write16(buf + (tid + i * C::NT) * 16, ok ? v : zero4);   // zero padding is post-activation
     }
@@ -571,9 +576,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       const char* xb = xfrag0 + (chunk & 1) * C::IN_BYTES;
 #pragma unroll
       for (int dx = 0; dx < KS; ++dx) {
-        bf16x8 xr[PT + KS - 1];
+        u32x4 xr[PT + KS - 1];
 #pragma unroll
-        for (int r = 0; r < PT + KS - 1; ++r) xr[r] = __builtin_bit_cast(bf16x8, lds_read16(xb + (r * C::IW + dx) * 16));
+        for (int r = 0; r < PT + KS - 1; ++r) xr[r] = lds_read16(xb + (r * C::IW + dx) * 16);
 #pragma unroll
         for (int dy = 0; dy < KS; ++dy) {
           const int e = dx * KS + dy;
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
           for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int c = 0; c < CT; ++c)
-              acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[c]), xr[p + dy], acc[p][c], 0, 0, 0);
+              acc[p][c] = fd_mfma<FX>(wcur[c], xr[p + dy], acc[p][c]);
           if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
           for (int c = 0; c < CT; ++c) {
@@ -637,18 +642,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
         dy = tap / KS;
         dx = tap - dy * KS;
       }
-      bf16x8 wf[CT], xf[PT];
+      u32x4 wf[CT], xf[PT];
 #pragma unroll
       for (int c = 0; c < CT; ++c)
-        wf[c] = __builtin_bit_cast(bf16x8, lds_read16(wb + (t * C::CTB + c) * 1024));
+        wf[c] = lds_read16(wb + (t * C::CTB + c) * 1024);
 #pragma unroll
       for (int p = 0; p < PT; ++p)
-        xf[p] = __builtin_bit_cast(bf16x8, lds_read16(xb + ((p * STRIDE + dy) * C::IW + dx) * 16));
+        xf[p] = lds_read16(xb + ((p * STRIDE + dy) * C::IW + dx) * 16);
 #pragma unroll
       for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int c = 0; c < CT; ++c)
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[p][c], 0, 0, 0);
+          acc[p][c] = fd_mfma<FX>(wf[c], xf[p], acc[p][c]);
     }
 
     if (has_next) store_w(w_lds + ((s + 1) & 1) * C::W_BYTES);
@@ -681,8 +686,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
     // and the lane keeps the 8 channels it owns for the whole tile: 16 coefficient registers, 16 running sums.
     // v = da * act'(bn(x));  sums (v, v * x) per channel;  store v, or y += gamma * rstd * v.
     using R = RowStore<CT>;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-    typedef __attribute__((ext_vector_type(4))) float f4_t;
+    typedef f32x4 f4_t;
     float* msc = red + WM * WN * CT * 16 * 2;   // [BN] scale, [BN] shift of this workgroup's channels
     float* msh = msc + C::BN;
     for (int cl = tid; cl < C::BN; cl += C::NT) {
@@ -714,8 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const u32x2 bits = __builtin_bit_cast(
-            u32x2, __builtin_convertvector((f4_t){acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]}, bf16x4_t));
+        const u32x2 bits = fd_pk4<FmtG>((f4_t){acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]});
         *reinterpret_cast<u32x2*>(tb + m * R::PITCH + c * 32 + kgl * 8) = bits;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -729,26 +732,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
         offs[i] = ok ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw + cg : -1;
         dav[i] = *reinterpret_cast<const u32x4*>(tb + (qok ? q : 0) * R::PITCH + piece * 16);
         xv[i] = gv[i] = u32x4{0u, 0u, 0u, 0u};
-        if (ok) {
+        if (ok && a.mk_mode != 0) {
           xv[i] = *reinterpret_cast<const u32x4*>(a.mk_x + (long long)n * a.mk_sn + (long long)row * a.mk_sh + (long long)(ox0 + q) * a.mk_sw + cg);
-          if (a.mk_acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(ybase + offs[i]);
         }
+        if (ok && a.mk_acc == 1) gv[i] = *reinterpret_cast<const u32x4*>(ybase + offs[i]);
       }
 #pragma unroll
       for (int i = 0; i < R::NIT; ++i) {
         if (offs[i] < 0) continue;
-        const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dav[i]), f32x8);
-        const f32x8 fx = __builtin_convertvector(__builtin_bit_cast(bf16x8, xv[i]), f32x8);
-        f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
+        const f32x8 da = fd_cvt8<FmtG>(dav[i]);
+        const f32x8 fx = fd_cvt8<FmtA>(xv[i]);      // the forward conv's input (fp16)
+        f32x8 o = fd_cvt8<FmtG>(gv[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float pre = fmaf(fx[e], sc8[e], sh8[e]);
-          const float v = (cg + e < a.Cout) ? da[e] * (pre > 0.f ? 1.f : a.mk_slope) : 0.f;
+          const float v = (cg + e < a.Cout) ? da[e] * ((pre > 0.f || a.mk_mode == 0) ? 1.f : a.mk_slope) : 0.f;
           s1[e] += v;
           s2[e] += v * fx[e];
           o[e] = a.mk_acc ? fmaf(sc8[e], v, o[e]) : v;   // o = 0 unless accumulating
         }
-        *reinterpret_cast<u32x4*>(ybase + offs[i]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+        *reinterpret_cast<u32x4*>(ybase + offs[i]) = fd_pk8<FmtG>(o);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
@@ -797,13 +800,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
       return (row < a.Ho && ox0 + q < a.Wo) ? (long long)n * a.y_sn + (long long)row * a.y_sh + (long long)(ox0 + q) * a.y_sw : -1;
     };
     if (rowstore) {
-      fd_store_row16<CT>(a, tb, v, lane, cbase, pixoff);
+      fd_store_row16<CT, false, FX>(a, tb, v, lane, cbase, pixoff);
     } else if (row < a.Ho && col < a.Wo) {
       const long long off = (long long)n * a.y_sn + (long long)(up * row) * a.y_sh + (long long)(up * col) * a.y_sw;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int cout0 = cbase + c * 16 + kgl * 4;
-        if (cout0 < a.Cout) fd_store4(a, off, cout0, v[c]);
+        if (cout0 < a.Cout) fd_store4<false, FX>(a, off, cout0, v[c]);
       }
     }
   }
@@ -910,7 +913,7 @@ bool conv3x3_pw_fits(int cout_total, int cin);
 bool conv3x3_rs_fits(const ConvArgs& a, int cout_total);
 // weight gradient of the growth conv, rows staged in their memory layout and read with ds_read_b64_tr_b16 (conv_wgrad_tr.hip)
 struct WgradRowsArgs {
-  const unsigned short* x;       // raw forward input (NHWC bf16 view)
+  const unsigned short* x;       // raw forward input (NHWC fp16 view)
   long long x_sn;
   int x_sh, x_sw;
   const unsigned short* dy;      // gradient of the conv output (NHWC bf16 view, 32 channels)

@@ -19,6 +19,8 @@ extern "C" int fdgan_conv_weight_layout(int cout, int cin, int ksize, int stride
 
 static int conv_dispatch(ConvArgs& a, long long nimg, int cout_total, int ksize, int stride, bool pool,
                          int w_layout, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
+  if (a.grad_io && (w_layout != FD_WLAYOUT_CHUNK32 || stride != 1 || pool || (a.pro_mode != 0 && a.mk_mode == 0)))
+    FD_FAIL(FD_EUNSUPPORTED, "conv2d on bf16 gradients: stride-1, chunk32 filter image, no prologue");
   if (w_layout == FD_WLAYOUT_X64) {
     if (ksize != 1 || stride != 1) FD_FAIL(FD_EINVAL, "conv2d: the x64 weight layout is for 1x1 stride-1 convs");
     return conv_dispatch_k1_xs(a, nimg, cout_total, pool, info, stats_cap, dry, stream);
@@ -36,7 +38,7 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
                       const FdTensor* y, int cout, const FdStats* stats, const FdConvDesc* d, ConvArgs& a,
                       long long& nimg, bool& pool) {
   FD_REQUIRE(x && y && d, "conv2d: NULL tensor/descriptor");
-  FD_REQUIRE(x->dtype == FD_BF16, "conv2d: x must be NHWC bf16");
+  FD_REQUIRE(x->dtype == FD_F16 || x->dtype == FD_BF16, "conv2d: x must be an NHWC fp16 (activation) or bf16 (gradient) view");
   FD_REQUIRE(x->stride[3] == 1 && x->stride[2] % 8 == 0 && x->stride[1] % 8 == 0 && x->stride[0] % 8 == 0,
              "conv2d: x strides must be channel-contiguous and multiples of 8 elements");
   FD_REQUIRE(((uintptr_t)x->ptr & 15) == 0, "conv2d: x pointer must be 16-byte aligned");
@@ -56,6 +58,7 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
              "conv2d: one image exceeds 2^31 elements");
   FD_REQUIRE(x->stride[1] < (1ll << 31) && x->stride[2] < (1ll << 31), "conv2d: stride overflow");
   a = ConvArgs{};
+  a.grad_io = x->dtype == FD_BF16;   // a convolution over gradients (data gradient): bf16 in, bf16 filter image, bf16 out
   a.x = static_cast<const unsigned short*>(x->ptr);
   a.x_sn = x->stride[0];
   a.x_sh = (int)x->stride[1];
@@ -117,7 +120,8 @@ static int conv_setup(const FdTensor* x, const void* w_packed, const float* bias
     a.y_sw = (int)y->stride[2];
     a.y_sc = y->stride[3];
   } else {
-    FD_REQUIRE(y->dtype == FD_BF16, "conv2d: y dtype %d", y->dtype);
+    FD_REQUIRE(y->dtype == x->dtype, "conv2d: a 16-bit y must have x's element format (fp16 activations / bf16 gradients), got %d vs %d",
+               y->dtype, x->dtype);
     FD_REQUIRE(y->stride[3] == 1 && y->stride[2] % 4 == 0 && y->stride[1] % 4 == 0 && y->stride[0] % 4 == 0,
                "conv2d: y strides must be channel-contiguous, multiples of 4 elements");
     FD_REQUIRE(((uintptr_t)y->ptr & 7) == 0, "conv2d: y pointer must be 8-byte aligned");
@@ -173,6 +177,13 @@ extern "C" int fdgan_conv2d_fwd(const FdTensor* x, const void* w_packed, const f
   const int cout = d->cout > 0 ? d->cout : (int)y->c;
   int rc = conv_setup(x, w_packed, bias, pro, y, cout, stats, d, a, nimg, pool);
   if (rc != FD_OK) return rc;
+  if (a.grad_io) {
+    // a plain convolution over bf16 gradients (the unfused data gradient: dy * flip(W)): runs on the backward-data
+    // instantiations with the mask switched off; their epilogue moves whole 16-byte pieces of pixel rows
+    FD_REQUIRE(!bias && !stats && !pro && d->epilogue_act == FD_ACT_NONE && !d->upsample2 && y->dtype == FD_BF16 && a.y_vec16 &&
+                   (y->stride[2] >= (y->c + 7) / 8 * 8 || y->w == 1),
+               "conv2d_fwd on bf16 gradients: no bias / prologue / epilogue / statistics; y rows 16-byte aligned, channels padded to 8");
+  }
   rc = conv_dispatch(a, nimg, cout, d->ksize, d->stride, pool, d->w_layout, nullptr,
                      stats ? stats->capacity_floats : -1, false, static_cast<hipStream_t>(stream));
   if (rc != FD_OK) return rc;
@@ -193,7 +204,7 @@ extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_p
   FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv1x1_bwd_data_weight: pooled prologues are not fused");
   const int act0 = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
   FD_REQUIRE(act0 == FD_ACT_NONE || act0 == FD_ACT_RELU || act0 == FD_ACT_LEAKY02, "conv1x1_bwd_data_weight: prologue activation %d", act0);
-  const bool fits = dy->dtype == FD_BF16 && dpre->dtype == FD_BF16 && fwd_x->dtype == FD_BF16 && dy->c == 128 && dy->n == dpre->n &&
+  const bool fits = dy->dtype == FD_BF16 && dpre->dtype == FD_BF16 && fwd_x->dtype == FD_F16 && dy->c == 128 && dy->n == dpre->n &&
                     dy->h == dpre->h && dy->w == dpre->w && fwd_x->n == dpre->n && fwd_x->h == dpre->h && fwd_x->w == dpre->w &&
                     fwd_x->c >= dpre->c && conv1x1_bwd_fits(dy, fwd_x, dpre);
   if (!fits) FD_FAIL(FD_EUNSUPPORTED, "conv1x1_bwd_data_weight: shape outside the fused kernel (use fdgan_conv2d_bwd_data + fdgan_conv2d_bwd_weight)");
@@ -206,9 +217,9 @@ extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_p
              ((uintptr_t)t->ptr & 15) == 0;
     };
     FD_REQUIRE(dy_affine_b && dy_affine_c, "conv1x1_bwd_data_weight: dy_affine_x without its coefficients");
-    FD_REQUIRE(dy_affine_x->dtype == FD_BF16 && dy_affine_x->c == 128 && dy_affine_x->n == dy->n && dy_affine_x->h == dy->h &&
+    FD_REQUIRE(dy_affine_x->dtype == FD_F16 && dy_affine_x->c == 128 && dy_affine_x->n == dy->n && dy_affine_x->h == dy->h &&
                    dy_affine_x->w == dy->w && dense(dy_affine_x),
-               "conv1x1_bwd_data_weight: dy_affine_x must be a dense 128-channel NHWC bf16 view shaped like dy");
+               "conv1x1_bwd_data_weight: dy_affine_x must be a dense 128-channel NHWC fp16 view shaped like dy");
   }
   const int rc = conv1x1_bwd_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, partial, capacity_floats, &rows, &cpad, st,
                                     wgrad_workspace, wgrad_workspace_floats, &nsplit, dy_affine_x, dy_affine_b, dy_affine_c);
@@ -231,9 +242,9 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
              "conv2d_bwd_data: stride-1 conv with the chunk32 filter image, no epilogue");
   FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv2d_bwd_data: a pooled prologue is differentiated at full resolution");
   const int64_t c8 = (dpre->c + 7) / 8 * 8;
-  FD_REQUIRE(dpre->dtype == FD_BF16 && fwd_x->dtype == FD_BF16 && fwd_x->n == dpre->n && fwd_x->h == dpre->h &&
+  FD_REQUIRE(dy->dtype == FD_BF16 && dpre->dtype == FD_BF16 && fwd_x->dtype == FD_F16 && fwd_x->n == dpre->n && fwd_x->h == dpre->h &&
                  fwd_x->w == dpre->w && fwd_x->c >= dpre->c && fwd_x->stride[3] == 1 && dpre->stride[3] == 1,
-             "conv2d_bwd_data: fwd_x must be an NHWC bf16 view shaped like dpre");
+             "conv2d_bwd_data: dy / dpre are NHWC bf16 gradients, fwd_x an NHWC fp16 view shaped like dpre");
   for (const FdTensor* t : {fwd_x, dpre})   // the epilogue moves whole 16-byte pieces of pixel rows, pad channels included
     FD_REQUIRE(t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0 &&
                    (t->stride[2] >= c8 || t->w == 1),

@@ -8,9 +8,9 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
   const bool narrow = cout_total <= 32;
   if (pool) FD_FAIL(FD_EUNSUPPORTED, "pool2 prologue needs a 1x1 stride-1 conv");
   if (stride != 1) FD_FAIL(FD_EUNSUPPORTED, "3x3 conv with stride %d", stride);
-  if (a.mk_mode == 0 && conv3x3_rs_fits(a, cout_total) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_RS") == nullptr)
+  if (!a.grad_io && conv3x3_rs_fits(a, cout_total) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_RS") == nullptr)
     return conv_dispatch_k3_rs(a, nimg, cout_total, info, stats_cap, dry, stream);
-  if (a.mk_mode == 0 && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_PW") == nullptr)
+  if (!a.grad_io && narrow && a.pad == 1 && conv3x3_pw_fits(cout_total, a.Cin) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_PW") == nullptr)
     return conv_dispatch_k3_pw(a, nimg, cout_total, info, stats_cap, dry, stream);
   // MFMA-bound shapes (VGG16, D, the refine convs, the dy blocks' 3x3) and their data gradients: filter-direct kernels
   // (conv_igemm.h, WD = 1), 8 x 16 output pixels per wave, 2-3 workgroups per CU:
@@ -24,7 +24,7 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
         const int waste128 = (cout_total + 127) / 128 * 128 - cout_total, waste144 = (cout_total + 143) / 144 * 144 - cout_total;
         v = cout_total <= 64 ? 'G' : (waste144 < waste128 ? 'H' : 'A');
       }
-      if (a.mk_mode != 0) {
+      if (a.grad_io) {
         if (v == 'G') FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 2, 2, 9, 1, 1, "conv3x3_wd64_bwd");
         if (v == 'H') FD_CONV_DISPATCH_W(3, 1, 0, 8, 3, 1, 3, 9, 1, 1, "conv3x3_wd144_bwd");
         FD_CONV_DISPATCH_W(3, 1, 0, 8, 2, 1, 4, 9, 1, 1, "conv3x3_wd128_bwd");
@@ -35,7 +35,7 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
     }
   }
   const bool mid = cout_total <= 64;   // 64 output channels per workgroup: the 128-wide tile would idle half its MFMAs (VGG16 conv1_2: 197 us)
-  if (a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
+  if (a.grad_io) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
     if (narrow) FD_CONV_DISPATCH_X(3, 1, 0, 4, 2, 4, 1, 9, 1, "conv3x3_bn32_bwd");
     if (mid) FD_CONV_DISPATCH_X(3, 1, 0, 4, 4, 4, 1, 1, 1, "conv3x3_bn64_bwd");
     FD_CONV_DISPATCH_X(3, 1, 0, 4, 8, 4, 1, 1, 1, "conv3x3_bn128_bwd");

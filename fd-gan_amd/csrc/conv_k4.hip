@@ -13,7 +13,7 @@ int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bo
         const int waste128 = (cout_total + 127) / 128 * 128 - cout_total, waste144 = (cout_total + 143) / 144 * 144 - cout_total;
         v = cout_total <= 64 ? 'G' : (waste144 < waste128 ? 'H' : 'A');
       }
-      if (a.mk_mode != 0) {
+      if (a.grad_io) {
         if (v == 'G') FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 2, 2, 16, 1, 1, "conv4x4_wd64_bwd");
         if (v == 'H') FD_CONV_DISPATCH_W(4, 1, 0, 8, 3, 1, 3, 16, 1, 1, "conv4x4_wd144_bwd");
         FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 1, 4, 16, 1, 1, "conv4x4_wd128_bwd");
@@ -23,7 +23,7 @@ int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bo
       FD_CONV_DISPATCH_W(4, 1, 0, 8, 2, 1, 4, 16, 0, 1, "conv4x4_wd128");
     }
   }
-  if (stride == 1 && a.mk_mode != 0) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
+  if (stride == 1 && a.grad_io) {   // backward data with the masked epilogue (fdgan_conv2d_bwd_data)
     if (narrow) FD_CONV_DISPATCH_X(4, 1, 0, 4, 2, 4, 1, 4, 1, "conv4x4_bn32_bwd");
     if (mid) FD_CONV_DISPATCH_X(4, 1, 0, 4, 4, 4, 1, 1, 1, "conv4x4_bn64_bwd");
     FD_CONV_DISPATCH_X(4, 1, 0, 4, 8, 4, 1, 1, 1, "conv4x4_bn128_bwd");

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(512) void conv_wgrad1x1_tr_kernel(Wg1Args a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       u32x4 v = xr[k];
-      if (a.pro_mode != 0 && x_ok && p0 + spix + 32 * k < p_end) v = fd_xform8(v, sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);
+      // fp16 forward input -> the bf16 operand (always: without a prologue scale 1, shift 0, slope 1 = the conversion)
+      if (x_ok && p0 + spix + 32 * k < p_end) v = fd_xform8<FmtA, FmtG>(v, sc_s + chunk * 8, sh_s + chunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);
       lds_write16(buf + dst[k], v);                        // pixels past the end stay zero: they add nothing
       lds_write16(buf + W1_PX * W1_ROW + dst[k], dr[k]);
     }

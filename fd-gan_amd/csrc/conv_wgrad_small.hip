@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(WgSmallArgs a) {
         const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
         const bool ok = pok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         if (ok) raw = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + c8 * 8);
-        f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, raw), f32x8);
+        f32x8 f = fd_cvt8<FmtA>(raw);      // the forward input is fp16; the staged operand is bf16 like dy
         if (a.pro_mode != 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(WgSmallArgs a) {
             f[e] = ok ? fmaxf(t, a.p_slope * t) : 0.f;      // zero padding applies to the ACTIVATED input
           }
         }
-        const u32x4 hw = a.pro_mode != 0 ? fd_pack8(f) : raw;
+        const u32x4 hw = fd_pack8<FmtG>(f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int ci = c8 * 8 + e;

@@ -2,7 +2,7 @@
 // growth conv (3x3, pad 1, 32 filters, Cin a multiple of 128) and the Fusion-discriminator's 4x4 144 -> 288 conv.
 //
 //   dW[co][ci][ky][kx] = sum over (n, y, x) of dy[n][y][x][co] * a[n][y + ky - 1][x + kx - 1][ci],
-//   a = relu(bn(x)) recomputed from the raw input exactly as the forward conv staged it (bf16, zero padding)
+//   a = relu(bn(x)) recomputed from the raw fp16 input as the forward conv staged it (rounded to bf16 here: dy is bf16; zero padding)
 //
 // Both MFMA operands want "8 consecutive k (= pixels) of one channel" per lane, while memory is pixel-major
 // with channels contiguous.  The first kernels (conv_bwd.hip) transposed in registers (v_perm_b32 +
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
       if (xpix0 + XPSTEP * k >= C::XPIX) break;
       u32x4 v = xr[k];
       if ((xok >> k) & 1) {
-        if (a.pro_mode != 0) v = fd_xform8(v, sc_s + xchunk * 8, sh_s + xchunk * 8, a.p_slope);
+        v = fd_xform8<FmtA, FmtG>(v, sc_s + xchunk * 8, sh_s + xchunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);   // fp16 x -> bf16 operand
       } else {
         v = zero4;   // zero padding of the ACTIVATED input
       }
@@ -288,18 +288,17 @@ __device__ __forceinline__ void r3_wait_vm() {
 // one dword (two channels) of the prologue transform; RELU: BatchNorm + ReLU on the packed result (fd_bn_relu8's recipe)
 template <bool RELU>
 __device__ __forceinline__ unsigned r3_xform2(unsigned raw, float sc0, float sc1, float sh0, float sh1, float slope, unsigned mask) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef f32x2 f32x2_t;
   typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-  f32x2_t f = {__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
+  f32x2_t f = fd_cvt2<FmtA>(raw);   // the forward input is fp16; the result is the bf16 operand multiplied with dy
   f = __builtin_elementwise_fma(f, (f32x2_t){sc0, sc1}, (f32x2_t){sh0, sh1});
   unsigned out;
   if constexpr (RELU) {
-    const s16x2_t pk = __builtin_bit_cast(s16x2_t, __builtin_convertvector(f, bf16x2_t));
+    const s16x2_t pk = __builtin_bit_cast(s16x2_t, fd_pk2<FmtG>(f));
     out = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
   } else {
     f = __builtin_elementwise_max(f, f * slope);
-    out = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+    out = fd_pk2<FmtG>(f);
   }
   return out & mask;   // zero padding of the ACTIVATED input
 }

@@ -4,14 +4,14 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------
-// weight packing: fp32 OIHW / IOHW -> bf16 MFMA fragment order
+// weight packing: fp32 OIHW / IOHW -> fp16 (forward image) or bf16 (flipped image of the data gradient) MFMA fragment order
 //   packed[((chunk*KK + tap)*ntile + tile)*512 + lane*8 + e]
 //     = W[cout = tile*16 + (lane&15)][cin = chunk*32 + (lane>>4)*8 + e][tap]
 // ---------------------------------------------------------------------------------
 struct PackArgs {
   const float* w;
   unsigned short* out;
-  int cout, cin, kk, ks, ntile, nchunk, transposed, flip, layout;
+  int cout, cin, kk, ks, ntile, nchunk, transposed, flip, layout, dtype;
   long long nunits;
 };
 
@@ -51,7 +51,7 @@ __global__ void pack_weight_kernel(PackArgs a) {
     }
     v[e] = x;
   }
-  *reinterpret_cast<u32x4*>(a.out + u * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+  *reinterpret_cast<u32x4*>(a.out + u * 8) = a.dtype == FD_F16 ? fd_pk8<FmtA>(v) : fd_pk8<FmtG>(v);
 }
 
 extern "C" size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize) {
@@ -62,8 +62,9 @@ extern "C" size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize) {
 }
 
 extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
-                                      int layout, void* packed, size_t packed_bytes, FdStream stream) {
+                                      int layout, int dtype, void* packed, size_t packed_bytes, FdStream stream) {
   FD_REQUIRE(w && packed, "pack_conv_weight: NULL pointer");
+  FD_REQUIRE(dtype == FD_F16 || dtype == FD_BF16, "pack_conv_weight: dtype must be FD_F16 (forward image) or FD_BF16 (gradient-side image)");
   FD_REQUIRE(cout > 0 && cin > 0 && ksize > 0, "pack_conv_weight: bad shape");
   FD_REQUIRE(layout == FD_WLAYOUT_CHUNK32 || (layout == FD_WLAYOUT_X64 && ksize == 1),
              "pack_conv_weight: layout %d not valid for ksize %d", layout, ksize);
@@ -81,6 +82,7 @@ extern "C" int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksi
   a.transposed = transposed;
   a.flip = flip;
   a.layout = layout;
+  a.dtype = dtype;
   a.nunits = layout == FD_WLAYOUT_X64 ? (long long)((cin + 63) / 64) * 2 * a.ntile * 64
                                       : (long long)a.nchunk * a.kk * a.ntile * 64;
   const unsigned nb = (unsigned)((a.nunits + 255) / 256);
@@ -138,7 +140,7 @@ __global__ void pack_weights_kernel(PackJobsArgs b) {
     }
     v[e] = x;
   }
-  *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(j.packed) + u * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+  *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(j.packed) + u * 8) = j.dtype == FD_F16 ? fd_pk8<FmtA>(v) : fd_pk8<FmtG>(v);
 }
 
 extern "C" int64_t fdgan_pack_units(int cout, int cin, int ksize, int layout) {
@@ -222,13 +224,14 @@ extern "C" int fdgan_bn_finalize(const float* partial, int64_t rows, int64_t cpa
 }
 
 // ---------------------------------------------------------------------------------
-// NCHW fp32 -> NHWC bf16 (zero-padded channels); one thread per (pixel, 8-channel group)
+// NCHW fp32 -> NHWC fp16 / bf16 (zero-padded channels); one thread per (pixel, 8-channel group)
 // ---------------------------------------------------------------------------------
 struct ToNhwcArgs {
   const float* x;
   unsigned short* y;
   long long n, c, h, w, y_sn, y_sh, y_sw;
   int groups;  // 8-channel groups to write per pixel
+  int dtype;
   long long total;
 };
 
@@ -249,18 +252,17 @@ __global__ void nchw_to_nhwc_kernel(ToNhwcArgs a) {
     const long long c = g * 8 + e;
     v[e] = c < a.c ? a.x[((n * a.c + c) * a.h + py) * a.w + px] : 0.f;
   }
-  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) =
-      __builtin_bit_cast(u32x4, __builtin_convertvector(v, bf16x8));
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) = a.dtype == FD_F16 ? fd_pk8<FmtA>(v) : fd_pk8<FmtG>(v);
 }
 
-extern "C" int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
-                                           const FdTensor* y, FdStream stream) {
-  FD_REQUIRE(x && y && y->ptr, "nchw_f32_to_nhwc_bf16: NULL pointer");
-  FD_REQUIRE(y->dtype == FD_BF16 && y->stride[3] == 1, "nchw_f32_to_nhwc_bf16: y must be NHWC bf16");
+extern "C" int fdgan_nchw_f32_to_nhwc(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
+                                      const FdTensor* y, FdStream stream) {
+  FD_REQUIRE(x && y && y->ptr, "nchw_f32_to_nhwc: NULL pointer");
+  FD_REQUIRE((y->dtype == FD_F16 || y->dtype == FD_BF16) && y->stride[3] == 1, "nchw_f32_to_nhwc: y must be an NHWC fp16 / bf16 view");
   FD_REQUIRE(y->n == n && y->h == h && y->w == w && y->c >= c && y->c % 8 == 0,
-             "nchw_f32_to_nhwc_bf16: y shape mismatch (y->c must be a multiple of 8 >= c)");
+             "nchw_f32_to_nhwc: y shape mismatch (y->c must be a multiple of 8 >= c)");
   FD_REQUIRE(y->stride[2] % 8 == 0 && y->stride[1] % 8 == 0 && y->stride[0] % 8 == 0 && ((uintptr_t)y->ptr & 15) == 0,
-             "nchw_f32_to_nhwc_bf16: y alignment");
+             "nchw_f32_to_nhwc: y alignment");
   ToNhwcArgs a;
   a.x = x;
   a.y = static_cast<unsigned short*>(y->ptr);
@@ -272,19 +274,21 @@ extern "C" int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c,
   a.y_sh = y->stride[1];
   a.y_sw = y->stride[2];
   a.groups = (int)(y->c / 8);
+  a.dtype = y->dtype;
   a.total = n * a.groups * h * w;
-  return fd_launch(&nchw_to_nhwc_kernel, "nchw_f32_to_nhwc_bf16", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
+  return fd_launch(&nchw_to_nhwc_kernel, "nchw_f32_to_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
                    0, a, static_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------
-// NHWC bf16 -> NCHW fp32; one thread per (n, c, pixel): coalesced fp32 writes
+// NHWC fp16 / bf16 -> NCHW fp32; one thread per (n, c, pixel): coalesced fp32 writes
 // ---------------------------------------------------------------------------------
 struct ToNchwArgs {
   const unsigned short* x;
   float* y;
   long long n, c, h, w, x_sn, x_sh, x_sw;
   long long total;
+  int dtype;
 };
 
 __global__ void nhwc_to_nchw_kernel(ToNchwArgs a) {
@@ -298,20 +302,20 @@ __global__ void nhwc_to_nchw_kernel(ToNchwArgs a) {
   const long long c = r % a.c;
   const long long n = r / a.c;
   const unsigned short b = a.x[n * a.x_sn + py * a.x_sh + px * a.x_sw + c];
-  a.y[u] = __uint_as_float((unsigned)b << 16);
+  a.y[u] = a.dtype == FD_F16 ? fd_cvt1<FmtA>(b) : fd_cvt1<FmtG>(b);
 }
 
-extern "C" int fdgan_nhwc_bf16_to_nchw_f32(const FdTensor* x, float* y, FdStream stream) {
-  FD_REQUIRE(x && x->ptr && y, "nhwc_bf16_to_nchw_f32: NULL pointer");
-  FD_REQUIRE(x->dtype == FD_BF16 && x->stride[3] == 1, "nhwc_bf16_to_nchw_f32: x must be NHWC bf16");
+extern "C" int fdgan_nhwc_to_nchw_f32(const FdTensor* x, float* y, FdStream stream) {
+  FD_REQUIRE(x && x->ptr && y, "nhwc_to_nchw_f32: NULL pointer");
+  FD_REQUIRE((x->dtype == FD_F16 || x->dtype == FD_BF16) && x->stride[3] == 1, "nhwc_to_nchw_f32: x must be an NHWC fp16 / bf16 view");
   ToNchwArgs a{static_cast<const unsigned short*>(x->ptr), y, x->n, x->c, x->h, x->w,
-               x->stride[0], x->stride[1], x->stride[2], x->n * x->c * x->h * x->w};
-  return fd_launch(&nhwc_to_nchw_kernel, "nhwc_bf16_to_nchw_f32", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
+               x->stride[0], x->stride[1], x->stride[2], x->n * x->c * x->h * x->w, x->dtype};
+  return fd_launch(&nhwc_to_nchw_kernel, "nhwc_to_nchw_f32", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
                    0, a, static_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------
-// channel-slice copy between NHWC bf16 views (16 B per thread)
+// channel-slice copy between NHWC 16-bit views (16 B per thread)
 // ---------------------------------------------------------------------------------
 struct CopyArgs {
   const unsigned short* s;
@@ -337,8 +341,8 @@ __global__ void copy_nhwc_kernel(CopyArgs a) {
 
 extern "C" int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream) {
   FD_REQUIRE(src && dst && src->ptr && dst->ptr, "copy_nhwc: NULL pointer");
-  FD_REQUIRE(src->dtype == FD_BF16 && dst->dtype == FD_BF16 && src->stride[3] == 1 && dst->stride[3] == 1,
-             "copy_nhwc: NHWC bf16 views required");
+  FD_REQUIRE((src->dtype == FD_F16 || src->dtype == FD_BF16) && dst->dtype == src->dtype && src->stride[3] == 1 && dst->stride[3] == 1,
+             "copy_nhwc: two NHWC views of the same 16-bit format required");
   FD_REQUIRE(src->n == dst->n && src->h == dst->h && src->w == dst->w && src->c == dst->c && src->c % 8 == 0,
              "copy_nhwc: shape mismatch or c not a multiple of 8");
   FD_REQUIRE((((uintptr_t)src->ptr | (uintptr_t)dst->ptr) & 15) == 0, "copy_nhwc: 16-byte alignment");
@@ -353,7 +357,7 @@ extern "C" int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStrea
 
 // ---------------------------------------------------------------------------------
 // tanh / sigmoid in place over what a conv stored (nn.Tanh dehaze1113.py:799, nn.Sigmoid :223).
-// Generic strided view (NCHW fp32 or NHWC bf16): one thread per element, w fastest.
+// Generic strided view (NCHW fp32 or NHWC fp16 / bf16): one thread per element, w fastest.
 // ---------------------------------------------------------------------------------
 struct ActArgs {
   void* y;
@@ -375,12 +379,9 @@ __global__ void act_inplace_kernel(ActArgs a) {
   } else {                   // NHWC: c, w, h, n
     i0 = r % a.c; r /= a.c; i1 = r % a.w; r /= a.w; i2 = r % a.h; i3 = r / a.h;
     unsigned short* p = static_cast<unsigned short*>(a.y) + i3 * a.sn + i2 * a.sh + i1 * a.sw + i0 * a.sc;
-    const float v = __uint_as_float((unsigned)(*p) << 16);
+    const float v = a.dtype == FD_F16 ? fd_cvt1<FmtA>(*p) : fd_cvt1<FmtG>(*p);
     const float o = a.act == FD_ACT_TANH ? tanhf(v) : 1.f / (1.f + expf(-v));
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    typedef __attribute__((ext_vector_type(2))) float f2_t;
-    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){o, 0.f}, bf16x2_t));
-    *p = (unsigned short)(bits & 0xffffu);
+    *p = a.dtype == FD_F16 ? fd_pk1<FmtA>(o) : fd_pk1<FmtG>(o);
   }
 }
 

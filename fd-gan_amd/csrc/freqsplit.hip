@@ -8,7 +8,7 @@
 // normalisation is affine and the kernel sums to 1, so it commutes with the blur and is applied
 // to the result.  fdgan_fusion_input_nhwc fuses both filters with the layout change the
 // discriminator needs: it reads the image once and writes [img, LF(img), HF(img)] as 9 NHWC
-// bf16 channels (+ zero padding) -- the tensor D's first 4x4 conv consumes.
+// fp16 channels (+ zero padding) -- the tensor D's first 4x4 conv consumes.
 #include <math.h>
 #include <stdlib.h>
 
@@ -21,7 +21,7 @@ constexpr int FS_T = 32, FS_R = 7, FS_E = FS_T + 2 * FS_R;   // 32x32 outputs, 4
 struct FsArgs {
   const float* x;   // [planes][H][W]
   float* y;         // blur / laplacian output planes (or NULL)
-  unsigned short* y_nhwc;   // fused: NHWC bf16 view
+  unsigned short* y_nhwc;   // fused: NHWC fp16 view
   long long yn_sn, yn_sh, yn_sw;
   int H, W, C;      // C = channels per image (plane % C = channel)
   int norm;         // apply (v - mean[c]) / std[c] to the blurred value
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
     } else if (a.mode == 1) {
       a.y[(long long)plane * a.H * a.W + (long long)oy * a.W + ox] = hf;
     } else {
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
       typedef __attribute__((ext_vector_type(2))) float f2_t;
       unsigned short* q = a.y_nhwc + n * a.yn_sn + oy * a.yn_sh + ox * a.yn_sw;
-      const unsigned b01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){ctr, lf}, bf16x2_t));
-      const unsigned b2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){hf, 0.f}, bf16x2_t));
+      const unsigned b01 = fd_pk2<FmtA>((f2_t){ctr, lf});
+      const unsigned b2 = fd_pk2<FmtA>((f2_t){hf, 0.f});
       q[ch] = (unsigned short)(b01 & 0xffffu);            // img
       q[a.C + ch] = (unsigned short)(b01 >> 16);          // LF(img)
       q[2 * a.C + ch] = (unsigned short)(b2 & 0xffffu);   // HF(img)
@@ -345,7 +345,7 @@ extern "C" int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t
 extern "C" int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w,
                                        const FdTensor* y, int use_input_norm, FdStream stream) {
   FD_REQUIRE(img && y && y->ptr, "fusion_input_nhwc: NULL pointer");
-  FD_REQUIRE(y->dtype == FD_BF16 && y->stride[3] == 1, "fusion_input_nhwc: y must be NHWC bf16");
+  FD_REQUIRE(y->dtype == FD_F16 && y->stride[3] == 1, "fusion_input_nhwc: y must be NHWC fp16");
   FD_REQUIRE(y->n == n && y->h == h && y->w == w && y->c >= 3 * c, "fusion_input_nhwc: y must hold 3*c channels");
   FD_REQUIRE(!use_input_norm || c == 3, "fusion_input_nhwc: use_input_norm needs 3 channels");
   FsArgs a{};

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void pyramid_pool4_kernel(PyrArgs a) {
     const unsigned short* xp = xb + py * a.x_sh + px * a.x_sw;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     for (int c = 0; c < a.C; ++c) {
-      const float v = __uint_as_float((unsigned)xp[c] << 16);
+      const float v = fd_cvt1<FmtA>(xp[c]);
       d0 = fmaf(v, wl[c], d0);
       d1 = fmaf(v, wl[a.C + c], d1);
       d2 = fmaf(v, wl[2 * a.C + c], d2);
@@ -76,10 +76,7 @@ __global__ __launch_bounds__(256) void pyramid_pool4_kernel(PyrArgs a) {
   unsigned short* yb = a.y + n * a.y_sn + (long long)(ty * k0) * a.y_sh + (long long)(tx * k0) * a.y_sw;
   for (int p = tid; p < npx; p += 256) {
     const int py = p / k0, px = p % k0, bidx = (py / f) * 8 + px / f;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-    typedef __attribute__((ext_vector_type(4))) float f4_t;
-    const bf16x4_t o = __builtin_convertvector((f4_t){m[bidx], m[64 + bidx], m[128 + bidx], m[192 + bidx]}, bf16x4_t);
-    *reinterpret_cast<u32x2*>(yb + py * a.y_sh + px * a.y_sw) = __builtin_bit_cast(u32x2, o);
+    *reinterpret_cast<u32x2*>(yb + py * a.y_sh + px * a.y_sw) = fd_pk4<FmtA>((f32x4){m[bidx], m[64 + bidx], m[128 + bidx], m[192 + bidx]});
   }
 }
 
@@ -103,7 +100,7 @@ __global__ void bn_dropout_kernel(BnDropArgs a) {
   r /= a.w;
   const long long py = r % a.h, n = r / a.h;
   const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + py * a.x_sh + px * a.x_sw + g * 8);
-  f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
+  f32x8 f = fd_cvt8<FmtA>(v);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = g * 8 + e;
@@ -118,7 +115,7 @@ __global__ void bn_dropout_kernel(BnDropArgs a) {
     }
     f[e] = o;
   }
-  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + py * a.y_sh + px * a.y_sw + g * 8) = fd_pk8<FmtA>(f);
 }
 
 struct Mp3Args {
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(Mp3Args a) {
           const int xx = 2 * wo - 1 + dx;
           if (xx < 0 || xx >= a.W) continue;
           const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)yy * a.x_sh + (long long)xx * a.x_sw + g * 8);
-          const f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
+          const f32x8 f = fd_cvt8<FmtA>(v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float t = fmaf(f[e], sc[e], sh[e]);
@@ -176,9 +173,9 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(Mp3Args a) {
           }
         }
       }
-      const bf16x8 ob = __builtin_convertvector(best, bf16x8);
-      *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)ho * a.y_sh + (long long)wo * a.y_sw + g * 8) = __builtin_bit_cast(u32x4, ob);
-      const f32x8 r = __builtin_convertvector(ob, f32x8);      // statistics of the STORED (bf16) values, as the conv kernels do
+      const u32x4 ob = fd_pk8<FmtA>(best);
+      *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)ho * a.y_sh + (long long)wo * a.y_sw + g * 8) = ob;
+      const f32x8 r = fd_cvt8<FmtA>(ob);      // statistics of the STORED (fp16) values
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[e] = r[e], s2[e] = r[e] * r[e];
     }
@@ -235,7 +232,7 @@ struct ScatterArgs {
 };
 
 // J = (I - A) / (|t| + eps) + A per pixel and channel (dehaze22.py:699-715), stored as NCHW fp32 (an output of the network) and,
-// with the hazy image behind it, as the 6 (+2 zero) channel NHWC bf16 input of refine1
+// with the hazy image behind it, as the 6 (+2 zero) channel NHWC fp16 input of refine1
 __global__ void scatter_dehaze_kernel(ScatterArgs a) {
   const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= a.total) return;
@@ -256,7 +253,7 @@ __global__ void scatter_dehaze_kernel(ScatterArgs a) {
     o[c] = d;
     o[3 + c] = xv;
   }
-  *reinterpret_cast<u32x4*>(a.cat + n * a.c_sn + (long long)py * a.c_sh + (long long)px * a.c_sw) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+  *reinterpret_cast<u32x4*>(a.cat + n * a.c_sn + (long long)py * a.c_sh + (long long)px * a.c_sw) = fd_pk8<FmtA>(o);
 }
 
 }  // namespace
@@ -265,7 +262,7 @@ extern "C" int fdgan_scatter_dehaze(const float* x, const float* tran, const flo
                                     float* window_mean, float* atp_out, float* dehaze2, const FdTensor* cat, FdStream stream) {
   FD_REQUIRE(x && tran && atp && window_mean && atp_out && dehaze2 && cat && cat->ptr, "scatter_dehaze: NULL pointer");
   FD_REQUIRE(n > 0 && h > 0 && w >= h, "scatter_dehaze: the reference pools the airlight over H x H windows (dehaze22.py:705): W >= H required");
-  FD_REQUIRE(cat->dtype == FD_BF16 && cat->stride[3] == 1 && cat->n == n && cat->h == h && cat->w == w && cat->c >= 8, "scatter_dehaze: cat must be an N x H x W x 8 NHWC bf16 view");
+  FD_REQUIRE(cat->dtype == FD_F16 && cat->stride[3] == 1 && cat->n == n && cat->h == h && cat->w == w && cat->c >= 8, "scatter_dehaze: cat must be an N x H x W x 8 NHWC fp16 view");
   FD_REQUIRE(((uintptr_t)cat->ptr & 15) == 0 && cat->stride[0] % 8 == 0 && cat->stride[1] % 8 == 0 && cat->stride[2] % 8 == 0, "scatter_dehaze: 16-byte alignment");
   const int nwin = (int)(w / h);
   AtpArgs r{atp, window_mean, (int)h, (int)w, nwin, slope};
@@ -278,7 +275,7 @@ extern "C" int fdgan_scatter_dehaze(const float* x, const float* tran, const flo
 extern "C" int fdgan_maxpool3s2_nhwc(const FdTensor* x, const FdPrologue* pro, const FdTensor* y, float* partial, int64_t capacity_floats,
                                      int64_t* rows_out, FdStream stream) {
   FD_REQUIRE(x && y && x->ptr && y->ptr, "maxpool3s2_nhwc: NULL pointer");
-  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "maxpool3s2_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(x->dtype == FD_F16 && y->dtype == FD_F16 && x->stride[3] == 1 && y->stride[3] == 1, "maxpool3s2_nhwc: NHWC fp16 views required");
   const int64_t ho = (x->h + 2 - 3) / 2 + 1, wo = (x->w + 2 - 3) / 2 + 1;
   FD_REQUIRE(y->n == x->n && y->h == ho && y->w == wo && y->c == x->c && x->c % 8 == 0, "maxpool3s2_nhwc: y must be N x %lld x %lld x C (C %% 8 == 0)",
              (long long)ho, (long long)wo);
@@ -300,7 +297,7 @@ extern "C" int fdgan_maxpool3s2_nhwc(const FdTensor* x, const FdPrologue* pro, c
 extern "C" int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* y,
                                    FdStream stream) {
   FD_REQUIRE(x && y && x->ptr && y->ptr && weight && bias, "pyramid_pool4: NULL pointer");
-  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "pyramid_pool4: NHWC bf16 views required");
+  FD_REQUIRE(x->dtype == FD_F16 && y->dtype == FD_F16 && x->stride[3] == 1 && y->stride[3] == 1, "pyramid_pool4: NHWC fp16 views required");
   FD_REQUIRE(k0 == 16 || k0 == 32, "pyramid_pool4: largest window %d (16 or 32: windows k0, k0/2, k0/4, k0/8)", k0);
   FD_REQUIRE(x->n == y->n && x->h == y->h && x->w == y->w && y->c == 4 && x->c >= 1 && x->c <= 64, "pyramid_pool4: shapes");
   FD_REQUIRE(x->h % k0 == 0 && x->w % k0 == 0, "pyramid_pool4: %lld x %lld is not a multiple of the largest window %d", (long long)x->h,
@@ -319,7 +316,7 @@ extern "C" int fdgan_bn_dropout_nhwc(const FdTensor* x, const float* mean, const
                                      const float* mask, const FdTensor* y, FdStream stream) {
   FD_REQUIRE(x && y && x->ptr && y->ptr, "bn_dropout_nhwc: NULL pointer");
   FD_REQUIRE((mean == nullptr) == (var == nullptr), "bn_dropout_nhwc: mean and var go together");
-  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1, "bn_dropout_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(x->dtype == FD_F16 && y->dtype == FD_F16 && x->stride[3] == 1 && y->stride[3] == 1, "bn_dropout_nhwc: NHWC fp16 views required");
   FD_REQUIRE(x->n == y->n && x->h == y->h && x->w == y->w && x->c == y->c, "bn_dropout_nhwc: shape mismatch");
   FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0, "bn_dropout_nhwc: 16-byte alignment");
   for (int i = 0; i < 3; ++i) FD_REQUIRE(x->stride[i] % 8 == 0 && y->stride[i] % 8 == 0, "bn_dropout_nhwc: strides must be multiples of 8");

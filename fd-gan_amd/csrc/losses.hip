@@ -1,6 +1,6 @@
 // losses.hip -- the scalar reductions between the networks' outputs and the number that drives backward:
 // L1 / MSE / BCE means on fp32 tensors (image-sized: 3 x 256 x 256, D's 126 x 126 sigmoid map) with their gradient in
-// the same pass, and the perceptual MSE between two NHWC bf16 feature maps of Vgg16 read in place -- no NCHW fp32
+// the same pass, and the perceptual MSE between two NHWC fp16 feature maps of Vgg16 read in place -- no NCHW fp32
 // copies of the feature maps, no elementwise torch kernels.  Reductions are two-stage and ordered (per-workgroup
 // partials, then one workgroup sums them in index order in fp64): bit-reproducible run to run.
 //
@@ -134,12 +134,11 @@ __global__ __launch_bounds__(256) void mse_nhwc_kernel(MseNhwcArgs a) {
     const long long n = p / a.H;
     const u32x4 av = *reinterpret_cast<const u32x4*>(a.a + n * a.a_sn + (long long)y * a.a_sh + (long long)x * a.a_sw + c8 * 8);
     const u32x4 bv = *reinterpret_cast<const u32x4*>(a.b + n * a.b_sn + (long long)y * a.b_sh + (long long)x * a.b_sw + c8 * 8);
-    const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, av), f32x8) -
-                    __builtin_convertvector(__builtin_bit_cast(bf16x8, bv), f32x8);
+    const f32x8 d = fd_cvt8<FmtA>(av) - fd_cvt8<FmtA>(bv);      // feature maps: fp16
     if (BWD) {
       f32x8 gv = d * up;
       if (a.relu_mask) {
-        const f32x8 af = __builtin_convertvector(__builtin_bit_cast(bf16x8, av), f32x8);
+        const f32x8 af = fd_cvt8<FmtA>(av);
 #pragma unroll
         for (int e = 0; e < 8; ++e) gv[e] = af[e] > 0.f ? gv[e] : 0.f;
       }
@@ -157,9 +156,9 @@ int mse_setup(const FdTensor* a, const FdTensor* b, const FdTensor* g, MseNhwcAr
   FD_REQUIRE(a && b, "mse_nhwc: NULL tensor");
   for (const FdTensor* t : {a, b, g}) {
     if (!t) continue;
-    FD_REQUIRE(t->dtype == FD_BF16 && t->stride[3] == 1 && ((uintptr_t)t->ptr & 15) == 0 && t->stride[2] % 8 == 0 &&
+    FD_REQUIRE(t->dtype == (t == g ? FD_BF16 : FD_F16) && t->stride[3] == 1 && ((uintptr_t)t->ptr & 15) == 0 && t->stride[2] % 8 == 0 &&
                    t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0,
-               "mse_nhwc: NHWC bf16 views with 16-byte aligned pixels");
+               "mse_nhwc: NHWC fp16 feature views (bf16 gradient view) with 16-byte aligned pixels");
     FD_REQUIRE(t->n == a->n && t->h == a->h && t->w == a->w && t->c == a->c, "mse_nhwc: shapes differ");
   }
   FD_REQUIRE(a->c % 8 == 0 && a->c > 0, "mse_nhwc: channels must be a multiple of 8");

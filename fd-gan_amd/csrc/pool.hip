@@ -1,4 +1,4 @@
-// pool.hip -- 2x2 stride-2 max pooling on NHWC bf16 views (F.max_pool2d(h, 2, 2),
+// pool.hip -- 2x2 stride-2 max pooling on NHWC fp16 views (F.max_pool2d(h, 2, 2),
 // /root/reference/myutils/vgg16.py:31,36,42).  HBM-bound: 16 bytes (8 channels) per thread.
 #include "common.h"
 
@@ -22,17 +22,12 @@ __global__ void maxpool2_kernel(PoolArgs a) {
   const int oy = (int)(r % a.Ho);
   const long long n = r / a.Ho;
   const unsigned short* p = a.x + n * a.x_sn + (long long)(2 * oy) * a.x_sh + (long long)(2 * ox) * a.x_sw + g * 8;
-  const bf16x8 v0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-  const bf16x8 v1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sw));
-  const bf16x8 v2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sh));
-  const bf16x8 v3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw));
-  f32x8 f0 = __builtin_convertvector(v0, f32x8), f1 = __builtin_convertvector(v1, f32x8);
-  f32x8 f2 = __builtin_convertvector(v2, f32x8), f3 = __builtin_convertvector(v3, f32x8);
+  const f32x8 f0 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p)), f1 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sw));
+  const f32x8 f2 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sh)), f3 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw));
   f32x8 m;
 #pragma unroll
   for (int e = 0; e < 8; ++e) m[e] = fmaxf(fmaxf(f0[e], f1[e]), fmaxf(f2[e], f3[e]));
-  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)oy * a.y_sh + (long long)ox * a.y_sw + g * 8) =
-      __builtin_bit_cast(u32x4, __builtin_convertvector(m, bf16x8));
+  *reinterpret_cast<u32x4*>(a.y + n * a.y_sn + (long long)oy * a.y_sh + (long long)ox * a.y_sw + g * 8) = fd_pk8<FmtA>(m);
 }
 // backward: every input position belongs to exactly one 2x2 window; the gradient of the window goes to its
 // FIRST maximum in row-major order (what F.max_pool2d's backward does on ties -- frequent after a ReLU), and is
@@ -58,7 +53,7 @@ __global__ void maxpool2_bwd_kernel(PoolBwdArgs a) {
   const long long xo[4] = {0, a.x_sw, a.x_sh, a.x_sh + a.x_sw};
   f32x8 f[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) f[q] = __builtin_convertvector(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + xo[q])), f32x8);
+  for (int q = 0; q < 4; ++q) f[q] = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + xo[q]));   // x: the forward activation (fp16); dy / dx: bf16
   const f32x8 d = __builtin_convertvector(
       __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a.dy + n * a.dy_sn + (long long)oy * a.dy_sh + (long long)ox * a.dy_sw + g * 8)), f32x8);
   int arg[8];
@@ -88,9 +83,9 @@ __global__ void maxpool2_bwd_kernel(PoolBwdArgs a) {
 
 extern "C" int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTensor* dx, FdStream stream) {
   FD_REQUIRE(x && dy && dx && x->ptr && dy->ptr && dx->ptr, "maxpool2_bwd_nhwc: NULL pointer");
-  FD_REQUIRE(x->dtype == FD_BF16 && dy->dtype == FD_BF16 && dx->dtype == FD_BF16 && x->stride[3] == 1 && dy->stride[3] == 1 &&
+  FD_REQUIRE(x->dtype == FD_F16 && dy->dtype == FD_BF16 && dx->dtype == FD_BF16 && x->stride[3] == 1 && dy->stride[3] == 1 &&
                  dx->stride[3] == 1,
-             "maxpool2_bwd_nhwc: NHWC bf16 views required");
+             "maxpool2_bwd_nhwc: x an NHWC fp16 activation, dy / dx NHWC bf16 gradients");
   FD_REQUIRE(dy->n == x->n && dy->h == x->h / 2 && dy->w == x->w / 2 && dy->c == x->c && x->c % 8 == 0 && dx->n == x->n &&
                  dx->h == x->h && dx->w == x->w && dx->c == x->c,
              "maxpool2_bwd_nhwc: shape mismatch (c must be a multiple of 8)");
@@ -108,8 +103,8 @@ extern "C" int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, co
 
 extern "C" int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream) {
   FD_REQUIRE(x && y && x->ptr && y->ptr, "maxpool2_nhwc: NULL pointer");
-  FD_REQUIRE(x->dtype == FD_BF16 && y->dtype == FD_BF16 && x->stride[3] == 1 && y->stride[3] == 1,
-             "maxpool2_nhwc: NHWC bf16 views required");
+  FD_REQUIRE(x->dtype == FD_F16 && y->dtype == FD_F16 && x->stride[3] == 1 && y->stride[3] == 1,
+             "maxpool2_nhwc: NHWC fp16 views required");
   FD_REQUIRE(y->n == x->n && y->h == x->h / 2 && y->w == x->w / 2 && y->c == x->c && x->c % 8 == 0,
              "maxpool2_nhwc: shape mismatch (c must be a multiple of 8)");
   FD_REQUIRE((((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0, "maxpool2_nhwc: 16-byte alignment");

@@ -123,11 +123,11 @@ class PlanBackward:
                 ptr = v.buf.data_ptr()
                 if ptr in alias:          # per-layer activation buffers whose gradients are consumed one at a time
                     if alias[ptr] not in self.gbuf:
-                        self.gbuf[alias[ptr]] = torch.zeros_like(v.buf)
+                        self.gbuf[alias[ptr]] = E.grad_like(v.buf)
                     self.gbuf[ptr] = self.gbuf[alias[ptr]]
                     self.multi_version.update((ptr, alias[ptr]))
                 else:
-                    self.gbuf[ptr] = torch.zeros_like(v.buf)
+                    self.gbuf[ptr] = E.grad_like(v.buf)
         # recomputation: op i's input was produced by op j and overwritten afterwards
         self.recompute = {}
         for i, r in enumerate(self.recs):
@@ -311,7 +311,7 @@ class PlanBackward:
         cin = w.cin
         if r["stride"] != 1:     # any-stride direct kernel (one thread per input element): the discriminators' 4x4 s2 convs
             hin, win = x.shape[1], x.shape[2]
-            T = E.new_act(n, hin, win, _r8(cin), p.device, zero=True)
+            T = E.new_grad(n, hin, win, _r8(cin), p.device, zero=True)
             E.conv_bwd_data_direct_nhwc(dy_view.fd, p.detach().contiguous(), desc, E.View(T, 0, cin), cin)
             return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
         hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
@@ -366,7 +366,7 @@ class PlanBackward:
                 self.flush(x)
                 self._finish_check(rec, x, gx_before, dx_ref)
             return
-        T = E.new_act(n, hin, win, _r8(cin), p.device)
+        T = E.new_grad(n, hin, win, _r8(cin), p.device)
         masked = None
         if fusable:     # the activation mask and the BatchNorm sums ride in the data-gradient kernel's epilogue
             masked = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, E.View(T, 0, cin).fd, ddesc, self.ws_bn if bn is not None else None)
@@ -444,7 +444,7 @@ class PlanBackward:
                 self._finish_check(rec, x, gx_before, dx_ref)
             return
         if meta["pool"]:
-            T2 = E.new_act(n, 2 * hin, 2 * win, _r8(cin), p.device)
+            T2 = E.new_grad(n, 2 * hin, 2 * win, _r8(cin), p.device)
             E.grad_ew(E.GRAD_UNPOOL, Tv, E.View(T2, 0, cin))
             T, Tv = T2, E.View(T2, 0, cin)
         if bn is not None:
@@ -496,7 +496,7 @@ class PlanBackward:
             dyv = gy
             if r["upsample"]:
                 n, h2, w2, _ = y.shape
-                t = E.new_act(n, h2 // 2, w2 // 2, _r8(y.c), y.buf.device)
+                t = E.new_grad(n, h2 // 2, w2 // 2, _r8(y.c), y.buf.device)
                 dyv = E.View(t, 0, y.c)
                 E.grad_ew(E.GRAD_SUMPOOL, gy, dyv)
             r["_post_relu"] = self.x_post_relu.get(i, False)

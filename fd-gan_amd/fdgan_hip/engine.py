@@ -21,12 +21,18 @@ def require_gpu(t, what):
                            "there is no CPU fallback" % what)
 
 
+ACT_DTYPE = torch.float16       # forward activations (and the forward filter images): FD_F16
+GRAD_DTYPE = torch.bfloat16     # activation gradients (and the flipped filter images): FD_BF16
+_FD_DTYPE = {torch.float16: L.FD_F16, torch.bfloat16: L.FD_BF16}
+
+
 class View:
-    """Channel slice [c0, c0+c) of an NHWC bf16 buffer of shape (N,H,W,C)."""
+    """Channel slice [c0, c0+c) of an NHWC 16-bit buffer of shape (N,H,W,C): fp16 = a forward activation, bf16 = a
+    gradient (include/fdgan_hip.h, "Two 16-bit element formats")."""
     __slots__ = ("buf", "c0", "c", "fd")
 
     def __init__(self, buf, c0=0, c=None):
-        assert buf.dtype == torch.bfloat16 and buf.dim() == 4 and buf.is_contiguous()
+        assert buf.dtype in _FD_DTYPE and buf.dim() == 4 and buf.is_contiguous()
         n, h, w, ctot = buf.shape
         c = ctot - c0 if c is None else c
         assert 0 <= c0 and c0 + c <= ctot and c > 0
@@ -35,7 +41,7 @@ class View:
         t.ptr = buf.data_ptr() + 2 * c0
         t.n, t.h, t.w, t.c = n, h, w, c
         t.stride[0], t.stride[1], t.stride[2], t.stride[3] = h * w * ctot, w * ctot, ctot, 1
-        t.dtype = L.FD_BF16
+        t.dtype = _FD_DTYPE[buf.dtype]
         self.fd = t
 
     @property
@@ -61,17 +67,35 @@ def nchw_f32_view(t):
 
 
 def new_act(n, h, w, c, device, zero=False):
+    """NHWC fp16 activation buffer."""
     f = torch.zeros if zero else torch.empty
-    return f((n, h, w, c), dtype=torch.bfloat16, device=device)
+    return f((n, h, w, c), dtype=ACT_DTYPE, device=device)
+
+
+def new_grad(n, h, w, c, device, zero=False):
+    """NHWC bf16 gradient buffer."""
+    f = torch.zeros if zero else torch.empty
+    return f((n, h, w, c), dtype=GRAD_DTYPE, device=device)
+
+
+def grad_like(act_buf, zero=True):
+    """The bf16 gradient buffer mirroring an activation buffer (same shape, so the same views apply)."""
+    f = torch.zeros if zero else torch.empty
+    return f(act_buf.shape, dtype=GRAD_DTYPE, device=act_buf.device)
 
 
 class PackedWeight:
-    """bf16 MFMA-fragment image of one conv filter + the recipe to refresh it."""
+    """MFMA-fragment image of one conv filter + the recipe to refresh it: fp16 for a forward convolution, bf16 for the
+    flipped image a data-gradient convolution multiplies gradients with."""
 
-    def __init__(self, param, cout, cin, k, transposed=False, flip=False, stride=1, layout=None):
+    def __init__(self, param, cout, cin, k, transposed=False, flip=False, stride=1, layout=None, grad=None):
         lib = L.load()
         self.param, self.cout, self.cin, self.k = param, cout, cin, k
         self.transposed, self.flip = int(transposed), int(flip)
+        # grad: the image multiplies GRADIENTS (a data-gradient convolution) -> bf16.  Default: a flipped image is one;
+        # the data-gradient twin of a ConvTranspose2d 1x1 is not flipped (its IOHW weight already is the transposed
+        # filter), so NetPlan.flipped_weight says grad=True explicitly.
+        self.dtype = L.FD_BF16 if (flip if grad is None else grad) else L.FD_F16
         # the library names the fragment order its kernel for this conv consumes
         self.layout = lib.fdgan_conv_weight_layout(cout, cin, k, stride) if layout is None else layout
         self.nbytes = lib.fdgan_packed_weight_bytes(cout, cin, k)
@@ -82,7 +106,7 @@ class PackedWeight:
         p = self.param.detach()
         assert p.dtype == torch.float32 and p.is_contiguous()
         L.check(lib.fdgan_pack_conv_weight(p.data_ptr(), self.cout, self.cin, self.k, self.transposed, self.flip,
-                                           self.layout, self.buf.data_ptr(), self.nbytes, stream_ptr()),
+                                           self.layout, self.dtype, self.buf.data_ptr(), self.nbytes, stream_ptr()),
                 "pack_conv_weight")
 
 
@@ -100,6 +124,7 @@ class PackTable:
             assert p.dtype == torch.float32 and p.is_contiguous()
             j.w, j.packed = p.data_ptr(), w.buf.data_ptr()
             j.cout, j.cin, j.ksize, j.transposed, j.flip, j.layout = w.cout, w.cin, w.k, w.transposed, w.flip, w.layout
+            j.dtype = w.dtype
             j.first_unit = first
             first += lib.fdgan_pack_units(w.cout, w.cin, w.k, w.layout)
         self.total_units = first
@@ -180,13 +205,13 @@ def bn_finalize(stats_buf, info, channels, count, mean, var, c0=0):
 
 def to_nhwc(x_nchw_f32, view):
     n, c, h, w = x_nchw_f32.shape
-    L.check(L.load().fdgan_nchw_f32_to_nhwc_bf16(x_nchw_f32.data_ptr(), n, c, h, w, C.byref(view.fd), stream_ptr()),
-            "nchw_f32_to_nhwc_bf16")
+    L.check(L.load().fdgan_nchw_f32_to_nhwc(x_nchw_f32.data_ptr(), n, c, h, w, C.byref(view.fd), stream_ptr()),
+            "nchw_f32_to_nhwc")
 
 
 def to_nchw(view, out_f32):
-    L.check(L.load().fdgan_nhwc_bf16_to_nchw_f32(C.byref(view.fd), out_f32.data_ptr(), stream_ptr()),
-            "nhwc_bf16_to_nchw_f32")
+    L.check(L.load().fdgan_nhwc_to_nchw_f32(C.byref(view.fd), out_f32.data_ptr(), stream_ptr()),
+            "nhwc_to_nchw_f32")
 
 
 def maxpool2(src, dst):
@@ -222,7 +247,7 @@ def laplacian3(x):
 
 
 def fusion_input_nhwc(img, view, use_input_norm=True):
-    """img: NCHW fp32 (n,c,h,w) -> channels [img | LF | HF] of the NHWC bf16 view (D's input)."""
+    """img: NCHW fp32 (n,c,h,w) -> channels [img | LF | HF] of the NHWC fp16 view (D's input)."""
     n, c, h, w = img.shape
     L.check(L.load().fdgan_fusion_input_nhwc(img.data_ptr(), n, c, h, w, C.byref(view.fd), int(bool(use_input_norm)),
                                              stream_ptr()), "fusion_input_nhwc")
@@ -258,19 +283,19 @@ def maxpool3s2(x, pro, y, stats_buf=None):
 
 
 def bn_dropout(x, mean, var, gamma, beta, eps, mask, y):
-    """y = mask[n][c] * bn(x) on NHWC bf16 views; any of (mean, var) / gamma / beta / mask may be None."""
+    """y = mask[n][c] * bn(x) on NHWC fp16 views; any of (mean, var) / gamma / beta / mask may be None."""
     ptr = lambda t: t.data_ptr() if t is not None else None
     L.check(L.load().fdgan_bn_dropout_nhwc(C.byref(x.fd), ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), ptr(mask),
                                            C.byref(y.fd), stream_ptr()), "bn_dropout_nhwc")
 
 
 class StridedView:
-    """An NHWC bf16 view that steps over rows and pixels of its buffer: channels [c0, c0 + c) of the pixels
+    """An NHWC 16-bit view that steps over rows and pixels of its buffer: channels [c0, c0 + c) of the pixels
     (y0 + sy i, x0 + sx j), i < h, j < w -- the output positions of one parity of a stride-2 transposed convolution."""
     __slots__ = ("buf", "c0", "c", "fd")
 
     def __init__(self, buf, c0, c, y0, x0, sy, sx, h, w):
-        assert buf.dtype == torch.bfloat16 and buf.dim() == 4 and buf.is_contiguous()
+        assert buf.dtype in _FD_DTYPE and buf.dim() == 4 and buf.is_contiguous()
         n, hh, ww, ctot = buf.shape
         assert y0 + sy * (h - 1) < hh and x0 + sx * (w - 1) < ww and c0 + c <= ctot
         self.buf, self.c0, self.c = buf, c0, c
@@ -278,7 +303,7 @@ class StridedView:
         t.ptr = buf.data_ptr() + 2 * ((y0 * ww + x0) * ctot + c0)
         t.n, t.h, t.w, t.c = n, h, w, c
         t.stride[0], t.stride[1], t.stride[2], t.stride[3] = hh * ww * ctot, sy * ww * ctot, sx * ctot, 1
-        t.dtype = L.FD_BF16
+        t.dtype = _FD_DTYPE[buf.dtype]
         self.fd = t
 
     @property

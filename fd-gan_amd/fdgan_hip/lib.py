@@ -12,10 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfdgan_hip.so")
 
 FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
-FD_BF16, FD_F32 = 0, 1
+FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class FdganLibraryError(RuntimeError):
@@ -36,7 +36,8 @@ class FdPrologue(C.Structure):
 
 class FdPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
-                ("transposed", C.c_int32), ("flip", C.c_int32), ("layout", C.c_int32), ("first_unit", C.c_int64)]
+                ("transposed", C.c_int32), ("flip", C.c_int32), ("layout", C.c_int32), ("dtype", C.c_int32), ("_pad", C.c_int32),
+                ("first_unit", C.c_int64)]
 
 
 class FdConvDesc(C.Structure):
@@ -61,7 +62,7 @@ SIGNATURES = {
     "fdgan_device_arch": (C.c_char_p, []),
     "fdgan_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fdgan_conv_weight_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "fdgan_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdgan_pack_units": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "fdgan_pack_conv_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -71,9 +72,9 @@ SIGNATURES = {
                                    C.POINTER(FdTensor), C.POINTER(FdStats), C.POINTER(FdConvDesc), C.c_void_p]),
     "fdgan_bn_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
-    "fdgan_nchw_f32_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                              C.POINTER(FdTensor), C.c_void_p]),
-    "fdgan_nhwc_bf16_to_nchw_f32": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p]),
+    "fdgan_nchw_f32_to_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                         C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_nhwc_to_nchw_f32": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p]),
     "fdgan_copy_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_scatter_dehaze": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),

@@ -163,7 +163,7 @@ class NetPlan:
         t = self.flipped.get(id(w))
         if t is None:
             p = w.param.detach()
-            t = E.PackedWeight(p, w.cin, w.cout, w.k, transposed=False, flip=not w.transposed, layout=L.WLAYOUT_CHUNK32)
+            t = E.PackedWeight(p, w.cin, w.cout, w.k, transposed=False, flip=not w.transposed, layout=L.WLAYOUT_CHUNK32, grad=True)
             t.pack()
             self.flipped[id(w)] = t
             self.keep.append(t)

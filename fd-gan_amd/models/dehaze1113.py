@@ -422,7 +422,7 @@ class FDGAN(_PlannedModule):
         B = _plan_backward(P)
         B.zero_()
         n, _, h, w = out.shape
-        g8 = E.new_act(n, h, w, 8, out.device)
+        g8 = E.new_grad(n, h, w, 8, out.device)
         E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))                          # dehaze = tanh(conv_refin3(x6)) (:799)
         grads = {}
         last = dict(x=E.View(P.x6), w=P.w_last, k=3, pad=1, stride=1, bias=self.conv_refin3.bias, pro=None)
@@ -800,7 +800,7 @@ class D(_PlannedModule):
         B = _plan_backward(P)
         B.zero_()
         n, _, h5, w5 = out.shape
-        g8 = E.new_act(n, h5, w5, 8, out.device)
+        g8 = E.new_grad(n, h5, w5, 8, out.device)
         E.out_act_bwd(dout, out, L.ACT_SIGMOID, E.View(g8))
         grads = {}
         last = dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,

@@ -116,7 +116,7 @@ class D(_PlannedModule):
         B = _plan_backward(P)
         B.zero_()
         n, _, h5, w5 = out.shape
-        g8 = E.new_act(n, h5, w5, 8, out.device)
+        g8 = E.new_grad(n, h5, w5, 8, out.device)
         E.out_act_bwd(dout, out, L.ACT_SIGMOID, E.View(g8))
         grads = {}
         last = dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,

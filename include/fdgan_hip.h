@@ -16,7 +16,16 @@
  *    synchronisation.  Re-entrant; one process per GPU in data-parallel runs.
  *  - Return value: FD_OK (0) or a negative FD_E* code; the message is available from
  *    fdgan_last_error() (thread-local).  Nothing throws or aborts across the ABI.
- *  - Activations are NHWC bf16 "views": element (n,h,w,c) lives at
+ *  - Two 16-bit element formats (FdTensor.dtype), same layout, strides and sizes:
+ *      FD_F16  (IEEE fp16)  everything the FORWARD pass stores or multiplies: activations and the forward
+ *                           filter images.  With bf16 storage the generator's output sits 46.8 dB from the
+ *                           reference's fp32 CPU path whatever the kernels do; with fp16 (11-bit significand)
+ *                           64 dB -- the 0.02 dB / 1e-3 metric budget needs >= 54 dB ("Precision").
+ *      FD_BF16              activation GRADIENTS and the flipped filter images the data-gradient kernels multiply
+ *                           them with: unscaled loss gradients (1e-7 per pixel) need fp32's exponent range.
+ *    Both run on the MFMA pipe at the same rate (v_mfma_f32_16x16x32_f16 / _bf16), fp32 accumulation.  Every entry
+ *    point checks the dtype of each view it is given; "activation" below means FD_F16, "gradient" FD_BF16.
+ *  - Activations are NHWC 16-bit "views": element (n,h,w,c) lives at
  *    ptr + n*stride[0] + h*stride[1] + w*stride[2] + c (stride[3] must be 1), so a
  *    view can be a channel slice of a wider dense-block / concat buffer
  *    (torch.cat, dehaze1113.py:275,773,783,786, is never materialised).
@@ -45,7 +54,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 6
+#define FDGAN_ABI_VERSION 7
 
 enum FdStatus {
   FD_OK = 0,
@@ -55,7 +64,7 @@ enum FdStatus {
   FD_ESTATE = -4        /* plan API misuse                               */
 };
 
-enum FdDtype { FD_BF16 = 0, FD_F32 = 1 };
+enum FdDtype { FD_BF16 = 0, FD_F32 = 1, FD_F16 = 2 };
 
 enum FdAct {
   FD_ACT_NONE = 0,
@@ -146,7 +155,7 @@ int fdgan_version(void); /* == FDGAN_ABI_VERSION */
 const char* fdgan_device_arch(void);
 
 /* ---- weights ------------------------------------------------------------- */
-/* Fragment orders of the packed bf16 filter image (1 KiB per 16 cout x 32 k fragment):
+/* Fragment orders of the packed 16-bit filter image (1 KiB per 16 cout x 32 k fragment):
  *   CHUNK32: k = 32-channel chunk-major, tap, then 8-channel groups (all kernels)
  *   X64    : 1x1 only; 64-channel k-steps whose lane groups own 16 consecutive channels,
  *            the order the x-stream kernel reads activations in (conv1x1_xs.hip).
@@ -154,15 +163,17 @@ const char* fdgan_device_arch(void);
  * with it and pass it back in FdConvDesc.w_layout. */
 enum FdWeightLayout { FD_WLAYOUT_CHUNK32 = 0, FD_WLAYOUT_X64 = 1 };
 int fdgan_conv_weight_layout(int cout, int cin, int ksize, int stride);
-/* Bytes of the packed bf16 image of a (cout, cin, k, k) filter (upper bound over layouts). */
+/* Bytes of the packed 16-bit image of a (cout, cin, k, k) filter (upper bound over layouts). */
 size_t fdgan_packed_weight_bytes(int cout, int cin, int ksize);
 /* fp32 OIHW (nn.Conv2d.weight) or, with transposed != 0, IOHW
  * (nn.ConvTranspose2d.weight, dehaze1113.py:363 -- a 1x1 stride-1 transposed conv
- * is a 1x1 conv with the weight indexed (Cin,Cout)) -> packed bf16.
+ * is a 1x1 conv with the weight indexed (Cin,Cout)) -> packed image.
  * With flip != 0 the filter is additionally rotated 180 degrees and its in/out
- * channels swapped (the data-gradient filter). */
+ * channels swapped (the data-gradient filter).  dtype: FD_F16 for the image a forward
+ * convolution multiplies activations with, FD_BF16 for the image a data-gradient
+ * convolution multiplies gradients with. */
 int fdgan_pack_conv_weight(const float* w, int cout, int cin, int ksize, int transposed, int flip,
-                           int layout, void* packed, size_t packed_bytes, FdStream stream);
+                           int layout, int dtype, void* packed, size_t packed_bytes, FdStream stream);
 
 /* Batched form for a whole network: `jobs` is a table in DEVICE memory (it is read by the kernel), one entry per packed
  * image -- e.g. every filter of a generator in both orientations -- and the launch packs all of them at once (one
@@ -173,6 +184,8 @@ typedef struct FdPackJob {
   const float* w;
   void* packed;
   int32_t cout, cin, ksize, transposed, flip, layout;
+  int32_t dtype; /* FD_F16 (forward image) or FD_BF16 (gradient-side image) */
+  int32_t _pad;
   int64_t first_unit;
 } FdPackJob;
 int64_t fdgan_pack_units(int cout, int cin, int ksize, int layout);
@@ -182,7 +195,8 @@ int fdgan_pack_conv_weights(const FdPackJob* jobs_device, int64_t njobs, int64_t
 /* Replaces nn.Conv2d / nn.ConvTranspose2d(1x1) forward and the BN/ReLU/pool/cat/
  * upsample/tanh/sigmoid modules fused around it:
  *   y = act_e( conv_k,s,p( pool?( act_p( bn?(x) ) ) ) + bias )   [nearest x2]
- * x: NHWC bf16 view with c = Cin.  y: NHWC bf16 view, or NCHW fp32, with c = Cout.
+ * x: NHWC fp16 view with c = Cin.  y: NHWC fp16 view, or NCHW fp32, with c = Cout.
+ * (x bf16: a plain stride-1 convolution over GRADIENTS with a bf16 filter image -- the unfused data gradient; y bf16.)
  * w_packed: from fdgan_pack_conv_weight(cout, cin, ksize).  bias: fp32[Cout] or NULL.
  * Call sites replaced: torchvision _DenseLayer.conv1/conv2, _Transition.conv,
  * dehaze1113.py:262,265,363 (dy blocks), :744-755 (refine convs), :196-222 (D),
@@ -200,13 +214,13 @@ int fdgan_bn_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t 
                       int64_t count, float* mean, float* var, FdStream stream);
 
 /* ---- layout helpers --------------------------------------------------------- */
-/* NCHW fp32 (n,c,h,w contiguous) -> NHWC bf16 view y (y->c >= c; channels c..y->c-1
- * are written as zeros). */
-int fdgan_nchw_f32_to_nhwc_bf16(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
-                                const FdTensor* y, FdStream stream);
-/* NHWC bf16 view -> NCHW fp32 contiguous. */
-int fdgan_nhwc_bf16_to_nchw_f32(const FdTensor* x, float* y, FdStream stream);
-/* Channel-slice copy between NHWC bf16 views of equal n,h,w,c (c multiple of 8). */
+/* NCHW fp32 (n,c,h,w contiguous) -> NHWC fp16 / bf16 view y, rounded to y->dtype (y->c >= c; channels
+ * c..y->c-1 are written as zeros). */
+int fdgan_nchw_f32_to_nhwc(const float* x, int64_t n, int64_t c, int64_t h, int64_t w,
+                           const FdTensor* y, FdStream stream);
+/* NHWC fp16 / bf16 view -> NCHW fp32 contiguous. */
+int fdgan_nhwc_to_nchw_f32(const FdTensor* x, float* y, FdStream stream);
+/* Channel-slice copy between NHWC views of one 16-bit format and equal n,h,w,c (c multiple of 8). */
 int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
 
 /* ---- legacy DCPDN-era networks (/root/reference/models/dehaze22.py G :205-362, G2 :364-488,
@@ -219,14 +233,14 @@ int fdgan_copy_nhwc(const FdTensor* src, const FdTensor* dst, FdStream stream);
  * x's size; the four maps land in the 4-channel view y (typically a slice of the buffer the next conv reads).  H and W
  * must be multiples of k0.  weight: [4][C] fp32, bias: [4] fp32.
  *
- * fdgan_bn_dropout_nhwc: y = mask[n][c] * ((x - mean[c]) / sqrt(var[c] + eps) * gamma[c] + beta[c]) on NHWC bf16 views:
+ * fdgan_bn_dropout_nhwc: y = mask[n][c] * ((x - mean[c]) / sqrt(var[c] + eps) * gamma[c] + beta[c]) on NHWC fp16 views:
  * train-mode nn.BatchNorm2d followed by train-mode nn.Dropout2d (dehaze22.py:60-63; the caller draws the (N, C) mask of
  * 0 / 1/(1-p) values).  mean == NULL: no normalisation; gamma / beta == NULL: 1 / 0; mask == NULL: no dropout.  Padding
  * channels of the 8-channel groups are written as zero. */
 /* fdgan_scatter_dehaze: the arithmetic between the sub-networks of `dehaze` (dehaze22.py:699-715), all tensors contiguous
  * N x 3 x H x W fp32:  A = upsample_nearest(LeakyReLU(slope)(avg_pool2d(atp, H)), (H, W))  (window_mean: scratch of
  * N * 3 * (W / H) floats),  J = (x - A) / (|tran| + eps) + A.  Outputs: atp_out = A, dehaze2 = J (two of the network's four
- * return values) and `cat`, an N x H x W x 8 NHWC bf16 view receiving [J (3) | x (3) | 0 0], the input of refine1. */
+ * return values) and `cat`, an N x H x W x 8 NHWC fp16 view receiving [J (3) | x (3) | 0 0], the input of refine1. */
 int fdgan_scatter_dehaze(const float* x, const float* tran, const float* atp, int64_t n, int64_t h, int64_t w, float slope, float eps,
                          float* window_mean, float* atp_out, float* dehaze2, const FdTensor* cat, FdStream stream);
 /* fdgan_maxpool3s2_nhwc: y = MaxPool2d(kernel 3, stride 2, padding 1)(act(bn(x))) -- torchvision DenseNet-121's norm0 / relu0 /
@@ -269,11 +283,12 @@ int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
 /* ---- pooling ------------------------------------------------------------------- */
 /* ---- backward (first version: D's training path; the generator's dense blocks follow) -------------
  * Autograd of the fused forward op  a = act(bn(x)); y = conv(a, W) + b  (nn.Conv2d / nn.BatchNorm2d /
- * nn.LeakyReLU as composed in dehaze1113.py:188-230).  Gradients of activations are NHWC bf16 views
- * like the activations themselves; parameter gradients are fp32 in the parameter's own layout.
+ * nn.LeakyReLU as composed in dehaze1113.py:188-230).  Gradients of activations are NHWC bf16 views laid out
+ * like the (fp16) activations themselves; parameter gradients are fp32 in the parameter's own layout.  In every
+ * signature below x / fwd_x / ref (a forward activation) is FD_F16 and dy / da / dpre / dx / g (a gradient) FD_BF16.
  *
  *  data gradient    da = conv^T(dy, W): call fdgan_conv2d_fwd on dy with the filter packed by
- *                   fdgan_pack_conv_weight(w, cout' = cin, cin' = cout, k, 0, flip = 1, ...) and pad' = k-1-pad
+ *                   fdgan_pack_conv_weight(w, cout' = cin, cin' = cout, k, 0, flip = 1, layout, FD_BF16, ...) and pad' = k-1-pad
  *                   (stride 1); fdgan_conv2d_bwd_data_direct covers any stride for gradients w.r.t.
  *                   network inputs (NCHW fp32, few channels).
  *  weight gradient  fdgan_conv2d_bwd_weight: dW[co][ci][ky][kx] = sum_px dy[px][co] * a[px*s + k - pad][ci],
@@ -349,7 +364,7 @@ int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipp
  * C = -gamma*rstd*dbeta/count - B*mean (pro: the forward prologue's mean / var / gamma / eps). */
 int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,
                       float* bsum, float* csum, FdStream stream);
-/* dx += bsum[c] * x + csum[c] (NHWC bf16 views of equal shape). */
+/* dx += bsum[c] * x + csum[c] (x: NHWC fp16 activation, dx: NHWC bf16 gradient of equal shape). */
 int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
 /* Pooled prologues (pro->pool2, the transitions: BatchNorm + ReLU + 2x2 average in front of the 1x1 conv,
  * torchvision _Transition as used at dehaze1113.py:716-728): fdgan_bn_act_bwd and fdgan_bn_bwd_apply accept the HALF-resolution
@@ -389,7 +404,7 @@ int fdgan_ssim_bwd(const float* x, const float* y, const float* da, const float*
  * t == NULL: the constant target t_const.  `partial` receives *nparts per-workgroup sums of the UNSCALED loss terms;
  * fdgan_sum_partials(partial, nparts, 1.0 / n, out) turns them into the mean (fp64 accumulation, index order).
  * grad (optional): d mean / d x, fp32, same shape.
- * fdgan_mse_nhwc_fwd / _bwd: mean squared difference of two NHWC bf16 views (Vgg16's tapped feature maps,
+ * fdgan_mse_nhwc_fwd / _bwd: mean squared difference of two NHWC fp16 views (Vgg16's tapped feature maps; the gradient view is bf16,
  * myutils/vgg16.py:27-49, read where the conv kernels left them): partial sums pre-multiplied by `scale` (1 / numel for
  * a mean; several maps may share one partial array and one fdgan_sum_partials), and g = upstream[0] * scale * (a - b)
  * written to the gradient view of `a` (scale = 2 / numel), `upstream` a DEVICE scalar so no host sync is needed.
@@ -414,7 +429,7 @@ int fdgan_cx_rows_fwd(const float* d, int64_t rows, int64_t n, float sigma, floa
 int fdgan_cx_rows_bwd(const float* d, int64_t rows, int64_t n, float sigma, float eps, const float* dmin, const float* S,
                       const int32_t* jmin, const float* gm, float* gd, FdStream stream);
 
-/* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC bf16 views;
+/* F.max_pool2d(h, kernel_size=2, stride=2) (myutils/vgg16.py:31,36,42) on NHWC fp16 views (backward: x fp16, dy / dx bf16);
  * y is (n, h/2, w/2, c), c a multiple of 8. */
 int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStream stream);
 /* its backward: dx += dy routed to the first maximum of each 2x2 window of x (F.max_pool2d's tie rule) */
@@ -429,7 +444,7 @@ int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTenso
  * fdgan_laplacian3_fwd = Laplacian(3).forward (loss.py:245-304): depthwise 3x3, ones with
  *                        centre -8, zero padding 1, not normalised.
  * fdgan_fusion_input_nhwc fuses both with the layout change D needs: reads img once and writes
- *   channels [img | Blur(img) | Laplacian(img)] (3*c) of the NHWC bf16 view y (the concat fed to
+ *   channels [img | Blur(img) | Laplacian(img)] (3*c) of the NHWC fp16 view y (the concat fed to
  *   D, facades/network.png); channels of y beyond 3*c are left untouched. */
 int fdgan_blur15_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
                      FdStream stream);

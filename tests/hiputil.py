@@ -1,6 +1,7 @@
 """Helpers for the GPU parity tests: an fp32/fp64 torch-CPU statement of exactly what
-one fused conv launch computes (including where the kernel rounds to bf16), used
-as the per-kernel checker.  Test infrastructure only."""
+one fused conv launch computes (including where the kernel rounds to fp16 -- forward
+activations and filter images -- or bf16 -- gradients and the operands multiplied with
+them), used as the per-kernel checker.  Test infrastructure only."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -8,8 +9,19 @@ import torch.nn.functional as F
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 
 
+ACT_DTYPE, GRAD_DTYPE = torch.float16, torch.bfloat16     # fdgan_hip.engine.ACT_DTYPE / GRAD_DTYPE
+
+
 def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+def f16_round(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+act_round = f16_round      # what the forward pass stores / multiplies
+grad_round = bf16_round    # activation gradients, and the operands of the gradient-side MFMAs
 
 
 def act(t, a):
@@ -26,7 +38,7 @@ def act(t, a):
 
 def fused_conv_ref(x, w, bias=None, k=1, stride=1, pad=0, p_act=ACT_NONE, bn=None, pool=False, e_act=ACT_NONE,
                    upsample=False, transposed=False):
-    """x: NCHW fp32 holding bf16-representable values.  w: fp32 OIHW (IOHW if transposed).
+    """x: NCHW fp32 holding fp16-representable values.  w: fp32 OIHW (IOHW if transposed).
     bn: None or dict(mean, var, gamma, beta, eps).  Returns (y_fp32_unrounded, mean, var)."""
     a = x.float()
     if bn is not None:
@@ -36,11 +48,11 @@ def fused_conv_ref(x, w, bias=None, k=1, stride=1, pad=0, p_act=ACT_NONE, bn=Non
     a = act(a, p_act)
     if pool:
         a = F.avg_pool2d(a, 2)
-    a = bf16_round(a)
+    a = act_round(a)
     wf = w.float()
     if transposed:
         wf = wf.permute(1, 0, 2, 3)
-    wf = bf16_round(wf)
+    wf = act_round(wf)
     y = F.conv2d(a.double(), wf.double(), None, stride, pad).float()
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
@@ -67,27 +79,28 @@ def seeded(shape, seed, lo=-1.0, hi=1.0):
 
 
 def emulate_bf16_operands(module, round_grads=False):
-    """Turns an fp32 oracle network into a statement of what the HIP path computes: every conv sees its
-    filter, its (activated) input and its stored output rounded to bf16 -- straight-through for autograd -- and in-place
+    """(Name kept from the all-bf16 rounds.)  Turns an fp32 oracle network into a statement of what the HIP path computes:
+    every conv sees its filter, its (activated) input and its stored output rounded to fp16 -- the forward element format;
+    activation gradients are rounded to bf16 with round_grads -- straight-through for autograd -- and in-place
     activations are made out-of-place so conv outputs can be inspected.  Accumulation stays fp32/fp64.
     Needed for GRADIENT parity: ReLU / LeakyReLU derivatives are discontinuous, so an oracle whose
     pre-activations differ by the bf16 rounding of the operands flips a few masks in a thousand, which
     alone is a 5-10 % rms difference in every upstream gradient."""
     import torch.nn as nn
-    st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+    st = lambda t: t + (t.to(torch.float16).float() - t).detach()
     if round_grads:
         # round_grads: the gradient arriving at every conv input is rounded to bf16 as well -- the HIP path keeps activation
         # GRADIENTS in NHWC bf16 buffers like the activations.  This matters for cancellation-dominated reductions (a
         # BatchNorm bias gradient whose terms sum to ~0 analytically): their noise floor is set by that storage.
         def st(t):          # noqa: F811
-            r = t + (t.to(torch.bfloat16).float() - t).detach()
+            r = t + (t.to(torch.float16).float() - t).detach()
             if r.requires_grad:
                 r.register_hook(lambda g: g.to(torch.bfloat16).float())
             return r
     with torch.no_grad():
         for m in module.modules():
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-                m.weight.copy_(m.weight.to(torch.bfloat16).float())
+                m.weight.copy_(m.weight.to(torch.float16).float())
     for m in module.modules():
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
             m.register_forward_pre_hook(lambda mod, inp: (st(inp[0]),))

@@ -32,13 +32,13 @@ def test_host_only_entry_points():
     assert lib.fdgan_packed_weight_bytes(3, 16, 3) == 1 * 9 * 1 * 1024
     assert lib.fdgan_packed_weight_bytes(0, 16, 3) == 0
     # fwd_info is a dry run (no HIP call): grid of the headline shape B=16 @256^2, 128->32 3x3
-    x = torch.empty((16, 256, 256, 128), dtype=torch.bfloat16, device="meta")
+    x = torch.empty((16, 256, 256, 128), dtype=torch.float16, device="meta")
 
     def fd(n, h, w, c, pitch):
         t = L.FdTensor()
         t.ptr, t.n, t.h, t.w, t.c = 4096, n, h, w, c
         t.stride[0], t.stride[1], t.stride[2], t.stride[3] = h * w * pitch, w * pitch, pitch, 1
-        t.dtype = L.FD_BF16
+        t.dtype = L.FD_F16
         return t
     info = E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1))
     # persistent-filter kernel: one 8-wave workgroup per CU, one statistics row per workgroup

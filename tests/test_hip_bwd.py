@@ -1,11 +1,12 @@
-"""GPU parity of the backward primitives (through the C ABI) against torch autograd on CPU in fp64,
-with operands rounded to bf16 where the kernels see bf16."""
+"""GPU parity of the backward primitives (through the C ABI) against torch autograd on CPU in fp64, with operands
+rounded where the kernels round them: the forward input x is an fp16 tensor, dy / G are bf16, the recomputed
+a = act(bn(x)) is rounded to bf16 (it is multiplied with the bf16 dy), the flipped filter image is bf16."""
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from hiputil import bf16_round, rel_rms, seeded
+from hiputil import bf16_round, f16_round, rel_rms, seeded
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -18,12 +19,17 @@ def E():
     return engine
 
 
-def _nhwc(t, pitch=None, dev=DEV):
+def _nhwc(t, pitch=None, dev=DEV, dtype=torch.bfloat16):
+    """NCHW fp32 -> NHWC device buffer: bf16 for a gradient (the default), fp16 (_nhwc_a) for a forward activation."""
     n, c, h, w = t.shape
     pitch = pitch or (c + 7) // 8 * 8
-    buf = torch.zeros((n, h, w, pitch), dtype=torch.bfloat16, device=dev)
-    buf[..., :c] = t.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    buf = torch.zeros((n, h, w, pitch), dtype=dtype, device=dev)
+    buf[..., :c] = t.permute(0, 2, 3, 1).to(dev).to(dtype)
     return buf
+
+
+def _nhwc_a(t, pitch=None, dev=DEV):
+    return _nhwc(t, pitch, dev, torch.float16)
 
 
 def _from_nhwc(buf, c):
@@ -41,7 +47,7 @@ def _bn_params(c, seed):
 def test_weight_gradient(E, cin, cout, k, stride, pad, bn, slope):
     from fdgan_hip import lib as L
     n, h, w = 2, 13, 18
-    x = bf16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     dy = bf16_round(seeded((n, cout, ho, wo), 2, -1.0, 1.0))
     p = _bn_params(cin, 10) if bn else None
@@ -57,7 +63,7 @@ def test_weight_gradient(E, cin, cout, k, stride, pad, bn, slope):
     wref = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
     y = F.conv2d(a, wref, None, stride, pad)
     y.backward(dy.double())
-    xb, dyb = _nhwc(x), _nhwc(dy)
+    xb, dyb = _nhwc_a(x), _nhwc(dy)
     pro = None
     if bn or act != L.ACT_NONE:
         kw = dict(act=act)
@@ -78,7 +84,7 @@ def test_weight_gradient(E, cin, cout, k, stride, pad, bn, slope):
 def test_prologue_backward(E, c, slope, bn):
     from fdgan_hip import lib as L
     n, h, w = 3, 11, 14
-    x = bf16_round(seeded((n, c, h, w), 3, -1.5, 1.5))
+    x = f16_round(seeded((n, c, h, w), 3, -1.5, 1.5))
     da = bf16_round(seeded((n, c, h, w), 4, -1.0, 1.0))
     act = {0.0: L.ACT_RELU, 0.2: L.ACT_LEAKY02}[slope]
     xr = x.double().requires_grad_(True)
@@ -92,7 +98,7 @@ def test_prologue_backward(E, c, slope, bn):
         pre = xr
     a = torch.where(pre > 0, pre, pre * slope)
     a.backward(da.double())
-    xb, dab = _nhwc(x, pitch=(c + 7) // 8 * 8 + 8), _nhwc(da)
+    xb, dab = _nhwc_a(x, pitch=(c + 7) // 8 * 8 + 8), _nhwc(da)
     xv, dav = E.View(xb, 0, c), E.View(dab, 0, c)
     if bn:
         keep = [mean.to(DEV), var.to(DEV), gamma.detach().float().to(DEV), beta.detach().float().to(DEV)]   # the struct holds raw pointers
@@ -138,7 +144,7 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
     dy = bf16_round(seeded((n, cout, ho, wo), 9, -1.0, 1.0))
     wt = seeded((cout, cin, k, k), 10, -0.3, 0.3)
     xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
-    F.conv2d(xr, bf16_round(wt).double(), None, s, pad).backward(dy.double())
+    F.conv2d(xr, f16_round(wt).double(), None, s, pad).backward(dy.double())      # the forward's fp16 filter
     dx = torch.full((n, cin, h, w), 5.0, dtype=torch.float32, device=DEV)
     dyv, wdev = E.View(_nhwc(dy), 0, cout), wt.to(DEV).contiguous()     # keep the buffers alive across the launch
     E.conv_bwd_data_direct(dyv.fd, wdev, E.conv_desc(k, s, pad, cout=cout), dx)
@@ -150,7 +156,7 @@ def test_data_gradient_as_flipped_forward_conv_and_direct(E):
         dy = bf16_round(seeded((n, cout, ho, wo), 11, -1.0, 1.0))
         wt = seeded((cout, cin, k, k), 12, -0.3, 0.3)
         xr = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
-        F.conv2d(xr, bf16_round(wt).double(), None, s, pad).backward(dy.double())
+        F.conv2d(xr, f16_round(wt).double(), None, s, pad).backward(dy.double())
         dx = torch.full((n, cin, h, w), 5.0, dtype=torch.float32, device=DEV)
         buf = _nhwc(dy, pitch=(cout + 7) // 8 * 8)
         buf[..., cout:] = float("nan")
@@ -175,7 +181,7 @@ def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     moments (sum dpre, sum dpre * x) -> fdgan_bn_bwd_finalize_raw = BatchNorm's (dgamma, dbeta); against torch."""
     from fdgan_hip import lib as L
     n, h, w = dims
-    x = bf16_round(seeded((n, cin, h, w), 71, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 71, -1.5, 1.5))
     ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
     dy = bf16_round(seeded((n, cout, ho, wo), 72, -1.0, 1.0))
     wt = bf16_round(seeded((cout, cin, k, k), 73, -1.0, 1.0) * (2.0 / (cin * k * k)) ** 0.5)
@@ -191,7 +197,7 @@ def test_data_gradient_with_masked_epilogue(E, k, pad, cin, cout, act, dims):
     wd = wt.to(DEV).contiguous()
     pw = E.PackedWeight(wd, cin, cout, k, transposed=False, flip=True, stride=1, layout=L.WLAYOUT_CHUNK32)
     pw.pack()
-    xb, dyb = _nhwc(x, pitch=cin + 8), _nhwc(dy)
+    xb, dyb = _nhwc_a(x, pitch=cin + 8), _nhwc(dy)
     T = torch.full((n, h, w, cin + 8), 7.0, dtype=torch.bfloat16, device=DEV)
     ws = torch.zeros(1 << 20, dtype=torch.float32, device=DEV)
     rows, cpad = E.conv_bwd_data(E.View(dyb, 0, cout).fd, pw, E.View(xb, 0, cin).fd, pro, E.View(T, 0, cin).fd,
@@ -237,7 +243,7 @@ def test_weight_gradient_split_k_pool_and_accumulate(E):
     prologue (transition: BN + ReLU + 2x2 average in front of a 1x1 conv)."""
     from fdgan_hip import lib as L
     n, cin, cout, h, w = 4, 256, 128, 32, 48
-    x = bf16_round(seeded((n, cin, h, w), 21, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 21, -1.5, 1.5))
     p = _bn_params(cin, 30)
     keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
     sc = (p["gamma"] / torch.sqrt(p["var"] + 1e-5)).float()
@@ -251,7 +257,7 @@ def test_weight_gradient_split_k_pool_and_accumulate(E):
         wref = torch.zeros(cout, cin, 1, 1, dtype=torch.float64, requires_grad=True)
         F.conv2d(a, wref).backward(dy.double())
         pro = E.make_prologue(act=L.ACT_RELU, pool=pool, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
-        xb, dyb = _nhwc(x), _nhwc(dy)
+        xb, dyb = _nhwc_a(x), _nhwc(dy)
         dw = torch.full((cout, cin, 1, 1), 1.0, dtype=torch.float32, device=DEV)
         E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(1, 1, 0, cout=cout), dw, None, ws, True)
         torch.cuda.synchronize()
@@ -271,7 +277,7 @@ def test_weight_gradient_1x1_transpose_read_kernel(E, n, cin, h, w, pitch):
     operands."""
     from fdgan_hip import lib as L
     cout = 128
-    x = bf16_round(seeded((n, cin, h, w), 81, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 81, -1.5, 1.5))
     dy = bf16_round(seeded((n, cout, h, w), 82, -1.0, 1.0))
     p = _bn_params(cin, 83)
     keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
@@ -281,7 +287,7 @@ def test_weight_gradient_1x1_transpose_read_kernel(E, n, cin, h, w, pitch):
     wref = torch.zeros(cout, cin, 1, 1, dtype=torch.float64, requires_grad=True)
     F.conv2d(a, wref).backward(dy.double())
     pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
-    xb, dyb = _nhwc(x, pitch=pitch), _nhwc(dy)
+    xb, dyb = _nhwc_a(x, pitch=pitch), _nhwc(dy)
     if pitch > cin:
         xb[..., cin:] = float("nan")                       # neighbouring channels of the buffer must not leak in
     ws = torch.zeros(1 << 22, dtype=torch.float32, device=DEV)
@@ -301,16 +307,16 @@ def test_gradient_plumbing_kernels(E):
     E.grad_ew(E.GRAD_ADD, E.View(sb, 0, c), E.View(db, 0, c))
     torch.cuda.synchronize()
     assert rel_rms(_from_nhwc(db, c), bf16_round(src + dst0)) < 1e-6
-    big = E.new_act(n, 2 * h, 2 * w, 40, DEV, zero=True)
+    big = E.new_grad(n, 2 * h, 2 * w, 40, DEV, zero=True)
     E.grad_ew(E.GRAD_UNPOOL, E.View(sb, 0, c), E.View(big, 0, c))
     torch.cuda.synchronize()
     assert rel_rms(_from_nhwc(big, c), bf16_round(F.interpolate(src, scale_factor=2, mode="nearest") * 0.25)) < 1e-6
-    small = E.new_act(n, h // 2, w // 2, 40, DEV, zero=True)
+    small = E.new_grad(n, h // 2, w // 2, 40, DEV, zero=True)
     E.grad_ew(E.GRAD_SUMPOOL, E.View(sb, 0, c), E.View(small, 0, c))
     torch.cuda.synchronize()
     assert rel_rms(_from_nhwc(small, c), bf16_round(F.avg_pool2d(src, 2) * 4)) < 1e-6
-    refy = bf16_round(torch.relu(seeded((n, c, h, w), 33, -1, 1)))
-    rb, ob = _nhwc(refy), E.new_act(n, h, w, 40, DEV, zero=True)
+    refy = f16_round(torch.relu(seeded((n, c, h, w), 33, -1, 1)))      # a stored forward activation
+    rb, ob = _nhwc_a(refy), E.new_grad(n, h, w, 40, DEV, zero=True)
     E.grad_ew(E.GRAD_RELU_MASK, E.View(sb, 0, c), E.View(ob, 0, c), ref=E.View(rb, 0, c))
     torch.cuda.synchronize()
     assert rel_rms(_from_nhwc(ob, c), src * (refy > 0)) < 1e-6
@@ -318,7 +324,7 @@ def test_gradient_plumbing_kernels(E):
     for cc, act, f in ((3, L.ACT_TANH, lambda t: 1 - t * t), (1, L.ACT_SIGMOID, lambda t: t * (1 - t))):
         out = (seeded((n, cc, h, w), 34, -0.9, 0.9) if act == L.ACT_TANH else seeded((n, cc, h, w), 34, 0.05, 0.95))
         dout = seeded((n, cc, h, w), 35, -1, 1)
-        g = E.new_act(n, h, w, 8, DEV)
+        g = E.new_grad(n, h, w, 8, DEV)
         od, dd = out.to(DEV).contiguous(), dout.to(DEV).contiguous()
         E.out_act_bwd(dd, od, act, E.View(g))
         torch.cuda.synchronize()
@@ -339,7 +345,7 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     summation order) to the per-tap kernel."""
     import os
     from fdgan_hip import lib as L
-    x = bf16_round(seeded((n, cin, h, w), 41, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 41, -1.5, 1.5))
     dy = bf16_round(seeded((n, cout, h, w), 42, -1.0, 1.0))
     p = _bn_params(cin, 50)
     keep = [v.to(DEV) for v in (p["mean"], p["var"], p["gamma"], p["beta"])]
@@ -349,7 +355,7 @@ def test_weight_gradient_3x3_all_taps_kernel(E, n, cin, cout, h, w):
     wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(a, wref, None, 1, 1).backward(dy.double())
     pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
-    xb, dyb = _nhwc(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 16)
+    xb, dyb = _nhwc_a(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 16)
     ws = torch.zeros(1 << 23, dtype=torch.float32, device=DEV)
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=DEV)
     E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(3, 1, 1, cout=cout), dw, None, ws, False)
@@ -371,7 +377,7 @@ def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     """conv_wgrad4x4_tr (the Fusion-discriminator's 4x4 stride-1 pad-1 conv behind BatchNorm + LeakyReLU(0.2),
     /root/reference/models/dehaze1113.py:200-207): ragged column blocks, rows outside the image, two cin slices."""
     from fdgan_hip import lib as L
-    x = bf16_round(seeded((n, cin, h, w), 61, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 61, -1.5, 1.5))
     ho, wo = h - 1, w - 1
     dy = bf16_round(seeded((n, cout, ho, wo), 62, -1.0, 1.0))
     p = _bn_params(cin, 63)
@@ -382,7 +388,7 @@ def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     wref = torch.zeros(cout, cin, 4, 4, dtype=torch.float64, requires_grad=True)
     F.conv2d(a, wref, None, 1, 1).backward(dy.double())
     pro = E.make_prologue(act=L.ACT_LEAKY02, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3], eps=1e-5)
-    xb, dyb = _nhwc(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 8)
+    xb, dyb = _nhwc_a(x), _nhwc(dy, pitch=(cout + 7) // 8 * 8 + 8)
     ws = torch.zeros(1 << 24, dtype=torch.float32, device=DEV)
     dw = torch.empty((cout, cin, 4, 4), dtype=torch.float32, device=DEV)
     E.conv_bwd_weight(E.View(xb, 0, cin).fd, pro, E.View(dyb, 0, cout).fd, E.conv_desc(4, 1, 1, cout=cout), dw, None, ws, False)
@@ -427,7 +433,7 @@ def test_weight_gradient_few_channel_kernel(E, cin, cout, k, stride, pad, bn, sl
     """conv_wgrad_small (all taps x all input channels as the N dimension of one GEMM, bias as a column of ones) vs an
     fp64 statement; deterministic; accumulates onto an existing gradient."""
     from fdgan_hip import lib as L
-    x = bf16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), 1, -1.5, 1.5))
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     dy = bf16_round(seeded((n, cout, ho, wo), 2, -1.0, 1.0))
     p = _bn_params(cin, 10) if bn else None
@@ -442,7 +448,7 @@ def test_weight_gradient_few_channel_kernel(E, cin, cout, k, stride, pad, bn, sl
     wref = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True, device=DEV if dev_ref else "cpu")
     F.conv2d(a.to(wref.device), wref, None, stride, pad).backward(dy.double().to(wref.device))
     gref = wref.grad.cpu()
-    xb, dyb = _nhwc(x), _nhwc(dy)
+    xb, dyb = _nhwc_a(x), _nhwc(dy)
     pro = None
     if bn or act != L.ACT_NONE:
         kw = dict(act=act)

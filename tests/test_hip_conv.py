@@ -1,15 +1,15 @@
 """GPU parity tests of the fused implicit-GEMM convolution (through the C ABI) against a
 torch-CPU statement of the same math (tests/hiputil.py), on seeded inputs.
 
-Tolerance: operands are rounded to bf16 exactly where the kernel rounds them, so the
+Tolerance: operands are rounded to fp16 exactly where the kernel rounds them, so the
 only differences are fp32 accumulation order, rare 1-ulp flips of the activated
-operand and the final bf16 rounding of the stored result (2^-8 relative)."""
+operand and the final fp16 rounding of the stored result (2^-11 relative)."""
 import os
 
 import pytest
 import torch
 
-from hiputil import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, bf16_round, fused_conv_ref, rel_rms,
+from hiputil import (ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, f16_round, fused_conv_ref, rel_rms,
                      seeded)
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,7 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
     up = 2 if upsample else 1
     cstore = cout if nchw_out else (cout + 3) // 4 * 4
     pitch_out = pitch_out or (cstore + 7) // 8 * 8
-    x = bf16_round(seeded((n, cin, h, w), seed, -1.5, 1.5))
+    x = f16_round(seeded((n, cin, h, w), seed, -1.5, 1.5))
     wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
     wt = seeded(wshape, seed + 1, -1.0, 1.0) * (2.0 / (cin * k * k)) ** 0.5
     b = seeded((cout,), seed + 2, -0.5, 0.5) if bias else None
@@ -47,8 +47,8 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
                    gamma=seeded((cin,), seed + 5, 0.5, 1.5), beta=seeded((cin,), seed + 6, -0.3, 0.3), eps=1e-5)
     y_ref, m_ref, v_ref = fused_conv_ref(x, wt, b, k, stride, pad, p_act, bnp, pool, e_act, upsample, transposed)
 
-    xbuf = torch.full((n, h, w, pitch_in), 7.0, dtype=torch.bfloat16, device=dev)   # poison outside the slice
-    xbuf[..., c0_in:c0_in + cin] = x.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    xbuf = torch.full((n, h, w, pitch_in), 7.0, dtype=torch.float16, device=dev)   # poison outside the slice
+    xbuf[..., c0_in:c0_in + cin] = x.permute(0, 2, 3, 1).to(dev).to(torch.float16)
     if (cin % 8) and c0_in + (cin + 7) // 8 * 8 <= pitch_in:
         xbuf[..., c0_in + cin:c0_in + (cin + 7) // 8 * 8] = 0     # padded channels must be finite
     xv = E.View(xbuf, c0_in, cin)
@@ -72,7 +72,7 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
         ybuf = torch.full((n, cout, ho * up, wo * up), 9.0, dtype=torch.float32, device=dev)
         yfd = E.nchw_f32_view(ybuf)
     else:
-        ybuf = torch.full((n, ho * up, wo * up, pitch_out), 9.0, dtype=torch.bfloat16, device=dev)
+        ybuf = torch.full((n, ho * up, wo * up, pitch_out), 9.0, dtype=torch.float16, device=dev)
         yv = E.View(ybuf, c0_out, cstore)
         yfd = yv.fd
     desc = E.conv_desc(k, stride, pad, e_act, upsample, cout=cout, w_layout=pw.layout)
@@ -101,8 +101,8 @@ def _run(E, n, h, w, cin, cout, k, stride=1, pad=0, pitch_in=None, c0_in=0, pitc
     err = rel_rms(y, y_ref)
     scale = float(y_ref.abs().max())
     maxerr = float((y - y_ref).abs().max())
-    tol_max = (0.02 if not nchw_out else 0.004) * max(scale, 1e-3) + 1e-3
-    assert err < (6e-3 if not nchw_out else 2e-3), "rel rms %.3g" % err
+    tol_max = 0.004 * max(scale, 1e-3) + 1e-3
+    assert err < (1.5e-3 if not nchw_out else 1e-3), "rel rms %.3g" % err
     assert maxerr < tol_max, "max err %.3g (scale %.3g)" % (maxerr, scale)
     if stats:
         assert (out["mean"] - m_ref).abs().max() < 2e-4 * max(1.0, float(m_ref.abs().max()))
@@ -136,8 +136,8 @@ def test_conv3x3_row_streaming_kernel(E):
     """conv3x3_rs (Cin == 128, Cout <= 32): ragged strips and rows, row segments, more work items than
     workgroups, input as a channel slice of a wider buffer, narrow outputs, no-BN and LeakyReLU prologues."""
     from fdgan_hip import engine, lib as L
-    info = engine.conv_info(engine.View(torch.empty((16, 64, 64, 128), dtype=torch.bfloat16, device="cuda:0")).fd,
-                            engine.View(torch.empty((16, 64, 64, 32), dtype=torch.bfloat16, device="cuda:0")).fd, 32,
+    info = engine.conv_info(engine.View(torch.empty((16, 64, 64, 128), dtype=torch.float16, device="cuda:0")).fd,
+                            engine.View(torch.empty((16, 64, 64, 32), dtype=torch.float16, device="cuda:0")).fd, 32,
                             engine.conv_desc(3, 1, 1))
     assert (info.grid_x, info.stats_rows, info.stats_cpad) == (256, 256, 32)      # 4 strips x 4 segments x 16 images
     _run(E, 3, 40, 24, 128, 32, 3, pad=1, bn=True, p_act=ACT_RELU, stats=True, pitch_out=96, c0_out=64, seed=50)
@@ -156,8 +156,8 @@ def test_conv3x3_row_streaming_second_generation(E):
     (16-pixel-wide images: both zero columns), a sliced output, and items with different lengths in one launch."""
     from fdgan_hip import engine
     for i, h in enumerate((4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52)):
-        info = engine.conv_info(engine.View(torch.empty((256, h, 16, 128), dtype=torch.bfloat16, device="cuda:0")).fd,
-                                engine.View(torch.empty((256, h, 16, 32), dtype=torch.bfloat16, device="cuda:0")).fd, 32,
+        info = engine.conv_info(engine.View(torch.empty((256, h, 16, 128), dtype=torch.float16, device="cuda:0")).fd,
+                                engine.View(torch.empty((256, h, 16, 32), dtype=torch.float16, device="cuda:0")).fd, 32,
                                 engine.conv_desc(3, 1, 1))
         assert info.grid_x == 256 and info.lds_bytes > 140 * 1024      # one whole-height item per workgroup, the 12-wave kernel
         kind = i % 3
@@ -175,8 +175,8 @@ def test_last_workgroup_finalizes_the_statistics(E):
     dev = torch.device("cuda:0")
     for k, cin, hw in ((3, 128, 128), (3, 128, 19), (1, 224, 128)):       # conv3x3_rs2, conv3x3_rs, conv1x1_ds
         cout = 32 if k == 3 else 128
-        x = (torch.randn(16, hw, hw, cin, device=dev) * 0.7).to(torch.bfloat16)
-        y = torch.empty(16, hw, hw, cout, dtype=torch.bfloat16, device=dev)
+        x = (torch.randn(16, hw, hw, cin, device=dev) * 0.7).to(torch.float16)
+        y = torch.empty(16, hw, hw, cout, dtype=torch.float16, device=dev)
         pw = E.PackedWeight(torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5, cout, cin, k)
         pw.pack()
         pro = E.make_prologue(act=ACT_RELU, mean=torch.randn(cin, device=dev) * 0.1, var=torch.rand(cin, device=dev) + 0.5,
@@ -266,11 +266,11 @@ def test_discriminator_convs(E):
 def test_plan_replay_matches_eager(E):
     """Record -> replay (and hipGraph) gives the same bytes as the eager launch."""
     dev = torch.device("cuda:0")
-    x = torch.randn(1, 16, 16, 64, device=dev).to(torch.bfloat16)
+    x = torch.randn(1, 16, 16, 64, device=dev).to(torch.float16)
     w = torch.randn(32, 64, 3, 3, device=dev) * 0.05
     pw = E.PackedWeight(w, 32, 64, 3)
     pw.pack()
-    y0 = torch.zeros(1, 16, 16, 32, dtype=torch.bfloat16, device=dev)
+    y0 = torch.zeros(1, 16, 16, 32, dtype=torch.float16, device=dev)
     y1 = torch.zeros_like(y0)
     d = E.conv_desc(3, 1, 1, cout=32)
     E.conv2d(E.View(x).fd, pw, None, None, E.View(y0).fd, d)

@@ -1023,14 +1023,14 @@ def test_dehaze22_d_backward():
 
 
 def test_pyramid_pool4_and_bn_dropout_kernels():
-    """The two element-wise kernels of the legacy networks (csrc/legacy.hip) against plain torch on the same bf16 values."""
+    """The two element-wise kernels of the legacy networks (csrc/legacy.hip) against plain torch on the same fp16 values."""
     import torch.nn.functional as F
     from fdgan_hip import engine as E
     torch.manual_seed(5)
     for k0, (h, w) in ((16, (64, 96)), (32, (64, 64))):
-        buf = torch.zeros(2, h, w, 24, dtype=torch.bfloat16, device=DEV)
+        buf = torch.zeros(2, h, w, 24, dtype=torch.float16, device=DEV)
         xs = torch.randn(2, h, w, 20, device=DEV)
-        buf[..., :20] = xs.bfloat16()
+        buf[..., :20] = xs.half()
         wt = torch.randn(4, 20, device=DEV) * 0.3
         bs = torch.randn(4, device=DEV) * 0.1
         E.pyramid_pool4(E.View(buf, 0, 20), wt, bs, k0, 0.2, E.View(buf, 20, 4))
@@ -1043,7 +1043,7 @@ def test_pyramid_pool4_and_bn_dropout_kernels():
         want = torch.cat(want, 1)
         got = buf[..., 20:].float().permute(0, 3, 1, 2)
         assert float((got - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max())), (k0, float((got - want).abs().max()))
-    x = torch.randn(3, 4, 4, 16, device=DEV).bfloat16()
+    x = torch.randn(3, 4, 4, 16, device=DEV).half()
     mean, var = torch.randn(12, device=DEV) * 0.2, torch.rand(12, device=DEV) + 0.5
     gamma, beta = torch.rand(12, device=DEV) + 0.5, torch.randn(12, device=DEV) * 0.1
     mask = (torch.rand(3, 12, device=DEV) > 0.5).float() * 2.0
