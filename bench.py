@@ -4,7 +4,7 @@
 Default workload (BASELINE.json configs[2]; configs[3] when N > 1 -- the configurations the metric "training
 images/sec @256x256 (1/2/4/8 GPUs)" is quoted on): ONE FULL TRAINING STEP of fd-gan_amd/train.py per "step" -- netG
 forward + backward, Fusion-D 3 forwards + 3 backwards, VGG16 2 forwards + 1 backward, SSIM, L1 / MSE / BCE, Adam(D),
-Adam(G) -- bf16 storage / fp32 accumulate, batch 16 @ 3x256x256 per GPU, train-mode BatchNorm, synthetic images
+Adam(G) -- fp16 forward activations and filters, bf16 gradients, fp32 accumulate (DESIGN.md 'Precision'), batch 16 @ 3x256x256 per GPU, train-mode BatchNorm, synthetic images
 resident in HBM before the timed region.  N > 1: one process per GPU, each rank its own batch (weak scaling, global
 batch 16 N), RCCL all-reduce of the two flat gradient buffers inside the step; value = N*B*K / max-over-ranks time.
 
@@ -15,7 +15,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel of the timed workload (largest share of GPU time in an instrumented warm-up
                   step): algorithmic bytes (or flops) of sampled launches / their hipEvent-measured duration inside
                   the timed region (events on the launch stream, fdgan_kernel_timer_*), against 8 TB/s HBM or
-                  2.5 PFLOP/s bf16 MFMA.
+                  2.5 PFLOP/s dense 16-bit MFMA (f16 and bf16 run at the same rate).
   cpu_baseline -- the CPU oracle (oracle/, PyTorch-CPU fp32 restatement of the reference, parity-checked against
                   it) running the same step on this host's cores, bounded sample, N = 1 only.
 """
@@ -33,7 +33,7 @@ for p in (ROOT, os.path.join(ROOT, "fd-gan_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / f16 MFMA (v_mfma_f32_16x16x32_{bf16,f16}: same rate)
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 
 
@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--forward", action="store_true",
                     help="BASELINE configs[1] instead of the training step: netG forward only, with its per-kernel roofline")
     ap.add_argument("--no-forward-leg", action="store_true", help="skip the forward_only object of the default line")
+    ap.add_argument("--no-forward-1024", action="store_true",
+                    help="skip the forward_1024 object (tools/pmc_bench.sh: its 4x larger launches of the same kernels would "
+                         "pollute per-kernel PMC averages keyed on the B=16 @256^2 shapes)")
     ap.add_argument("--train-g", action="store_true",
                     help="NOT the default workload: time netG forward + backward (mse loss), the part of the training "
                          "step (BASELINE configs[2]) that exists; no roofline / cpu_baseline objects")
@@ -244,7 +247,7 @@ def train_bench(a, dp, dev, B, S):
             stride += 1
         E.kernel_timer_arm(dom_name, stride, min(65536, 16 * a.steps + 16))
     comm = None
-    if world > 1:
+    if world > 1 or dp.force_exchange:
         # the gradient exchange on its own (nothing to hide behind): both flat buffers, same slicing as the step uses
         import torch.distributed as dist
         dp.barrier()
@@ -263,13 +266,18 @@ def train_bench(a, dp, dev, B, S):
     dp.barrier()                                   # torch.cuda.synchronize() + a collective barrier when world > 1
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        last = ts.step(haze, gt)
+        last_dev = ts.step(haze, gt, sync=False)   # the losses stay on the device: no host round trip inside the timed region
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0             # this rank alone (before the closing barrier)
     dp.barrier()
     dt = dp.max_over_ranks(time.perf_counter() - t0)
     images = dp.sum_over_ranks(B * a.steps)
+    last = ts.losses_dict(last_dev)
+    per_rank_ms = dp.gather_floats(1e3 * dt_rank / a.steps)
     if comm is not None:
         exposed = sum(e0.elapsed_time(e1) for e0, e1 in ts.optG.comm_events + ts.optD.comm_events) / a.steps
-        comm["exposed_ms_per_step"] = round(exposed, 3)       # compute stream stalled on the collectives (G: after its backward; D: all of it)
+        comm["exposed_ms_per_step"] = round(exposed, 3)       # stream stalled on the collectives (G: after its backward; D: on the side stream, beside VGG16)
+        comm["ms_per_step_by_rank"] = [round(v, 3) for v in per_rank_ms]
         comm["hidden_fraction"] = round(max(0.0, 1.0 - exposed / max(comm["isolated_ms_per_step"], 1e-9)), 3)
         ts.optG.comm_events = ts.optD.comm_events = None
     roof = None
@@ -303,7 +311,9 @@ def train_bench(a, dp, dev, B, S):
                 traffic_mb = (2.0 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024 / 1e6
                 roof["traffic_mb_per_launch"] = round(traffic_mb, 2)
                 if roof["unit"] == "GB/s":
-                    roof["traffic"] = round(ach * traffic_mb / roof["algorithmic_mb_per_launch"], 1)
+                    traffic = ach * traffic_mb / roof["algorithmic_mb_per_launch"]
+                    # a PMC row that mixes launches of other shapes would price traffic above the pins: not evidence
+                    roof["traffic"] = round(traffic, 1) if traffic <= HBM_PEAK_GBS else None
         except (OSError, ValueError):
             pass
     # ---- whole-step roofline: counted work of the step / measured step time.  Work is counted from the plans' own op logs
@@ -337,7 +347,7 @@ def train_bench(a, dp, dev, B, S):
         res = {"metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "synthetic",
+               "dtype": "f16+bf16", "data": "synthetic",
                "config": {"workload": "full training step (fd-gan_amd/train.py; BASELINE.json configs[%d]): G fwd+bwd, Fusion-D 3 fwd + 3 "
                                       "bwd, VGG16 2 fwd + 1 bwd, SSIM, Adam(G), Adam(D), gradient all-reduce when n_gpus > 1; batch %d @ "
                                       "%dx%d per GPU; loss composition reconstructed (the reference ships no training loop)"
@@ -373,7 +383,7 @@ def forward_1024(g, dev, batch=4, size=1024, warm=2, steps=5):
     del y
     torch.cuda.empty_cache()
     return {"value": round(batch / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
-            "workload": "netG (FDGAN) forward-only, batch %d @ %dx%d, bf16 storage / fp32 accumulate, train-mode BatchNorm "
+            "workload": "netG (FDGAN) forward-only, batch %d @ %dx%d, fp16 storage / fp32 accumulate, train-mode BatchNorm "
                         "(BASELINE.json configs[4])" % (batch, size, size),
             "gflop_per_step": round(fl / 1e9, 1), "algorithmic_gb_per_step": round(by / 1e9, 2),
             "tflops": round(fl / dt / 1e12, 1), "frac_mfma": round(fl / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -439,7 +449,7 @@ def main():
                 "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS", "value": round(images / dt, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "data": "synthetic",
+                "dtype": "f16+bf16", "data": "synthetic",
                 "config": {"workload": "PARTIAL training step: netG (FDGAN) forward + backward, mse loss, train-mode BatchNorm, "
                                        "batch %d @ %dx%d per GPU; no D / VGG / optimizer / all-reduce yet" % (B, S, S),
                            "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world},
@@ -480,7 +490,7 @@ def main():
         dom = dict(dom, idx=sample, bytes_all=dom["bytes"], flops_all=dom["flops"], bytes=sum(per_launch[i]["bytes"] for i in sample),
                    flops=sum(per_launch[i]["flops"] for i in sample), ms=sum(ms[i] for i in sample),
                    ms_all=dom["ms"], launches_all=len(dom["idx"]))
-        headline = classes.get("conv3x3_rs_bn32[128->32 @%dx%d]" % (S, S))
+        headline = classes.get("conv3x3_rs2_bn32[128->32 @%dx%d]" % (S, S)) or classes.get("conv3x3_rs_bn32[128->32 @%dx%d]" % (S, S))
         if a.graph:
             plan.main.instantiate_graph()
         else:
@@ -501,8 +511,8 @@ def main():
             "metric": "training images/sec @256x256 (1/2/4/8 GPUs) + PSNR/SSIM parity on SOTS",
             "value": round(images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "netG (FDGAN) forward-only, bf16 storage / fp32 accumulate, train-mode "
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16+bf16", "data": "synthetic",
+            "config": {"workload": "netG (FDGAN) forward-only, fp16 storage / fp32 accumulate, train-mode "
                                    "BatchNorm, batch %d @ %dx%d per GPU (BASELINE.json configs[1])" % (B, S, S),
                        "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
                        "launches_per_step": len(plan.main) + 2, "replay": "hipGraph" if a.graph else "eager+events",
@@ -533,6 +543,8 @@ def main():
                 # same unit as `achieved`: PMC bytes per launch (all launches of the kernel) priced at the achieved rate
                 traffic = round(roof["achieved"] * traffic_mb * 1e6 / (dom["bytes_all"] / dom["launches_all"]), 1) \
                     if roof["unit"] == "GB/s" else None
+                if traffic is not None and traffic > HBM_PEAK_GBS:      # a PMC row polluted by launches of another shape: not evidence
+                    traffic = None
         except (OSError, ValueError):
             pass
         roof.update({"traffic": traffic, "traffic_mb_per_launch": round(traffic_mb, 2) if traffic_mb else None,
@@ -545,7 +557,7 @@ def main():
                      "share_of_gpu_time": round(dom["ms_all"] / total_ms, 3)})
         if headline is not None and headline["ms"] > 0:   # the north-star shape (3x3 128->32 @256^2), from the instrumented replay
             hl_us = headline["ms"] / len(headline["idx"]) * 1e3
-            roof["headline_3x3"] = {"kernel": "conv3x3_rs_bn32[128->32 @%dx%d]" % (S, S), "avg_launch_us": round(hl_us, 2),
+            roof["headline_3x3"] = {"kernel": "conv3x3_rs2_bn32[128->32 @%dx%d]" % (S, S), "avg_launch_us": round(hl_us, 2),
                                     "achieved_GB/s": round(headline["bytes"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e9, 1),
                                     "frac_hbm": round(headline["bytes"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                     "tflops": round(headline["flops"] / len(headline["idx"]) / (hl_us * 1e-6) / 1e12, 1)}
@@ -566,7 +578,8 @@ def main():
         if train_res is not None:       # default line: the training step, with the forward-only measurement attached
             train_res["forward_only"] = {"value": res["value"], "unit": "images/sec", "ms_per_step": res["ms_per_step"],
                                          "workload": res["config"]["workload"], "roofline": res["roofline"]}
-            train_res["forward_1024"] = forward_1024(g, dev)
+            if not a.no_forward_1024:
+                train_res["forward_1024"] = forward_1024(g, dev)
             if world == 1 and not a.no_cpu_baseline:
                 train_res["cpu_baseline"] = cpu_baseline_train(S, a.cpu_seconds)
             print(json.dumps(train_res), flush=True)

@@ -963,6 +963,6 @@ int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
   if (stats_cap >= 0 && (long long)grid.x * a.stats_cpad * 2 > stats_cap)
     FD_FAIL(FD_EINVAL, "stats workspace too small: need %lld floats, have %lld", (long long)grid.x * a.stats_cpad * 2,
             stats_cap);
-  if (gen2) return fd_launch(&conv3x3_rs2_kernel, "conv3x3_rs_bn32", grid, block, lds, a, stream);
+  if (gen2) return fd_launch(&conv3x3_rs2_kernel, "conv3x3_rs2_bn32", grid, block, lds, a, stream);
   return fd_launch(&conv3x3_rs_kernel, "conv3x3_rs_bn32", grid, block, lds, a, stream);
 }

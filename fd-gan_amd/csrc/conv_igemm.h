@@ -772,15 +772,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
             red[idx] = s1[e];
             red[idx + 1] = s2[e];
           }
-      } else {   // 6 lanes per pixel: the PPI lanes of a channel group are not a butterfly; wave-private LDS adds, once per kernel
-        for (int i = lane; i < CT * 16 * 2; i += 64) red[wave * CT * 16 * 2 + i] = 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (q0 < R::PPI)
+      } else {   // 6 lanes per pixel: lanes piece + LPP k (k < PPI) own the same channels, which is not a butterfly.  Summed in a
+                 // FIXED order through ds_bpermute, once per kernel (LDS atomics here made D's BatchNorm gradients differ in the
+                 // last bit from run to run: tests/test_hip_models.py::test_training_step_full_size_configs2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < R::PPI; ++k) {
+            t1 += __shfl(s1[e], piece + R::LPP * k, 64);
+            t2 += __shfl(s2[e], piece + R::LPP * k, 64);
+          }
+          s1[e] = t1, s2[e] = t2;
+        }
+        if (q0 == 0)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int idx = (wave * CT * 16 + piece * 8 + e) * 2;
-            atomicAdd(&red[idx], s1[e]);
-            atomicAdd(&red[idx + 1], s2[e]);
+            red[idx] = s1[e];
+            red[idx + 1] = s2[e];
           }
       }
     }

@@ -723,11 +723,14 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) 
         acc[ky * 4 + kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], B[kx], acc[ky * 4 + kx][0], 0, 0, 0);
         acc[ky * 4 + kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], B[kx], acc[ky * 4 + kx][1], 0, 0, 0);
       }
-      B[kx] = g3_frag(bp[kx][0] + xn, bp[kx][1] + xn);
       u[kx] = r3_xform2<RELU>(u[kx], sv[0], sv[1], hv[0], hv[1], slope, rm & xcol0);
       sv = svn, hv = hvn;
+      // the step's LDS WRITE goes out before the last block's fragment refills: R4_STEP_BARRIER waits for everything but the
+      // six youngest LDS operations, which must all be reads (with the write after B[3]'s refill it sat among those six and
+      // was not covered by the barrier: the D 4x4 weight gradient differed from run to run at 127 x 127, round 3)
+      if (kx == 3) lds_write16(xwp0 + xw, u);
+      B[kx] = g3_frag(bp[kx][0] + xn, bp[kx][1] + xn);
       if (kx == 3) {
-        lds_write16(xwp0 + xw, u);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) A[(p + 1) & 3][ct] = g3_frag(ap[ct][0] + dn, ap[ct][1] + dn);
       }

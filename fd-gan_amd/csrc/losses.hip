@@ -213,6 +213,8 @@ __global__ __launch_bounds__(256) void cx_rows_kernel(CxArgs a) {
       const int oj = __shfl_xor(jm, dlt, 64);
       if (om < mn || (om == mn && oj < jm)) mn = om, jm = oj;
     }
+    if (jm < 0 || jm >= a.n) jm = 0;    // an all-NaN row (0 / 0 in the cosine of a zero-norm feature): `v < mn` never fired;
+                                        // the loss is NaN as in torch, but the index the backward writes through stays in the row
     const float inv = 1.f / (a.sigma * (mn + a.eps));
     float s = 0.f;
     for (int j = lane; j < a.n; j += 64) s += __expf((mn - dr[j]) * inv);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void cx_rows_kernel(CxArgs a) {
       }
     }
     acc = wave_sum(acc);
-    if (lane == 0) gr[jm] = -k * acc / (mn + a.eps);
+    if (lane == 0 && jm >= 0 && jm < a.n) gr[jm] = -k * acc / (mn + a.eps);
   }
 }
 

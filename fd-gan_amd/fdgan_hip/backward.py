@@ -32,31 +32,6 @@ def _r8(v):
     return (v + 7) // 8 * 8
 
 
-def _op_reference(r, dy_view, meta):
-    """The single fused op under torch autograd on the SAME device tensors (fp32 math, operands rounded to
-    bf16 where the kernels round them): returns (dW reference, dx reference).  Verification aid."""
-    import torch.nn.functional as F
-    x, w, k, pad = r["x"], r["w"], r["k"], r["pad"]
-    st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
-    with torch.enable_grad():            # this runs inside an autograd.Function's backward
-        xr = x.torch_nchw().requires_grad_(True)
-        a = xr
-        if meta.get("bn") is not None:
-            a = F.batch_norm(a, None, None, meta["gamma"].detach(), meta["beta"].detach(), True, 0.0, meta["eps"])
-        if meta["act"] == L.ACT_RELU:
-            a = torch.relu(a)
-        elif meta["act"] == L.ACT_LEAKY02:
-            a = F.leaky_relu(a, 0.2)
-        if meta["pool"]:
-            a = F.avg_pool2d(a, 2)
-        a = st(a)
-        p = w.param.detach()
-        wt = (p.permute(1, 0, 2, 3) if w.transposed else p).to(torch.bfloat16).float().requires_grad_(True)
-        y = F.conv2d(a, wt, None, r["stride"], pad)
-        y.backward(dy_view.torch_nchw()[:, :w.cout])
-    return wt.grad, xr.grad
-
-
 def _region(view):
     return view.buf.data_ptr(), view.c0, view.c0 + view.c
 
@@ -186,7 +161,11 @@ class PlanBackward:
                     per_gbuf.setdefault(id(self.gbuf[reads(r)[0]]), []).append(False)
                 r["_sole"] = sole
             self.nozero = {g for g, flags in per_gbuf.items() if all(flags)}
-        self.checks = None      # set to a list: every op is verified against torch autograd on the same tensors
+        # Verification hook: tests set `checks` to a list AND `check_reference` to a callable (r, dy_view, meta) -> (dW, dx)
+        # that states the single fused op under torch autograd (tests/hiputil.op_reference); every op's two gradients are
+        # then compared with it in place.  No reference implementation lives in the product package.
+        self.checks = None
+        self.check_reference = None
         # ReLU pre-masking (enable_relu_premask): whether each conv's input region is the stored output of a ReLU epilogue
         # (directly, or through max-pools / copies of one)
         self.relu_premask = False
@@ -287,7 +266,7 @@ class PlanBackward:
                 E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grad_target(grads, p), db, self.ws, True)
         check = self.checks is not None
         if check:
-            dw_ref, dx_ref = _op_reference(r, dy_view, meta)
+            dw_ref, dx_ref = self.check_reference(r, dy_view, meta)      # supplied by the test (tests/hiputil.op_reference)
             tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
             E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
             # the op's input-gradient contribution is measured in ISOLATION: the accumulated gradient of the region is

@@ -23,6 +23,7 @@ import torch.distributed as dist  # noqa: E402
 class DpContext:
     def __init__(self, rank=0, world=1, local_rank=0, device=None, owns_group=False):
         self.rank, self.world, self.local_rank, self.device, self._owns = rank, world, local_rank, device, owns_group
+        self.force_exchange = False         # run the gradient collectives even when world == 1 (from_env)
 
     @classmethod
     def from_env(cls, backend=None, device=None):
@@ -36,14 +37,19 @@ class DpContext:
             device = torch.device("cuda", local)
             torch.cuda.set_device(device)
         owns = False
-        if world > 1 and not dist.is_initialized():
+        # FDGAN_DP_FORCE_EXCHANGE=1 (tests, single-GPU boxes): build the process group and run the gradient collectives even
+        # with ONE rank, so that `torchrun --nproc-per-node 1 bench.py --gpus 1` walks the whole RCCL code path
+        force = os.environ.get("FDGAN_DP_FORCE_EXCHANGE") == "1"
+        if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
                 backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
             dist.init_process_group(backend, rank=rank, world_size=world)
             owns = True
-        return cls(rank, world, local, device, owns)
+        ctx = cls(rank, world, local, device, owns)
+        ctx.force_exchange = force and dist.is_initialized()
+        return ctx
 
     # ---- partitioning -------------------------------------------------------------------
     def batch_slice(self, global_batch):
@@ -83,6 +89,15 @@ class DpContext:
         t = self._tensor(count, torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
+
+    def gather_floats(self, value):
+        """[value of rank 0, ..., value of rank world-1] on every rank (diagnostics: per-rank step times)."""
+        if self.world == 1:
+            return [float(value)]
+        t = self._tensor(0.0, torch.float64).repeat(self.world)
+        t[self.rank] = float(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
 
     def throughput(self, units_this_rank, seconds):
         """Whole-job units/s: all ranks' units over the slowest rank's time."""

@@ -62,20 +62,33 @@ class FlatAdam:
 
     def allreduce_grads(self, ctx, bucket_mb=8.0):
         """Data-parallel gradient averaging on the flat buffer: RCCL all-reduce of contiguous slices, last slice
-        first (the parameters whose gradients are produced first by the backward walk live at the end)."""
-        if ctx is None or ctx.world == 1:
-            return 0
+        first (the parameters whose gradients are produced first by the backward walk live at the end).  Issue and
+        wait in one call; allreduce_begin / allreduce_end split them so that other work can be enqueued in between."""
+        return self.allreduce_end(self.allreduce_begin(ctx, bucket_mb))
+
+    def allreduce_begin(self, ctx, bucket_mb=8.0):
+        """Enqueue the collectives (RCCL's stream waits for what the CURRENT stream has enqueued so far) and return a
+        handle for allreduce_end.  None on a single rank."""
+        if ctx is None or (ctx.world == 1 and not getattr(ctx, "force_exchange", False)):
+            return None
         import torch.distributed as dist
         n, step = self.grad.numel(), max(1, int(bucket_mb * (1 << 20) / 4))
         works = []
-        ev = _events(self)
         for hi in range(n, 0, -step):
             lo = max(0, hi - step)
             works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        return works, ctx.world
+
+    def allreduce_end(self, handle):
+        """Make the CURRENT stream wait for the collectives of `handle`, then divide by the world size (on that stream)."""
+        if handle is None:
+            return 0
+        works, world = handle
+        ev = _events(self)
         for w in works:
             w.wait()
         _events_done(self, ev)
-        self.grad.div_(ctx.world)
+        self.grad.div_(world)
         return len(works)
 
 
@@ -97,7 +110,7 @@ class _Overlap:
     def __init__(self, opt, ctx, bucket_mb, reduce_fn, force=False):
         self.opt, self.ctx, self.reduce_fn = opt, ctx, reduce_fn
         # force: run the collectives even on a one-rank group (exercises the RCCL path on a single-GPU box)
-        self.active = reduce_fn is not None or (ctx is not None and (ctx.world > 1 or force))
+        self.active = reduce_fn is not None or (ctx is not None and (ctx.world > 1 or force or getattr(ctx, "force_exchange", False)))
         self.bucket = max(1, int(bucket_mb * (1 << 20) / 4))
         self.index = {id(p): k for k, p in enumerate(opt.params)}
         self.tables = {}                    # id(PlanBackward) -> per-record parameter indices

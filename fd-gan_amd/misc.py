@@ -45,20 +45,20 @@ def getLoader(datasetName, dataroot, originalSize, imageSize, batchSize=64, work
 
 
 class AverageMeter(object):
-    """misc.py:121-136 interface: `val` (last value), `sum`, `count`, `avg` (count-weighted running mean), `reset()`,
-    `update(val, n=1)`."""
+    """misc.py:121-136: plain attributes `val` (last value), `avg` (count-weighted running mean), `sum`, `count`;
+    `reset()`, `update(val, n=1)`.  All four stay assignable, as in the reference."""
 
     def __init__(self):
-        self.val, self.sum, self.count = 0, 0, 0
+        self.reset()
 
-    reset = __init__
-
-    @property
-    def avg(self):
-        return self.sum / self.count if self.count else 0
+    def reset(self):
+        self.val, self.avg, self.sum, self.count = 0, 0, 0, 0
 
     def update(self, val, n=1):
-        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
+        self.val = val
+        self.sum = self.sum + val * n
+        self.count = self.count + n
+        self.avg = self.sum / self.count if self.count else 0
 
 
 class ImagePool:
@@ -66,14 +66,17 @@ class ImagePool:
     as they are; afterwards a fair coin decides between returning the new image untouched and swapping it with a
     uniformly chosen stored one, which is returned instead.  `pool_size == 0` disables the pool.
 
-    Here the history is ONE preallocated tensor on the images' device (slot copies instead of a python list of clones)
-    and the draws come from an explicit numpy Generator: pass `seed`, or let it be drawn from numpy's global RNG so that
-    `np.random.seed()` (which `datasets.pix2pix(seed=...)` calls) still makes a run reproducible."""
+    The history is a list with one entry per slot, like the reference's (`images`), so queries may differ in shape, dtype
+    or device (a ragged last batch -- getLoader has no drop_last -- or a change of imageSize).  A slot whose stored
+    tensor already has the new image's shape / dtype / device is overwritten in place (no allocation in steady state);
+    any other slot is replaced by a clone.  Nothing is ever broadcast.  The draws come from an explicit numpy Generator:
+    pass `seed`, or let it be drawn from numpy's global RNG so that `np.random.seed()` (which
+    `datasets.pix2pix(seed=...)` calls) still makes a run reproducible."""
 
     def __init__(self, pool_size=50, seed=None):
         self.pool_size = pool_size
         self.num_imgs = 0
-        self.store = None
+        self.images = []
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         self.rng = np.random.default_rng(seed)
@@ -82,17 +85,20 @@ class ImagePool:
         if self.pool_size == 0:
             return image
         if self.num_imgs < self.pool_size:
-            if self.store is None:
-                self.store = torch.empty((self.pool_size,) + tuple(image.shape), dtype=image.dtype, device=image.device)
-            self.store[self.num_imgs].copy_(image)
+            self.images.append(image.detach().clone())
             self.num_imgs += 1
             return image
         if self.rng.random() <= 0.5:
             return image
         slot = int(self.rng.integers(self.pool_size))
-        old = self.store[slot].clone()
-        self.store[slot].copy_(image)
-        return old
+        old = self.images[slot]
+        if old.shape == image.shape and old.dtype == image.dtype and old.device == image.device:
+            out = old.clone()
+            old.copy_(image.detach())
+        else:
+            out = old
+            self.images[slot] = image.detach().clone()
+        return out
 
 
 def adjust_learning_rate(optimizer, init_lr, epoch, factor, every):

@@ -11,7 +11,7 @@ those pieces -- the loss weights are not recoverable from the reference:
     F(img) = cat[img, Blur15(img), Laplacian3(img)]
 
 Every network forward / backward, the frequency split, SSIM and the scalar losses (L1, BCE, the perceptual MSE on
-Vgg16's NHWC bf16 feature maps: fdgan_hip/losses.py) run through libfdgan_hip.so; Adam is one HIP kernel over a flat
+Vgg16's NHWC fp16 feature maps: fdgan_hip/losses.py) run through libfdgan_hip.so; Adam is one HIP kernel over a flat
 fp32 parameter buffer (fdgan_hip/optim.py), whose flat gradient is also what RCCL all-reduces.  Nothing in a step
 synchronises with the host until its six loss values are read, once, at the end.
 Activations live in the modules' plan buffers, so each module's backward runs before its next forward (two
@@ -40,6 +40,9 @@ class TrainStep:
         ImageNet-pretrained encoder (dehaze1113.py:707) and a pretrained, frozen VGG16 (myutils/utils.py:84-94): without the
         files both are RANDOM here, which only `synthetic=True` (benchmarks, tests) accepts silently."""
         import warnings
+        device = torch.device(device)
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("TrainStep: the FD-GAN HIP path needs an MI355X (`cuda`) device; there is no CPU fallback (got %s)" % device)
         self.dev = device
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")                 # the pretrained=True warning is replaced by the explicit check below
@@ -74,7 +77,7 @@ class TrainStep:
         self.dp = dp
         # second HIP stream: work that does not depend on the generator's output (the discriminator's real half, VGG16 on
         # the ground truth) is enqueued there and fills the CUs the generator's small-grid launches leave idle
-        self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.side = torch.cuda.Stream(device=device)
         if dp is not None and dp.world > 1:
             self.sync_replicas()
 
@@ -114,13 +117,18 @@ class TrainStep:
         for p in self.netD.parameters():
             p.requires_grad_(flag)
 
-    def step(self, haze, gt):
-        """haze, gt: (B,3,H,W) float in [0,1] on the device.  Returns a dict of python floats (ONE host sync, at the end)."""
+    LOSS_NAMES = ("lossD", "lossG", "l1", "ssim", "perc", "adv")
+
+    def step(self, haze, gt, sync=True):
+        """haze, gt: (B,3,H,W) float in [0,1] on the device.  sync=True: a dict of python floats (ONE host sync, at the
+        end).  sync=False: the six loss values as ONE device tensor in LOSS_NAMES order and no host synchronisation at
+        all -- a training loop reads it every k steps (`losses_dict`): under data parallelism a per-step .tolist() is a
+        bubble in every rank's launch queue."""
         # ---- D step: two backward calls (D's activations live in its plan buffers).  The real half and VGG16's target
         # features depend on `gt` only: they go to the side stream and run beside the generator's forward.
         self._set_d_grad(True)
         self.optD.zero_grad()
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.dev)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             with torch.no_grad():
@@ -134,16 +142,17 @@ class TrainStep:
             fake_in = fusion_input(self.pool.query(fake.detach()))
         l_fake = bce_loss(self.netD(fake_in), 0.0)
         l_fake.backward()
-        self.optD.allreduce_grads(self.dp)
-        self.optD.step()
-        # ---- G step
-        self._set_d_grad(False)                                                    # D is a fixed critic here: no dW work
-        self.optG.zero_grad()
-        # the adversarial branch (frequency split -> D -> BCE) and the perceptual / SSIM / L1 branch only meet at `fake`:
-        # forward AND backward of the former run on the side stream (autograd replays a node on its forward's stream)
+        # ---- D's gradient exchange + Adam(D) + the G step's adversarial branch (frequency split -> D -> BCE) on the side
+        # stream; the perceptual / SSIM / L1 branch, which does not need D, meanwhile on the main one.  So D's all-reduce
+        # (3.2 MB: latency-priced on xGMI) is hidden under VGG16's forward instead of waited for.  The two branches only
+        # meet at `fake`; autograd replays a node on its forward's stream, so the adversarial BACKWARD runs beside VGG16's too.
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
+            self.optD.allreduce_end(self.optD.allreduce_begin(self.dp))
+            self.optD.step()
+            self._set_d_grad(False)                                                # D is a fixed critic here: no dW work
             l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        self.optG.zero_grad()
         l_perc = vgg_perceptual(self.vgg, fake, feats_gt)
         ssim = pytorch_ssim.ssim(fake, gt)
         l_l1 = l1_loss(fake, gt)
@@ -152,36 +161,115 @@ class TrainStep:
         with self.optG.overlap(self.dp):            # slices of the flat gradient are all-reduced while the backward still runs
             lossG.backward()
         self.optG.step()
-        vals = torch.stack([t.detach().float() for t in (l_real + l_fake, lossG, l_l1, ssim, l_perc, l_adv)]).tolist()
-        return dict(zip(("lossD", "lossG", "l1", "ssim", "perc", "adv"), vals))
+        vals = torch.stack([t.detach().float() for t in (l_real + l_fake, lossG, l_l1, ssim, l_perc, l_adv)])
+        return self.losses_dict(vals) if sync else vals
+
+    @classmethod
+    def losses_dict(cls, vals):
+        """The device tensor step(sync=False) returned -> dict of python floats (this is the host synchronisation)."""
+        return dict(zip(cls.LOSS_NAMES, vals.tolist()))
+
+    # ---- checkpoints in the format demo.py loads (/root/reference/demo.py:78-86: an nn.DataParallel state_dict) ----------
+    def save_checkpoint(self, out_dir, epoch):
+        """netG_epoch_<e>.pth / netD_epoch_<e>.pth with `module.`-prefixed keys, as torch.save(netG.state_dict()) of the
+        reference's nn.DataParallel-wrapped networks would write them."""
+        import os
+        os.makedirs(out_dir, exist_ok=True)
+        paths = []
+        for name, netw in (("netG", self.netG), ("netD", self.netD)):
+            sd = {"module." + k: v.detach().cpu().clone() for k, v in netw.state_dict().items()}
+            path = os.path.join(out_dir, "%s_epoch_%d.pth" % (name, epoch))
+            torch.save(sd, path)
+            paths.append(path)
+        return paths
 
 
-def main():
-    ap = argparse.ArgumentParser(description="synthetic-data smoke run of the FD-GAN training step")
+def build_parser():
+    ap = argparse.ArgumentParser(description="FD-GAN training on the HIP path (flags as /root/reference/demo.py:28-60 names them)")
+    ap.add_argument("--dataset", default="pix2pix")
+    ap.add_argument("--dataroot", default="", help="directory of <i>.h5 pairs (datasets/pix2pix.py); empty: synthetic images")
     ap.add_argument("--batchSize", type=int, default=16)
+    ap.add_argument("--originalSize", type=int, default=256)
     ap.add_argument("--imageSize", type=int, default=256)
-    ap.add_argument("--niter", type=int, default=5)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--niter", type=int, default=5, help="epochs over --dataroot (synthetic: steps)")
     ap.add_argument("--lrG", type=float, default=0.0002)
     ap.add_argument("--lrD", type=float, default=0.0002)
     ap.add_argument("--beta1", type=float, default=0.5)
+    ap.add_argument("--annealStart", type=int, default=0, help="first epoch of the linear LR decay (misc.adjust_learning_rate)")
+    ap.add_argument("--annealEvery", type=int, default=400, help="epochs over which the LR decays to zero")
+    ap.add_argument("--poolSize", type=int, default=50)
+    ap.add_argument("--exp", "--save", dest="exp", default="", help="directory for netG_epoch_<e>.pth / netD_epoch_<e>.pth")
+    ap.add_argument("--evalIter", type=int, default=1, help="save a checkpoint every this many epochs")
+    ap.add_argument("--display", type=int, default=5, help="read the losses back (one host sync) every this many steps")
     ap.add_argument("--vgg", default="", help="pretrained VGG16: vgg16.weight, a torchvision state_dict or vgg16.t7")
     ap.add_argument("--densenet", default="", help="torchvision densenet121 state_dict for the generator's encoder")
-    opt = ap.parse_args()
+    return ap
+
+
+def run(opt):
+    """Trains and returns (checkpoint paths written, last loss dict).  With --dataroot: epochs over the .h5 pairs through
+    misc.getLoader (rank r takes every world-th batch); without: --niter steps on synthetic images."""
     dp = DpContext.from_env()
     dev = dp.device or torch.device("cuda", 0)
-    ts = TrainStep(dev, opt.lrG, opt.lrD, opt.beta1, dp=dp, vgg_weights=opt.vgg or None, densenet_weights=opt.densenet or None,
-                   synthetic=not (opt.vgg or opt.densenet))
-    g = torch.Generator(device="cpu").manual_seed(1234 + dp.rank)
-    for it in range(opt.niter):
-        gt = torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)
-        haze = (gt * 0.6 + 0.3).clamp(0, 1)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        r = ts.step(haze, gt)
-        torch.cuda.synchronize()
-        if dp.rank == 0:
-            print("[%d] %.1f ms  %s" % (it, 1e3 * (time.time() - t0), {k: round(v, 4) for k, v in r.items()}), flush=True)
+    synthetic = not opt.dataroot
+    if synthetic and dp.rank == 0 and not (opt.vgg and opt.densenet):
+        print("train.py: no --dataroot / weight files: a SYNTHETIC run on random images with randomly initialised "
+              "VGG16 / DenseNet-121 encoder (throughput and plumbing only)", flush=True)
+    ts = TrainStep(dev, opt.lrG, opt.lrD, opt.beta1, pool_size=opt.poolSize, dp=dp, vgg_weights=opt.vgg or None,
+                   densenet_weights=opt.densenet or None, synthetic=synthetic)
+    written, last, it = [], None, 0
+    t0 = time.time()
+
+    def one(haze, gt):
+        nonlocal last, it, t0
+        vals = ts.step(haze, gt, sync=False)
+        it += 1
+        if it % max(1, opt.display) == 0:
+            last = ts.losses_dict(vals)                  # the only host synchronisation of the loop
+            if dp.rank == 0:
+                dt = (time.time() - t0) / max(1, opt.display)
+                print("[%d] %.1f ms/step  %s" % (it, 1e3 * dt, {k: round(v, 4) for k, v in last.items()}), flush=True)
+            t0 = time.time()
+        return vals
+
+    if synthetic:
+        g = torch.Generator(device="cpu").manual_seed(1234 + dp.rank)
+        vals = None
+        for _ in range(opt.niter):
+            gt = torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)
+            vals = one((gt * 0.6 + 0.3).clamp(0, 1), gt)
+        if vals is not None:
+            last = ts.losses_dict(vals)
+        if opt.exp and dp.rank == 0:
+            written += ts.save_checkpoint(opt.exp, 0)
+    else:
+        loader = misc.getLoader(opt.dataset, opt.dataroot, opt.originalSize, opt.imageSize, opt.batchSize, opt.workers,
+                                split="train", shuffle=True, seed=1234)
+        for epoch in range(opt.niter):
+            if epoch > opt.annealStart:                  # linear decay, as misc.adjust_learning_rate is written to be used
+                misc.adjust_learning_rate(ts.optG, opt.lrG, epoch, None, opt.annealEvery)
+                misc.adjust_learning_rate(ts.optD, opt.lrD, epoch, None, opt.annealEvery)
+            vals = None
+            for i, (haze, gt) in enumerate(loader):
+                if i % dp.world != dp.rank:
+                    continue
+                vals = one(haze.float().to(dev, non_blocking=True), gt.float().to(dev, non_blocking=True))
+            if vals is not None:
+                last = ts.losses_dict(vals)
+            if opt.exp and dp.rank == 0 and (epoch + 1) % max(1, opt.evalIter) == 0:
+                written += ts.save_checkpoint(opt.exp, epoch)
+    torch.cuda.synchronize()
     dp.close()
+    return written, last
+
+
+def main(argv=None):
+    written, last = run(build_parser().parse_args(argv))
+    if last is not None:
+        print("final losses:", {k: round(v, 4) for k, v in last.items()}, flush=True)
+    for pth in written:
+        print("wrote", pth, flush=True)
 
 
 if __name__ == "__main__":

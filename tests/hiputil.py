@@ -108,3 +108,28 @@ def emulate_bf16_operands(module, round_grads=False):
         if isinstance(m, (nn.ReLU, nn.LeakyReLU)):
             m.inplace = False
     return module
+
+
+def op_reference(r, dy_view, meta):
+    """PlanBackward.check_reference: ONE fused op of a recorded plan under torch autograd on the SAME device tensors (fp32
+    math; the activated input is rounded to bf16 and the filter to bf16, as the gradient-side kernels see them): returns
+    (dW reference, dx reference) for the op's record `r`, the gradient view of its output and its prologue description."""
+    x, w, k, pad = r["x"], r["w"], r["k"], r["pad"]
+    st = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+    with torch.enable_grad():            # this runs inside an autograd.Function's backward
+        xr = x.torch_nchw().requires_grad_(True)
+        a = xr
+        if meta.get("bn") is not None:
+            a = F.batch_norm(a, None, None, meta["gamma"].detach(), meta["beta"].detach(), True, 0.0, meta["eps"])
+        if meta["act"] == ACT_RELU:
+            a = torch.relu(a)
+        elif meta["act"] == ACT_LEAKY02:
+            a = F.leaky_relu(a, 0.2)
+        if meta["pool"]:
+            a = F.avg_pool2d(a, 2)
+        a = st(a)
+        p = w.param.detach()
+        wt = (p.permute(1, 0, 2, 3) if w.transposed else p).to(torch.bfloat16).float().requires_grad_(True)
+        y = F.conv2d(a, wt, None, r["stride"], pad)
+        y.backward(dy_view.torch_nchw()[:, :w.cout])
+    return wt.grad, xr.grad

@@ -75,6 +75,9 @@ def test_loader_and_helpers(tmp_path):
     m = misc.AverageMeter()
     m.update(2.0, 3), m.update(4.0, 1)
     assert m.avg == 2.5 and m.count == 4
+    m.avg = 7.0                                  # a plain attribute, as in the reference (misc.py:121-136)
+    m.reset()
+    assert (m.val, m.avg, m.sum, m.count) == (0, 0, 0, 0)
     opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)
     misc.adjust_learning_rate(opt, 2e-4, 0, 0, 4)
     assert opt.param_groups[0]['lr'] == pytest.approx(1.5e-4)
@@ -98,9 +101,15 @@ def test_loader_and_helpers(tmp_path):
             swapped += 1
             assert float(got[0]) < i and float(got[0]) not in seen          # an older image, returned once
             seen.add(float(got[0]))
-            assert any(float(pool.store[s][0]) == i for s in range(4))      # the new one took its slot
+            assert any(float(pool.images[s][0]) == i for s in range(4))     # the new one took its slot
     assert 150 < kept < 250 and kept + swapped == 400
     assert misc.ImagePool(0).query(a) is a
+    # queries of different shapes (a ragged last batch, another image size): stored per slot, never broadcast
+    pool = misc.ImagePool(2, seed=3)
+    pool.query(torch.zeros(4, 3, 8, 8)), pool.query(torch.ones(4, 3, 8, 8))
+    outs = [pool.query(torch.full(shape, 2.0 + i)) for i, shape in enumerate([(1, 3, 8, 8), (4, 3, 16, 16), (4, 3, 8, 8)] * 8)]
+    assert all(o.dim() == 4 for o in outs) and {tuple(t.shape) for t in pool.images} <= {(4, 3, 8, 8), (1, 3, 8, 8), (4, 3, 16, 16)}
+    assert all(bool((t == t.flatten()[0]).all()) for t in pool.images)       # every slot holds ONE whole image batch
     np.random.seed(5)
     r1 = misc.ImagePool(3).rng.integers(1 << 30)
     np.random.seed(5)

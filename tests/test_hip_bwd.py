@@ -399,6 +399,44 @@ def test_weight_gradient_4x4_transpose_read_kernel(E, n, cin, cout, h, w):
     assert rel_rms(dw.cpu(), dw_direct.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,k", [(4, 144, 288, 127, 127, 4), (4, 128, 32, 256, 256, 3), (2, 72, 144, 128, 128, 3),
+                                              (4, 224, 128, 128, 128, 1)])
+def test_weight_gradient_is_bitwise_reproducible_at_full_size(E, n, cin, cout, h, w, k):
+    """Six launches of the same weight gradient at the training step's own image sizes (D's 4x4 144 -> 288 @ 127, the growth
+    conv @ 256, D's 72 -> 144 @ 128, a bottleneck @ 128): bitwise equal, with the workspace poisoned in between (a partial
+    that is read but never written, or an LDS write that a counted barrier does not cover, shows up here: conv_wgrad_r4's
+    step barrier left its row write uncovered in round 2 -- 1 % wrong, differently on every launch, at 127 x 127 only)."""
+    from fdgan_hip import lib as L
+    pad = {4: 1, 3: 1, 1: 0}[k]
+    ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+    torch.manual_seed(0)
+    x = torch.randn(n, h, w, cin, device=DEV).to(torch.float16)
+    dy = (torch.randn(n, ho, wo, cout, device=DEV) * 0.1).to(torch.bfloat16)
+    keep = [torch.randn(cin, device=DEV) * 0.1, torch.rand(cin, device=DEV) + 0.5, torch.rand(cin, device=DEV) + 0.5,
+            torch.randn(cin, device=DEV) * 0.1]
+    pro = E.make_prologue(act=L.ACT_LEAKY02 if k == 4 else L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3])
+    ws = torch.empty(1 << 26, dtype=torch.float32, device=DEV)
+    desc = E.conv_desc(k, 1, pad, cout=cout)
+    outs = []
+    for it in range(6):
+        if it % 2 == 1:
+            ws.fill_(float("nan"))
+        dw = torch.zeros(cout, cin, k, k, device=DEV)
+        E.conv_bwd_weight(E.View(x).fd, pro, E.View(dy).fd, desc, dw, None, ws, False)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert bool(torch.isfinite(outs[0]).all())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), float((o - outs[0]).abs().max())
+    # and right: against torch on the same operands (fp32 accumulation on the device; a = bf16(act(bn(x))) as the kernel rounds it)
+    sc = keep[2] / torch.sqrt(keep[1] + 1e-5)
+    a = x.float() * sc + (keep[3] - keep[0] * sc)
+    a = torch.where(a > 0, a, a * (0.2 if k == 4 else 0.0)).to(torch.bfloat16).float().permute(0, 3, 1, 2).contiguous()
+    wref = torch.zeros(cout, cin, k, k, device=DEV, requires_grad=True)
+    F.conv2d(a, wref, None, 1, pad).backward(dy.float().permute(0, 3, 1, 2).contiguous())
+    assert rel_rms(outs[0].cpu(), wref.grad.cpu()) < 2e-3
+
+
 def test_flat_adam_matches_torch_adam():
     from fdgan_hip.optim import FlatAdam
     torch.manual_seed(3)

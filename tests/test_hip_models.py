@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from hiputil import op_reference as hiputil_op_reference
 from hiputil import psnr, rel_rms
 
 pytestmark = pytest.mark.gpu
@@ -234,11 +235,19 @@ def test_vgg16_matches_golden(golden_dir):
         assert a.shape == b.shape and rel_rms(a.cpu(), b) < 2e-2
 
 
-@pytest.mark.parametrize("hw", [(96, 128), (256, 256)])
-def test_demo_end_to_end_png_parity(nets, tmp_path, hw):
-    """demo.py's whole pipeline (dataset -> `module.`-prefixed checkpoint -> train-mode generator on
-    the HIP path -> min-max normalised PNG) against the oracle pushed through the same writer:
-    SURVEY 8c's acceptance is PSNR within 0.02 dB and SSIM within 1e-3 of the reference's score."""
+@pytest.mark.parametrize("hw,n,ref_db", [((96, 128), 2, 25.0), ((256, 256), 2, 25.0), ((256, 256), 2, 30.0), ((1024, 1024), 1, 30.0)])
+def test_demo_end_to_end_png_parity(nets, tmp_path, hw, n, ref_db):
+    """demo.py's whole pipeline (dataset -> `module.`-prefixed checkpoint -> train-mode generator on the HIP path ->
+    min-max normalised PNG) against the oracle pushed through the same writer, scored by PSNRSSIM.py -- the reference's own
+    workflow (/root/reference/README.md:27-51, demo.py:116-151, PSNRSSIM.py:201-273).
+
+    north_star's acceptance: PSNR within 0.02 dB and SSIM within 1e-3 of the reference's score.  That budget only BINDS
+    where the reference scores realistically (weights and SOTS are not in the image, so the generator is random-init and
+    a random ground truth scores 8.7 dB / SSIM 0.01, where any perturbation is invisible -- VERDICT r2, weak #1).  So the
+    ground truth is built FROM the oracle's PNG: GT = clamp(oracle PNG + seeded Gaussian noise), sigma chosen so that the
+    oracle scores `ref_db` (25 dB: a typical SOTS score, MSE 3.2e-3; 30 dB: a strong one, MSE 1e-3).  A HIP-vs-oracle
+    floor of F dB then costs 10 log10(1 + 10^((ref_db - F) / 10)) dB: 0.02 dB needs F >= 48.3 dB at 25 and >= 53.4 dB at
+    30.  Asserted per image, not on the mean."""
     net, ref = nets
     import demo
     import misc
@@ -253,27 +262,34 @@ def test_demo_end_to_end_png_parity(nets, tmp_path, hw):
     root, res, oref, gtd = (str(tmp_path / d) for d in ("ds", "res", "oref", "gt"))
     for d in (res, oref, gtd):
         os.makedirs(d)
-    hz = det_input((2, 3) + hw, seed=77, lo=0.0, hi=1.0)
-    gt = det_input((2, 3) + hw, seed=78, lo=0.0, hi=1.0)
-    for i in range(2):
-        path = write_pair(root, i, hz[i].permute(1, 2, 0).numpy(), gt[i].permute(1, 2, 0).numpy())
-        assert path.endswith(".h5")                                  # the reference's file format, via datasets/h5lite.py
-        Image.fromarray(misc.to_uint8_image(gt[i], normalize=False)).save(os.path.join(gtd, "%d.png" % i))
-    opt = demo.build_parser().parse_args(["--valDataroot", root, "--netG", ck, "--outDir", res, "--workers", "0"])
-    written = demo.run(opt)
-    assert [os.path.basename(p) for p in written] == ["0.png", "1.png"]
-    for i in range(2):                          # the reference runs batch 1 in train mode, one sample per call
+    hz = det_input((n, 3) + hw, seed=77, lo=0.0, hi=1.0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sigma = 10.0 ** (-ref_db / 20.0)
+    rng = np.random.default_rng(20260928)
+    for i in range(n):                          # the reference runs batch 1 in train mode, one sample per call
         with torch.no_grad():
             y = og(hz[i:i + 1].clone())
         misc.save_image(y[0], os.path.join(oref, "%d.png" % i), normalize=True)
+        o8 = np.asarray(Image.open(os.path.join(oref, "%d.png" % i)).convert("RGB")).astype(np.float64) / 255.0
+        gt = np.clip(o8 + rng.normal(0.0, sigma, o8.shape), 0.0, 1.0)
+        gt8 = np.round(gt * 255.0).astype(np.uint8)
+        Image.fromarray(gt8).save(os.path.join(gtd, "%d.png" % i))
+        path = write_pair(root, i, hz[i].permute(1, 2, 0).numpy(), gt8.astype(np.float32) / 255.0)
+        assert path.endswith(".h5")                                  # the reference's file format, via datasets/h5lite.py
+    opt = demo.build_parser().parse_args(["--valDataroot", root, "--netG", ck, "--outDir", res, "--workers", "0"])
+    written = demo.run(opt)
+    assert [os.path.basename(p) for p in written] == ["%d.png" % i for i in range(n)]
     direct_p, direct_s = ps.score_dirs(oref, res, verbose=False)
     hp, hs = ps.score_dirs(gtd, res, verbose=False)
     rp, rs = ps.score_dirs(gtd, oref, verbose=False)
-    rep = {"png_psnr_hip_vs_oracle": direct_p, "png_ssim_hip_vs_oracle": direct_s, "psnr_vs_gt": [hp, rp],
-           "ssim_vs_gt": [hs, rs]}
-    _report("demo_png_%dx%d" % hw, rep)
-    assert min(direct_p) > 35.0 and min(direct_s) > 0.98, rep
-    assert abs(np.mean(hp) - np.mean(rp)) < 0.02 and abs(np.mean(hs) - np.mean(rs)) < 1e-3, rep
+    dp = [abs(a - b) for a, b in zip(hp, rp)]
+    ds = [abs(a - b) for a, b in zip(hs, rs)]
+    rep = {"png_psnr_hip_vs_oracle": direct_p, "png_ssim_hip_vs_oracle": direct_s, "psnr_vs_gt": {"hip": hp, "oracle": rp},
+           "ssim_vs_gt": {"hip": hs, "oracle": rs}, "abs_delta_psnr_db": dp, "abs_delta_ssim": ds, "budget": [0.02, 1e-3]}
+    _report("demo_png_%dx%d_ref%ddB" % (hw + (int(ref_db),)), rep)
+    assert all(abs(v - ref_db) < 1.0 for v in rp), rep               # the regime the test is about
+    assert min(direct_p) > 52.0 and min(direct_s) > 0.998, rep
+    assert max(dp) <= 0.02 and max(ds) <= 1e-3, rep
 
 
 def test_dehaze22_d_matches_golden(golden_dir):
@@ -610,6 +626,7 @@ def test_dense_block_backward_small(nets):
     P.launch()
     B = PlanBackward(P)
     B.checks = []
+    B.check_reference = hiputil_op_reference
     B.zero_()
     E.to_nhwc(cot.to(DEV), B.G(E.View(yb)))
     grads = {}
@@ -662,6 +679,7 @@ def test_fdgan_backward_matches_oracle_and_golden(nets, golden_dir):
     from models.dehaze1113 import _plan_backward
     B = _plan_backward(g._plan_for(xg))
     B.checks = []
+    B.check_reference = hiputil_op_reference
     y = g(xg)
     assert y.requires_grad
     ((y - tgt.to(DEV)) ** 2).mean().backward()
@@ -717,6 +735,7 @@ def test_vgg16_backward_perceptual_path(golden_dir):
     from fdgan_hip.backward import PlanBackward
     P._bwd = PlanBackward(P)
     P._bwd.checks = []
+    P._bwd.check_reference = hiputil_op_reference
     sum((f * c.to(DEV)).sum() for f, c in zip(feats, cots)).backward()
     torch.cuda.synchronize()
     checks = P._bwd.checks
@@ -854,7 +873,49 @@ def test_training_step_matches_oracle_step():
         agree[name] = same / max(total, 1)
     rep["first_update_sign_agreement"] = agree
     _report("train_step_vs_oracle", rep)
-    assert agree["D"] > 0.97 and agree["G"] > 0.85, agree      # bf16 storage flips the sign of some near-zero generator gradients
+    assert agree["D"] > 0.98 and agree["G"] > 0.95, agree      # bf16 gradient storage flips the sign of some near-zero generator gradients
+
+
+def test_training_step_full_size_configs2():
+    """BASELINE.json configs[2] at its real size -- B = 16 @ 256x256, the workload bench.py times -- asserted, not just
+    timed (at the 2 x 64x64 of the other step tests dense blocks 2 / 3 run at 32^2 / 16^2 and fall back to
+    the first-generation gradient kernels).  Two TrainStep objects built from the same seed take one step on the same
+    batch: every loss is finite and BITWISE equal between the two (fixed-order reductions everywhere), the instrumented
+    launch list of the step contains every second-generation kernel, and both networks' parameters moved."""
+    import train
+    from fdgan_hip import engine as E
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(21)
+    gt = torch.rand(16, 3, 256, 256, generator=g).to(dev)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    runs = []
+    for k in range(2):
+        torch.manual_seed(1234)
+        np.random.seed(99)                                   # ImagePool's generator is seeded from numpy's global RNG
+        ts = train.TrainStep(dev, synthetic=True)
+        w0 = ts.netG.dense_block2.denselayer7.conv2.weight.detach().clone()
+        d0 = ts.netD.main.layer4.conv.weight.detach().clone()
+        names = None
+        if k == 0:
+            E.kernel_timer_arm(None, 1, 4096)
+        r = ts.step(haze, gt)
+        torch.cuda.synchronize()
+        if k == 0:
+            samples, n_launch = E.kernel_timer_read(4096)
+            names = {nm for _, _, nm in samples}
+        assert all(np.isfinite(v) for v in r.values()), r
+        assert not torch.equal(w0, ts.netG.dense_block2.denselayer7.conv2.weight)
+        assert not torch.equal(d0, ts.netD.main.layer4.conv.weight)
+        runs.append((r, names, ts.optG.flat.clone(), ts.optD.flat.clone()))
+        del ts
+        torch.cuda.empty_cache()
+    (r1, names, g1, dflat1), (r2, _, g2, dflat2) = runs
+    _report("train_step_full_size", {"run1": r1, "run2": r2, "launchers": sorted(names)})
+    assert r1 == r2, (r1, r2)                                # bitwise: python floats of the same fp32 values
+    assert torch.equal(g1, g2) and torch.equal(dflat1, dflat2)      # and so is every updated parameter
+    for want in ("conv1x1_ds_bn128", "conv3x3_rs2_bn32", "conv1x1_bwd_wgrad_stream", "conv3x3_bwd_stream2", "conv_wgrad3x3_r3",
+                 "conv_wgrad4x4_r4", "conv3x3_wd128", "conv3x3_wd128_bwd", "conv4x4_wd144", "conv4x4_wd144_bwd", "adam_step"):
+        assert want in names, (want, sorted(names))
 
 
 def test_overlapped_allreduce_slices_are_final_when_sent():

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/p$i" -o p -- python "$R/bench.py" --no-cpu-baseline --steps 2 --warmup 1 "$@" > "$OUT/p$i.log" 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT/p$i" -o p -- python "$R/bench.py" --no-cpu-baseline --no-forward-1024 --steps 2 --warmup 1 "$@" > "$OUT/p$i.log" 2>&1
   i=$((i+1))
 done
 python - "$OUT" "$R/gpurun_out/pmc_bench.json" <<'PY'
@@ -21,7 +21,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernel symbol -> (launcher name, workload key): the forward kernels are keyed on the forward-only workload, the
 # BatchNorm-backward pass on the training step (both run in the default bench.py)
-names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs2_kernel": ("conv3x3_rs_bn32", "netG_B16_256"),
+names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs2_kernel": ("conv3x3_rs2_bn32", "netG_B16_256"),
          "bn_bwd_apply_kernel": ("bn_bwd_apply", "train_B16_256"),
          "conv1x1_bwd_kernel": ("conv1x1_bwd_stream", "train_B16_256"),
          "conv1x1_bwdw_kernel": ("conv1x1_bwd_wgrad_stream", "train_B16_256"),
@@ -37,7 +37,7 @@ names = {"conv1x1_ds_kernel": ("conv1x1_ds_bn128", "netG_B16_256"), "conv3x3_rs2
          "conv_igemm_kernel<3, 1, 0, 8, 2, 1, 4, 9, 1, 1>": ("conv3x3_wd128_bwd", "train_B16_256"),
          "conv_igemm_kernel<4, 1, 0, 8, 3, 1, 3, 16, 0, 1>": ("conv4x4_wd144", "train_B16_256"),
          "conv_igemm_kernel<4, 1, 0, 8, 3, 1, 3, 16, 1, 1>": ("conv4x4_wd144_bwd", "train_B16_256")}
-res = {"_comment": "average per launch over every launch of the kernel in `python bench.py` (training step + netG forward leg, B=16 @256^2); KiB; "
+res = {"_comment": "average per launch over every launch of the kernel in `python bench.py --no-forward-1024` (training step + netG forward leg, B=16 @256^2 only); KiB; "
                    "FETCH_SIZE is x2-corrected by bench.py per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
 for k, cs in agg.items():
     for sym, (nm, wl) in names.items():
