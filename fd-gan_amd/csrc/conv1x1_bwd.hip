@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a) {
 constexpr int F1_TBP = 64 * 2 + 16;              // transposition pitch of one pixel (64 channels)
 constexpr int F1_TB = 16 * F1_TBP;               // per wave
 constexpr int F1_TILE = B1_PX * 256;             // a [64 px][128 ch] bf16 tile
-constexpr int F1_LDS = 3 * F1_TILE + 4 * 8 * 1024 + 8 * F1_TB + 2 * F1_TILE + 1024;   // dy tiles, filter, transposition, activated tiles, dy_affine coefficients
+constexpr int F1_LDS = 3 * F1_TILE + 4 * 8 * 1024 + 8 * F1_TB + 2 * F1_TILE + 1024 + 1024;   // dy tiles, filter, transposition, activated tiles, dy_affine coefficients, BatchNorm scale / shift
 
 typedef short f1_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 f1_trfrag(const char* p0, const char* p1) {
@@ -267,6 +267,8 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   char* tb0 = wt + 4 * 8 * 1024;                              // 8 x transposition areas
   char* at0 = tb0 + 8 * F1_TB;                                // 2 x activated tile [64 px][256 B]: tile t lives in t mod 2
   float* cf = reinterpret_cast<float*>(at0 + 2 * F1_TILE);    // dy_affine: cB[128], cC[128] (read per step: 16 registers less)
+  float* scf = cf + 256;                                      // this channel tile's BatchNorm scale[128], shift[128]: read per row phase
+                                                              // (16 registers less: the third x / G set of the two-tile prefetch needs them)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kgl = lane >> 4;
@@ -286,18 +288,22 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   const int piece = lane & 7, ql0 = lane >> 3;
   const int cg = c0 + chh * 64 + piece * 8;
   const bool ch_ok = cg < a.C;
-  const int cg_ld = ch_ok ? cg : 0;                           // lanes past the last channel read channel 0 (ignored below)
-  float sc8[8], sh8[8], s1[8], s2[8];
+  const int cg_ld = ch_ok ? cg : 0;                           // lanes past the last channel work on channels 0-7 (their G store is skipped,
+                                                              // their sums and weight-gradient columns are never read; C % 8 == 0)
+  f32x2 s1[4], s2[4];                                         // BatchNorm's two sums of the lane's 8 channels, as 4 pairs (fd_row8)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = cg + e;
-    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
-    if (a.mode == 2 && c < a.C) {
+  for (int k = 0; k < 4; ++k) s1[k] = s2[k] = f32x2{0.f, 0.f};
+  if (tid < 128) {                                            // scale / shift of the tile's 128 channels -> LDS
+    const int c = c0 + tid < a.C ? c0 + tid : 0;
+    float sc = 1.f, sh = 0.f;
+    if (a.mode == 2) {
       const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
-      sh8[e] = bt - a.mean[c] * sc8[e];
+      sc = gm / sqrtf(a.var[c] + a.eps);
+      sh = bt - a.mean[c] * sc;
     }
+    scf[tid] = sc, scf[128 + tid] = sh;
   }
+  const float* scl = scf + chh * 64 + piece * 8;              // the lane's 8 channels
   for (int f = tid; f < 4 * 512; f += 512) {                  // this channel tile's filter fragments: once
     const int kc = f >> 9, t8 = (f >> 6) & 7, ln = f & 63;
     const int tile16 = ct * 8 + t8;
@@ -314,26 +320,42 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
 
   // dy rows (2 units per thread), x / G rows (2 units) of a pixel tile: requested one whole tile ahead, two register sets
   u32x4 dyr[2], ybr[2];
-  if (AFFINE && tid < 256) cf[tid] = tid < 128 ? aa.cB[tid] : aa.cC[tid - 128];   // (published by the first step's barrier ... of the
-  if (AFFINE) __syncthreads();                                                     // previous line: it is read BEFORE that barrier)
+  if (AFFINE && tid < 256) cf[tid] = tid < 128 ? aa.cB[tid] : aa.cC[tid - 128];
+  __syncthreads();                                            // cf (read BEFORE the first step's barrier) and scf
   const float* cfl = cf + (tid & 15) * 8;                     // the thread's dy column is the same for both units
+  // addresses: a wave-uniform tile base (scalar arithmetic) + the lane's 32-bit element offset inside the 64-pixel tile, fixed
+  // for the whole kernel (the first version multiplied 64-bit pixel indices per load: v_mad_u64_u32 / v_lshl_add_u64 per access)
+  unsigned dyo[2], ybo[2], xo[2], go[2], ato[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * 512;                              // dy / yb unit: (pixel u / 16, 16-byte column u % 16)
+    dyo[i] = (unsigned)((u >> 4) * a.dy_pitch + (u & 15) * 8);
+    ybo[i] = AFFINE ? (unsigned)((u >> 4) * aa.yb_pitch + (u & 15) * 8) : 0u;
+    const int pl = pq * 16 + i * 8 + ql0;                     // row-phase unit: pixel pl of the tile, this lane's 8 channels
+    xo[i] = (unsigned)(pl * a.x_pitch + cg_ld);
+    go[i] = (unsigned)(pl * a.g_pitch + cg_ld);
+    const int c16 = chh * 8 + piece;                          // 16-byte column of the 128-channel activated tile
+    ato[i] = (unsigned)(f1_off(pl, c16 >> 1) + ((c16 & 1) << 4));
+  }
   auto request_dy = [&](int tl) __attribute__((always_inline)) {   // tl < my_tiles
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    const unsigned short* dyt_g = a.dy + p0 * a.dy_pitch;
+    const unsigned short* ybt_g = AFFINE ? aa.yb + p0 * aa.yb_pitch : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int u = tid + i * 512;                            // (pixel u / 16, 16-byte column u % 16)
-      dyr[i] = *reinterpret_cast<const u32x4*>(a.dy + (p0 + (u >> 4)) * a.dy_pitch + (u & 15) * 8);
-      if (AFFINE) ybr[i] = *reinterpret_cast<const u32x4*>(aa.yb + (p0 + (u >> 4)) * aa.yb_pitch + (u & 15) * 8);
+      dyr[i] = *reinterpret_cast<const u32x4*>(dyt_g + dyo[i]);
+      if (AFFINE) ybr[i] = *reinterpret_cast<const u32x4*>(ybt_g + ybo[i]);
     }
   };
   auto request = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2]) __attribute__((always_inline)) {   // tl < my_tiles
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
+    const unsigned short* xt_g = a.x + p0 * a.x_pitch;
+    const unsigned short* gt_g = a.g + p0 * a.g_pitch;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const long long p = p0 + pq * 16 + i * 8 + ql0;
-      xv[i] = *reinterpret_cast<const u32x4*>(a.x + p * a.x_pitch + cg_ld);
+      xv[i] = *reinterpret_cast<const u32x4*>(xt_g + xo[i]);
       gv[i] = zero4;
-      if (ACC == 1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + p * a.g_pitch + cg_ld);
+      if (ACC == 1) gv[i] = *reinterpret_cast<const u32x4*>(gt_g + go[i]);
     }
   };
   // weight gradient of one tile: dW[128 co][128 ci tile] += dy^T (64 px x 128 co) * act (64 px x 128 ci)
@@ -352,6 +374,15 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
         for (int j = 0; j < 2; ++j) wacc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf[j], wacc[c][j], 0, 0, 0);
     }
   };
+  unsigned dyl[2];                                             // LDS offset of the thread's two dy units inside a staged tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * 512, q = u >> 4, c16 = u & 15;
+    dyl[i] = (unsigned)(f1_off(q, c16 >> 1) + ((c16 & 1) << 4));
+  }
+  // One step = one 64-pixel tile; the next tile's rows are requested right after the step's barrier.  (Requesting x / G TWO tiles
+  // ahead in a third register set was tried in round 3: 76-368 B of scratch per lane whatever else was moved to LDS, and a
+  // scratch reload is a vmcnt(0): 2.4-3.6 TB/s instead of 4.1-5.6.)
   int d3 = 0;                                                  // tl mod 3
   auto step = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2], auto last) __attribute__((always_inline)) {
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
@@ -369,7 +400,6 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int u = tid + i * 512, q = u >> 4, c16 = u & 15;
       u32x4 v = dyr[i];
       if (AFFINE) {     // dy' = dy + cB * yb + cC, rounded to bf16 exactly as the separate pass stored it
         f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
@@ -377,7 +407,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
         f = __builtin_elementwise_fma(cb8, y8, f + cc8);        // packed fp32: 8 instructions
         v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
       }
-      lds_write16(dyt + f1_off(q, c16 >> 1) + ((c16 & 1) << 4), v);
+      lds_write16(dyt + dyl[i], v);
     }
     B1_BARRIER();                                             // this tile's dy rows and the previous tile's activated rows are in place
     if (!decltype(last)::value) {
@@ -408,6 +438,14 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (tl > 0 && !(a.dbg & 32)) wgrad_tile(dyp, atp);        // its MFMAs execute while the row phase below issues
+    unsigned short* gst = a.g + p0 * a.g_pitch;                 // wave-uniform
+    f32x2 sc2[4], sh2[4];
+    {
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(scl), sb = *reinterpret_cast<const f32x4*>(scl + 4);
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(scl + 128), hb = *reinterpret_cast<const f32x4*>(scl + 132);
+      sc2[0] = f32x2{sa[0], sa[1]}, sc2[1] = f32x2{sa[2], sa[3]}, sc2[2] = f32x2{sb[0], sb[1]}, sc2[3] = f32x2{sb[2], sb[3]};
+      sh2[0] = f32x2{ha[0], ha[1]}, sh2[1] = f32x2{ha[2], ha[3]}, sh2[2] = f32x2{hb[0], hb[1]}, sh2[3] = f32x2{hb[2], hb[3]};
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ql = i * 8 + ql0;
@@ -415,19 +453,10 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
       const f32x8 fx = fd_cvt8<FmtA>(xv[i]);                  // the forward input: fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[i]), f32x8);
       f32x8 act;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pre = fmaf(fx[e], sc8[e], sh8[e]);
-        const bool in = cg + e < a.C;
-        const float v = in ? da[e] * (pre > 0.f ? 1.f : a.slope) : 0.f;
-        s1[e] += v;
-        s2[e] += v * fx[e];
-        o[e] = ACC ? fmaf(sc8[e], v, o[e]) : v;
-        act[e] = in ? (pre > 0.f ? pre : a.slope * pre) : 0.f;        // what the forward conv saw
-      }
-      const int pix = pq * 16 + ql, c16 = chh * 8 + piece;            // 16-byte column of the 128-channel tile
-      if (!(a.dbg & 64)) lds_write16(at + f1_off(pix, c16 >> 1) + ((c16 & 1) << 4), __builtin_bit_cast(u32x4, __builtin_convertvector(act, bf16x8)));
-      if (ch_ok) *reinterpret_cast<u32x4*>(a.g + (p0 + pq * 16 + ql) * a.g_pitch + cg) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+      fd_row8<ACC, true>(da, fx, o, sc2, sh2, 1.f, a.slope, s1, s2, act);      // act: what the forward conv saw
+      // (lanes past the last channel computed on channels 0-7: finite values in weight-gradient columns that are never stored)
+      if (!(a.dbg & 64)) lds_write16(at + ato[i], __builtin_bit_cast(u32x4, __builtin_convertvector(act, bf16x8)));
+      if (ch_ok) *reinterpret_cast<u32x4*>(gst + go[i]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
@@ -452,19 +481,22 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   if (my_tiles > 0) wgrad_tile(dyt0 + ((my_tiles - 1) % 3) * F1_TILE, at0 + ((my_tiles - 1) & 1) * F1_TILE);
   B1_BARRIER();                                               // every wave is through its last fragment reads
   if (a.partial != nullptr) {   // lanes 8 apart own the same channels; then the four pixel quarters in a fixed order
+    float t1[8], t2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 8; ++e) {
+      t1[e] = s1[e >> 1][e & 1], t2[e] = s2[e >> 1][e & 1];
 #pragma unroll
       for (int d = 8; d < 64; d <<= 1) {
-        s1[e] += __shfl_xor(s1[e], d, 64);
-        s2[e] += __shfl_xor(s2[e], d, 64);
+        t1[e] += __shfl_xor(t1[e], d, 64);
+        t2[e] += __shfl_xor(t2[e], d, 64);
       }
+    }
     float* red = reinterpret_cast<float*>(tb0);               // [8 waves][64][2]
     if (ql0 == 0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(wave * 64 + piece * 8 + e) * 2] = s1[e];
-        red[(wave * 64 + piece * 8 + e) * 2 + 1] = s2[e];
+        red[(wave * 64 + piece * 8 + e) * 2] = t1[e];
+        red[(wave * 64 + piece * 8 + e) * 2 + 1] = t2[e];
       }
     B1_BARRIER();
     if (tid < 256) {
@@ -507,7 +539,7 @@ bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor*
            ((uintptr_t)t->ptr & 15) == 0;
   };
   const long long P = dpre->n * dpre->h * dpre->w;
-  return (dy->c == 32 || dy->c == 64 || dy->c == 128) && dense(dy) && dense(fwd_x) && dense(dpre) && P % B1_PX == 0 &&
+  return (dy->c == 32 || dy->c == 64 || dy->c == 128) && dense(dy) && dense(fwd_x) && dense(dpre) && P % B1_PX == 0 && dpre->c % 8 == 0 &&
          dpre->c <= 1024 && dpre->stride[2] >= (dpre->c + 7) / 8 * 8 && fwd_x->stride[2] >= (dpre->c + 7) / 8 * 8 &&
          P * fwd_x->stride[2] < (1ll << 40) && FD_TUNE_GETENV("FDGAN_DEBUG_NO_BWD1X1S") == nullptr;
 }

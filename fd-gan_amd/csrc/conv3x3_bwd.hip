@@ -258,16 +258,18 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   // ---- row phase ownership: lane -> 8 channels (piece) of pixels pl0 and pl0 + 16 of the wave's 32
   const int piece = lane & 3, pl0 = lane >> 2;
   const int cg = chq * 32 + piece * 8;
-  float sc8[8], sh8[8], s1[8], s2[8];
+  f32x2 sc2[4], sh2[4], s1[4], s2[4];                         // the lane's 8 channels as 4 pairs (fd_row8: packed fp32 math)
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = cg + e;
-    sc8[e] = 1.f, sh8[e] = 0.f, s1[e] = s2[e] = 0.f;
+    float sc = 1.f, sh = 0.f;
     if (a.mode == 2) {
       const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-      sc8[e] = gm / sqrtf(a.var[c] + a.eps);
-      sh8[e] = bt - a.mean[c] * sc8[e];
+      sc = gm / sqrtf(a.var[c] + a.eps);
+      sh = bt - a.mean[c] * sc;
     }
+    sc2[e >> 1][e & 1] = sc, sh2[e >> 1][e & 1] = sh;
+    s1[e >> 1][e & 1] = 0.f, s2[e >> 1][e & 1] = 0.f;
   }
   // ---- dy staging: thread -> (pixel tid / 4, 16-byte piece tid % 4) of the 66-pixel row; waves 0-4 (264 threads).
   // Row index rr counts from the segment's first halo row: rr = row - (y_begin - 1); slot = rr & 3.
@@ -330,16 +332,9 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   auto row_unit = [&](u32x4 dat, u32x4 xv, u32x4 gv, float w1, float w0) __attribute__((always_inline)) -> u32x4 {
     const f32x8 da = __builtin_convertvector(__builtin_bit_cast(bf16x8, dat), f32x8);
     const f32x8 fx = fd_cvt8<FmtA>(xv);         // the forward input: fp16
-    f32x8 o;
+    f32x8 o, unused;
     if constexpr (ACC == 1) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv), f32x8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float pre = fmaf(fx[e], sc8[e], sh8[e]);
-      const float v = da[e] * (pre > 0.f ? w1 : w0);
-      s1[e] += v;
-      s2[e] += v * fx[e];
-      o[e] = ACC == 1 ? fmaf(sc8[e], v, o[e]) : (ACC == 2 ? sc8[e] * v : v);
-    }
+    fd_row8<ACC, false>(da, fx, o, sc2, sh2, w1, w0, s1, s2, unused);
     return __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
   };
 
@@ -448,20 +443,23 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
     }
   }
   if (a.partial != nullptr) {   // lanes 4 apart own the same channels; then the two pixel halves in a fixed order
+    float t1[8], t2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 8; ++e) {
+      t1[e] = s1[e >> 1][e & 1], t2[e] = s2[e >> 1][e & 1];
 #pragma unroll
       for (int d = 4; d < 64; d <<= 1) {
-        s1[e] += __shfl_xor(s1[e], d, 64);
-        s2[e] += __shfl_xor(s2[e], d, 64);
+        t1[e] += __shfl_xor(t1[e], d, 64);
+        t2[e] += __shfl_xor(t2[e], d, 64);
       }
+    }
     B3_BARRIER();                                             // every wave is through its last row phase (red aliases the tiles)
     float* red = reinterpret_cast<float*>(b3_lds + 4 * B4_DROW);   // [8 waves][32][2]
     if (pl0 == 0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(wave * 32 + piece * 8 + e) * 2] = s1[e];
-        red[(wave * 32 + piece * 8 + e) * 2 + 1] = s2[e];
+        red[(wave * 32 + piece * 8 + e) * 2] = t1[e];
+        red[(wave * 32 + piece * 8 + e) * 2 + 1] = t2[e];
       }
     B3_BARRIER();
     if (tid < 256) {

@@ -165,6 +165,37 @@ __device__ __forceinline__ u32x4 fd_xform8(u32x4 raw, const float* sc, const flo
   return fd_pack8<FO>(fd_affine_act<F>(raw, sc, sh, slope));
 }
 
+// ---- the row phase of a data gradient on one 8-channel piece (one pixel), shared by the streaming backward kernels ------
+//   pre = x * sc + sh;   v = da * (pre > 0 ? w1 : w0);   s1 += v;   s2 += v * x          (BatchNorm's two reductions)
+//   o   = ACC == 1 ? o + sc * v  :  ACC == 2 ? sc * v  :  v                              (into / as the gradient of x)
+//   act = pre * (pre > 0 ? w1 : w0)        (WANT_ACT: what the forward conv saw, for a fused weight gradient; needs w1 == 1)
+// Written on float2 pairs so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two channels per instruction) and
+// two v_cmp + v_cndmask per pair; NO control flow: the element-wise `in ? ... : 0` selects of the first versions were
+// compiled into s_and_saveexec / s_cbranch_execz pairs (88 exec-mask regions per two steps of conv1x1_bwdw_kernel).
+// Channels past the tensor's last one are the CALLER's business (whole pieces: skip the store; their sums are never read).
+template <int ACC, bool WANT_ACT>
+__device__ __forceinline__ void fd_row8(const f32x8& da, const f32x8& fx, f32x8& o, const f32x2 (&sc)[4], const f32x2 (&sh)[4], float w1,
+                                        float w0, f32x2 (&s1)[4], f32x2 (&s2)[4], f32x8& act) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 x2 = {fx[2 * k], fx[2 * k + 1]}, d2 = {da[2 * k], da[2 * k + 1]};
+    const f32x2 pre = __builtin_elementwise_fma(x2, sc[k], sh[k]);
+    const f32x2 m = {pre[0] > 0.f ? w1 : w0, pre[1] > 0.f ? w1 : w0};
+    const f32x2 v = d2 * m;
+    s1[k] += v;
+    s2[k] = __builtin_elementwise_fma(v, x2, s2[k]);
+    f32x2 o2;
+    if constexpr (ACC == 1) o2 = __builtin_elementwise_fma(sc[k], v, (f32x2){o[2 * k], o[2 * k + 1]});
+    else if constexpr (ACC == 2) o2 = sc[k] * v;
+    else o2 = v;
+    o[2 * k] = o2[0], o[2 * k + 1] = o2[1];
+    if constexpr (WANT_ACT) {
+      const f32x2 a2 = pre * m;
+      act[2 * k] = a2[0], act[2 * k + 1] = a2[1];
+    }
+  }
+}
+
 // Once per workgroup: BatchNorm -> per-channel (scale, shift) in LDS for channels [0, nch);
 // (1, 0) when the conv has no norm.  Workgroup (0,0) also applies the train-mode side
 // effects of the norm (running statistics, num_batches_tracked).
