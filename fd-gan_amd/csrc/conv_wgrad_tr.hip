@@ -466,6 +466,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_r3_kernel(WgradRowsArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) A[0][sub][ct] = g3_frag(ap[ct][0] + sub * 2048, ap[ct][1] + sub * 2048);
   }
+  // Every wave's first fragment reads (row 0: transformed slot 0, dy slot 0) must have COMPLETED before any wave enters step 0,
+  // which rewrites those very slots (row 2 into transformed slot 0 a third of the way in, the DMA of row 6 into dy slot 0): in
+  // the steady state a step's barrier separates the reads of a slot from its next writer, here nothing did.  A wave held back
+  // right after the barrier above -- e.g. by a co-resident kernel's s_setprio'd waves, which is what the training step's
+  // second stream puts beside this kernel -- then read the NEXT rows' data (round 3: 1 % errors that came and went with what
+  // ran on the other stream; invisible in every single-stream test).
+  R3_BARRIER();
 
   // step j (phase P = j mod 6): MFMAs of input row j; dy row j - ky is in A[(j - ky) mod 3].  Six blocks of 6 MFMAs; the
   // transform of row j + 2's two full units is spread over blocks 1-4 (two dwords each), pinned by sched_barriers so that
@@ -706,6 +713,7 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) 
   for (int kx = 0; kx < 4; ++kx) B[kx] = g3_frag(bp[kx][0], bp[kx][1]);
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) A[0][ct] = g3_frag(ap[ct][0], ap[ct][1]);
+  R3_BARRIER();      // as in conv_wgrad_r3_kernel: the first fragment reads of every wave complete before step 0 rewrites their slots
 
   // step j (phase P = j mod 4): MFMAs of input row j; dy row j - ky is in A[(j - ky) mod 4]
   auto step = [&](int j, auto P) __attribute__((always_inline)) {

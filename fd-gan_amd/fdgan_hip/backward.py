@@ -133,6 +133,15 @@ class PlanBackward:
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
         self.fuse_wgrad = os.environ.get("FDGAN_NO_FUSED_WGRAD") is None        # tuning aid: separate 1x1 weight-gradient kernel
         self.fold_flush = os.environ.get("FDGAN_NO_FOLDED_FLUSH") is None       # tuning aid: separate affine_accumulate pass
+        # Weight gradients off the critical path: dW only feeds the optimizer, while the data gradient is what the next
+        # (earlier) layer waits for.  Every unfused weight gradient (kernel + its fixed-order reduction) whose operands are
+        # persistent buffers runs on a second HIP stream with its own split-K workspace; the walk joins it at the end (and
+        # before a gradient slice is handed to the all-reduce).  At 64 x 64 and below, where every kernel of a dense layer is
+        # launch-sized, this takes two launches per layer out of the serial chain.
+        self.offload_wgrad = os.environ.get("FDGAN_NO_WGRAD_STREAM") is None and dev.type == "cuda" and not self.recompute
+        self.wstream = torch.cuda.Stream(device=dev) if self.offload_wgrad else None
+        self.ws_w = torch.empty(1 << 26, dtype=torch.float32, device=dev) if self.offload_wgrad else None
+        self._w_pending = False
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
         # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
@@ -209,6 +218,13 @@ class PlanBackward:
             out += [bn.weight, bn.bias]
         return [p for p in out if p.requires_grad]
 
+    def join_side(self):
+        """The walk's stream waits for the weight gradients issued on the side stream so far (end of a walk; before a slice
+        of the flat gradient is handed to the all-reduce)."""
+        if self._w_pending:
+            torch.cuda.current_stream(self.wstream.device).wait_stream(self.wstream)
+            self._w_pending = False
+
     def G(self, view):
         return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
 
@@ -263,7 +279,21 @@ class PlanBackward:
                 db = None
                 if r["bias"] is not None and r["bias"].requires_grad:
                     db = grad_target(grads, r["bias"])
-                E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, grad_target(grads, p), db, self.ws, True)
+                dw_t = grad_target(grads, p)
+                # dy must be a view of a persistent gradient buffer that nothing rewrites before the walk ends (not the
+                # dense blocks' shared bottleneck-gradient buffer, not a temporary of this call)
+                side = (self.offload_wgrad and self.checks is None and r.get("y") is not None and dy_view.buf is self.gbuf.get(r["y"].buf.data_ptr())
+                        and r["y"].buf.data_ptr() not in self.multi_version)
+                if side:
+                    main = torch.cuda.current_stream(p.device)
+                    self.wstream.wait_stream(main)            # dy is final (flushed) on the walk's stream
+                    with torch.cuda.stream(self.wstream):
+                        E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, dw_t, db, self.ws_w, True)
+                    self._w_pending = True
+                    if os.environ.get("FDGAN_WGRAD_SERIAL") is not None:      # debug aid: side stream, but no concurrency
+                        self.join_side()
+                else:
+                    E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, dw_t, db, self.ws, True)
         check = self.checks is not None
         if check:
             dw_ref, dx_ref = self.check_reference(r, dy_view, meta)      # supplied by the test (tests/hiputil.op_reference)
@@ -490,3 +520,4 @@ class PlanBackward:
             if PROGRESS_HOOK is not None:
                 PROGRESS_HOOK(self, i)
         self.flush_all()      # plan inputs: their gradients are read by the caller
+        self.join_side()      # parameter gradients written on the side stream are complete for whatever follows on this one

@@ -118,6 +118,7 @@ class _Overlap:
         self.sent = [False] * len(opt.params)
         self.touched = [False] * len(opt.params)
         self.works, self.sent_early = [], 0
+        self.walks = []                     # the PlanBackward objects seen (their side streams are joined before a send)
 
     def __enter__(self):
         if self.active:
@@ -128,6 +129,7 @@ class _Overlap:
     def _progress(self, B, i):
         tab = self.tables.get(id(B))
         if tab is None:                     # first record of this walk: count every record's contributions
+            self.walks.append(B)
             tab = self.tables[id(B)] = [[self.index[id(p)] for p in B.record_params(j) if id(p) in self.index]
                                         for j in range(len(B.recs))]
             if self.pending is None:
@@ -141,6 +143,8 @@ class _Overlap:
         self._sweep(final=False)
 
     def _send(self, k0, k1):
+        for B in self.walks:                # weight gradients a walk put on its side stream must have landed
+            B.join_side()
         lo, hi = self.opt.offsets[k0], self.opt.offsets[k1]
         for k in range(k0, k1):
             self.sent[k] = True

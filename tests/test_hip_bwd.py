@@ -437,6 +437,102 @@ def test_weight_gradient_is_bitwise_reproducible_at_full_size(E, n, cin, cout, h
     assert rel_rms(outs[0].cpu(), wref.grad.cpu()) < 2e-3
 
 
+def test_streaming_kernels_are_reproducible_beside_a_busy_second_stream(E):
+    """The training step runs two HIP streams, so every hand-pipelined kernel shares CUs with another kernel's waves -- among
+    them the filter-direct convolutions, which raise their wave priority around the MFMA blocks.  A wave that is held back at
+    the wrong moment exposes any hand-counted wait or barrier that does not really cover what it is assumed to cover
+    (conv_wgrad_r3 / r4's first fragment reads, round 3).  Each kernel below runs alone, then repeatedly while a second stream
+    runs D's 4x4 data gradient (s_setprio, 30 KB of LDS: it co-resides with all of them) and an HBM-bound elementwise kernel:
+    results must be bitwise those of the solo run."""
+    from fdgan_hip import lib as L
+    dev = torch.device(DEV)
+    torch.manual_seed(1)
+    side = torch.cuda.Stream()
+    # the neighbour: data gradient of D's 4x4 144 -> 288 @ 128 (conv4x4_wd144_bwd) + a streaming elementwise op
+    nb = dict(x=torch.randn(8, 128, 128, 144, device=dev).half(), dy=(torch.randn(8, 127, 127, 288, device=dev) * 0.1).bfloat16(),
+              G=torch.zeros(8, 128, 128, 144, device=dev, dtype=torch.bfloat16), ws=torch.empty(1 << 22, device=dev),
+              big=torch.randn(1 << 26, device=dev))
+    wt = torch.randn(288, 144, 4, 4, device=dev) * 0.05
+    nb["pw"] = E.PackedWeight(wt, 144, 288, 4, transposed=False, flip=True, stride=1, layout=L.WLAYOUT_CHUNK32)
+    nb["pw"].pack()
+    nb["pro"] = E.make_prologue(act=L.ACT_LEAKY02)
+    nb["desc"] = E.conv_desc(4, 1, 2, cout=144, w_layout=L.WLAYOUT_CHUNK32)
+
+    def neighbour():
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                E.conv_bwd_data(E.View(nb["dy"]).fd, nb["pw"], E.View(nb["x"]).fd, nb["pro"], E.View(nb["G"]).fd, nb["desc"], None, accumulate=1)
+            nb["big"].mul_(1.0001)
+
+    def bn(c):
+        return [torch.randn(c, device=dev) * 0.1, torch.rand(c, device=dev) + 0.5, torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1]
+
+    cases = []
+    # weight gradients: D's 4x4 (conv_wgrad_r4), the growth conv (conv_wgrad_r3), 72 -> 144 (first generation)
+    for (n, cin, cout, h, w, k, act) in ((8, 144, 288, 128, 128, 4, L.ACT_LEAKY02), (8, 128, 32, 128, 128, 3, L.ACT_RELU), (4, 72, 144, 128, 128, 3, L.ACT_LEAKY02)):
+        pad, ho, wo = 1, h + 2 - k + 1, w + 2 - k + 1
+        x = torch.randn(n, h, w, cin, device=dev).half()
+        dy = (torch.randn(n, ho, wo, cout, device=dev) * 0.1).bfloat16()
+        keep = bn(cin)
+        pro = E.make_prologue(act=act, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3])
+        ws = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+        desc = E.conv_desc(k, 1, pad, cout=cout)
+
+        def run(x=x, dy=dy, pro=pro, ws=ws, desc=desc, cout=cout, cin=cin, k=k, keep=keep):
+            dw = torch.zeros(cout, cin, k, k, device=dev)
+            E.conv_bwd_weight(E.View(x).fd, pro, E.View(dy).fd, desc, dw, None, ws, False)
+            return dw
+        cases.append(("wgrad %dx%d %d->%d" % (k, k, cin, cout), run))
+    # forward: growth conv (conv3x3_rs2) and bottleneck (conv1x1_ds) with statistics
+    for (cin, cout, k) in ((128, 32, 3), (224, 128, 1)):
+        x = torch.randn(8, 128, 128, 256, device=dev).half()
+        keep = bn(cin)
+        pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3])
+        pw = E.PackedWeight(torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5, cout, cin, k)
+        pw.pack()
+        desc = E.conv_desc(k, 1, k // 2, cout=cout, w_layout=pw.layout)
+        ws = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+
+        def run(x=x, pro=pro, pw=pw, desc=desc, ws=ws, cin=cin, cout=cout, keep=keep):
+            y = torch.empty(8, 128, 128, cout, dtype=torch.float16, device=dev)
+            info = E.conv2d(E.View(x, 0, cin).fd, pw, None, pro, E.View(y).fd, desc, ws)
+            return torch.cat([y.float().flatten(), ws[:info.stats_rows * info.stats_cpad * 2].clone()])
+        cases.append(("fwd %dx%d %d->%d" % (k, k, cin, cout), run))
+    # backward data: growth conv (conv3x3_bwd_stream2) and the fused bottleneck backward (conv1x1_bwd_wgrad_stream)
+    for kind in ("dgrad3x3", "fused1x1"):
+        c = 128 if kind == "dgrad3x3" else 224
+        cy = 32 if kind == "dgrad3x3" else 128
+        k = 3 if kind == "dgrad3x3" else 1
+        x = torch.randn(8, 128, 128, 256, device=dev).half()
+        dy = (torch.randn(8, 128, 128, cy, device=dev) * 0.1).bfloat16()
+        G0 = (torch.randn(8, 128, 128, 256, device=dev) * 0.1).bfloat16()
+        keep = bn(c)
+        pro = E.make_prologue(act=L.ACT_RELU, mean=keep[0], var=keep[1], gamma=keep[2], beta=keep[3])
+        pwf = E.PackedWeight(torch.randn(cy, c, k, k, device=dev) * 0.05, c, cy, k, transposed=False, flip=True, stride=1, layout=L.WLAYOUT_CHUNK32)
+        pwf.pack()
+        desc = E.conv_desc(k, 1, k // 2, cout=c, w_layout=L.WLAYOUT_CHUNK32)
+        ws_bn, ws = torch.empty(1 << 22, device=dev), torch.empty(1 << 26, device=dev)
+
+        def run(kind=kind, x=x, dy=dy, G0=G0, pro=pro, pwf=pwf, desc=desc, ws_bn=ws_bn, ws=ws, c=c, keep=keep):
+            G = G0.clone()
+            if kind == "dgrad3x3":
+                rows, cpad = E.conv_bwd_data(E.View(dy).fd, pwf, E.View(x, 0, c).fd, pro, E.View(G, 0, c).fd, desc, ws_bn, accumulate=1)
+                return torch.cat([G.float().flatten(), ws_bn[:rows * cpad * 2].clone()])
+            dw = torch.zeros(128, c, device=dev)
+            rows, cpad = E.conv1x1_bwd_data_weight(E.View(dy).fd, pwf, E.View(x, 0, c).fd, pro, E.View(G, 0, c).fd, ws_bn, 1, ws, dw, False)
+            return torch.cat([G.float().flatten(), ws_bn[:rows * cpad * 2].clone(), dw.flatten()])
+        cases.append((kind, run))
+    for name, run in cases:
+        solo = run()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(solo).all()), name
+        for it in range(6):
+            neighbour()
+            got = run()
+            torch.cuda.synchronize()
+            assert torch.equal(got, solo), (name, it, float((got - solo).abs().max()))
+
+
 def test_flat_adam_matches_torch_adam():
     from fdgan_hip.optim import FlatAdam
     torch.manual_seed(3)
