@@ -449,10 +449,54 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
   }
 }
 
+// Batched form: every [nsplit][numel] partial block of a backward walk in ONE launch (job table in device memory, as
+// fdgan_pack_conv_weights does for the filter images).  blockIdx.x walks 64-element column groups of all jobs.
+struct WredBatchArgs {
+  const FdReduceJob* jobs;
+  int njobs;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WredBatchArgs b) {
+  __shared__ float sh[4][64];
+  const long long g = blockIdx.x;
+  int lo = 0, hi = b.njobs - 1;
+  while (lo < hi) {   // last job with first_group <= g
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.jobs[mid].first_group <= g) lo = mid;
+    else hi = mid - 1;
+  }
+  const FdReduceJob j = b.jobs[lo];
+  const int col = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = (g - j.first_group) * 64 + col;
+  float t = 0.f;
+  if (i < j.numel) {
+    const float* src = j.part + i;
+    int s_ = ty;
+    for (; s_ + 28 < j.nsplit; s_ += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[(long long)(s_ + 4 * k) * j.numel];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
+    }
+    for (; s_ < j.nsplit; s_ += 4) t += src[(long long)s_ * j.numel];
+  }
+  sh[ty][col] = t;
+  __syncthreads();
+  if (ty == 0 && i < j.numel) {
+    t = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);      // the summation order of wgrad_reduce_kernel: bitwise the same result
+    j.out[i] = j.accumulate ? j.out[i] + t : t;
+  }
+}
+
 }  // namespace
 int fd_wgrad_reduce(const float* part, float* out, long long numel, int nsplit, int accumulate, hipStream_t stream) {
   WredArgs r{part, out, numel, nsplit, accumulate};
   return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, stream);
+}
+extern "C" int fdgan_wgrad_reduce_batch(const FdReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream) {
+  FD_REQUIRE(jobs_device && njobs > 0 && njobs < (1 << 20) && total_groups > 0 && total_groups < (1ll << 31), "wgrad_reduce_batch: empty job table");
+  WredBatchArgs b{jobs_device, (int)njobs};
+  return fd_launch(&wgrad_reduce_batch_kernel, "wgrad_reduce_batch", dim3((unsigned)total_groups), dim3(256), 0, b, static_cast<hipStream_t>(stream));
 }
 namespace {
 

@@ -197,8 +197,8 @@ extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_p
                                              const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                                              int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw,
                                              int dw_accumulate, const FdTensor* dy_affine_x, const float* dy_affine_b, const float* dy_affine_c,
-                                             FdStream stream) {
-  FD_REQUIRE(dy && w_packed_flipped && fwd_x && dpre && wgrad_workspace && dw, "conv1x1_bwd_data_weight: NULL argument");
+                                             int64_t* wsplit_out, FdStream stream) {
+  FD_REQUIRE(dy && w_packed_flipped && fwd_x && dpre && wgrad_workspace, "conv1x1_bwd_data_weight: NULL argument");
   FD_REQUIRE(accumulate >= 0 && accumulate <= 2, "conv1x1_bwd_data_weight: accumulate %d", accumulate);
   FD_REQUIRE(((uintptr_t)w_packed_flipped & 15) == 0, "conv1x1_bwd_data_weight: packed weights must be 16-byte aligned");
   FD_REQUIRE(fwd_pro == nullptr || !fwd_pro->pool2, "conv1x1_bwd_data_weight: pooled prologues are not fused");
@@ -227,6 +227,8 @@ extern "C" int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_p
   if (rc != FD_OK) return rc;
   if (rows_out) *rows_out = rows;
   if (cpad_out) *cpad_out = cpad;
+  if (wsplit_out) *wsplit_out = nsplit;
+  if (dw == nullptr) return FD_OK;      // the caller reduces the partials later (fdgan_wgrad_reduce_batch)
   return fd_wgrad_reduce(wgrad_workspace, dw, 128LL * dpre->c, (int)nsplit, dw_accumulate, st);
 }
 

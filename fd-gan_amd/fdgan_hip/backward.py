@@ -142,6 +142,18 @@ class PlanBackward:
         self.wstream = torch.cuda.Stream(device=dev) if self.offload_wgrad else None
         self.ws_w = torch.empty(1 << 26, dtype=torch.float32, device=dev) if self.offload_wgrad else None
         self._w_pending = False
+        # The fused bottleneck kernel's weight-gradient partials ([pixel slots][128][C] per dense layer) are summed by ONE
+        # table-driven launch at the end of the walk instead of one 10 us launch per layer inside the chain of dependent
+        # launches: every such record keeps its own partial buffer (0.7 GB for the generator at B = 16 @ 256^2: nothing next
+        # to 288 GB).  Which records these are is learned by the first walk (it reduces per layer and notes where the fused
+        # kernel ran); the set is fixed from the second walk on, so the all-reduce overlap can count on it.
+        self.defer_reduce = os.environ.get("FDGAN_NO_DEFERRED_REDUCE") is None
+        self._fused_seen = set()    # records on which the fused kernel launched (filled by every walk)
+        self._deferred_idx = None   # frozen after the first walk
+        self.wparts = {}            # record index -> (private partial buffer, nsplit of its last launch)
+        self.reduce_jobs = []
+        self.reduce_table = None
+        self.walks_done = 0
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
         # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
@@ -205,12 +217,23 @@ class PlanBackward:
             raise NotImplementedError("ReLU pre-masking needs the fused data-gradient path")
         self.relu_premask = True
 
+    def deferred_records(self):
+        """Records whose weight gradient leaves through the batched reduce at the end of the walk."""
+        return self._deferred_idx if self._deferred_idx is not None else frozenset()
+
+    def num_progress_records(self):
+        """PROGRESS_HOOK is called with 0 .. len(recs): the last index is the pseudo-record of the batched reduce."""
+        return len(self.recs) + 1
+
     def record_params(self, i):
-        """Parameters whose gradient record i's backward adds to (conv weight, bias, the prologue's BatchNorm pair)."""
+        """Parameters whose gradient record i's backward adds to (conv weight, bias, the prologue's BatchNorm pair).
+        i == len(self.recs): the deferred reductions' conv weights, complete only after the batched reduce."""
+        if i == len(self.recs):
+            return [self.recs[j]["w"].param for j in sorted(self.deferred_records()) if self.recs[j]["w"].param.requires_grad]
         r = self.recs[i]
         if r["kind"] != "conv":
             return []
-        out = [r["w"].param]
+        out = [] if i in self.deferred_records() else [r["w"].param]
         if r.get("bias") is not None:
             out.append(r["bias"])
         bn = r["pro"]._meta.get("bn") if r.get("pro") is not None else None
@@ -349,9 +372,23 @@ class PlanBackward:
                 aff = None
                 if dy_pending is not None:
                     aff = (E.View(dy_pending["buf"], 0, 128).fd, dy_pending["coef"][0], dy_pending["coef"][1])
-                res = E.conv1x1_bwd_data_weight(dy_view.fd, pw, x.fd, act_pro, gx.fd, self.ws_bn if bn is not None else None,
-                                                2 if store else 1, self.ws, grad_target(grads, p).view(w.cout, w.cin), True,
-                                                dy_affine=aff)
+                idx = r.get("_idx")
+                if idx in self.deferred_records():      # partials into the record's own buffer, summed by the batched launch
+                    ent = self.wparts.get(idx)
+                    if ent is None:
+                        nct = (w.cin + 127) // 128
+                        ent = self.wparts[idx] = [torch.empty(max(1, 256 // nct) * 128 * w.cin, dtype=torch.float32, device=p.device), 0]
+                    res = E.conv1x1_bwd_data_weight(dy_view.fd, pw, x.fd, act_pro, gx.fd, self.ws_bn if bn is not None else None,
+                                                    2 if store else 1, ent[0], None, True, dy_affine=aff)
+                    if res is not None:
+                        self.reduce_jobs.append((ent[0], grad_target(grads, p).view(w.cout, w.cin), w.cout * w.cin, res[2], True))
+                        res = res[:2]
+                else:
+                    res = E.conv1x1_bwd_data_weight(dy_view.fd, pw, x.fd, act_pro, gx.fd, self.ws_bn if bn is not None else None,
+                                                    2 if store else 1, self.ws, grad_target(grads, p).view(w.cout, w.cin), True,
+                                                    dy_affine=aff)
+                    if res is not None and idx is not None:
+                        self._fused_seen.add(idx)
                 if res is not None and dy_pending is not None:
                     dy_pending["coef"].zero_()
                     dy_pending["dirty"].clear()
@@ -484,8 +521,10 @@ class PlanBackward:
     def run(self, grads, skip_dx_of=()):
         """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's
         outputs.  `grads`: dict parameter -> fp32 gradient, filled / accumulated."""
+        self.reduce_jobs = []
         for i in range(len(self.recs) - 1, -1, -1):
             r = self.recs[i]
+            r["_idx"] = i
             if r["kind"] == "copy":
                 self.flush(r["dst"])
                 E.grad_ew(E.GRAD_ADD, self.G(r["dst"]), self.G(r["src"]))
@@ -520,4 +559,14 @@ class PlanBackward:
             if PROGRESS_HOOK is not None:
                 PROGRESS_HOOK(self, i)
         self.flush_all()      # plan inputs: their gradients are read by the caller
+        if self.reduce_jobs:  # the fused bottlenecks' weight gradients: one launch for all of them
+            key = tuple((pt.data_ptr(), o.data_ptr(), n, s_, a) for pt, o, n, s_, a in self.reduce_jobs)
+            if self.reduce_table is None or self.reduce_table.key != key:
+                self.reduce_table = E.ReduceTable(self.reduce_jobs, self.plan.device)
+            self.reduce_table.launch()
+        if self._deferred_idx is None and self.checks is None:
+            self._deferred_idx = frozenset(self._fused_seen) if self.defer_reduce else frozenset()
+        self.walks_done += 1
+        if PROGRESS_HOOK is not None:
+            PROGRESS_HOOK(self, len(self.recs))
         self.join_side()      # parameter gradients written on the side stream are complete for whatever follows on this one

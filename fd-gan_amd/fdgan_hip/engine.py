@@ -440,20 +440,43 @@ def conv1x1_bwd_data_weight(dy_fd, pw_flipped, fwd_x_fd, fwd_pro, dpre_fd, ws_bn
                             dy_affine=None):
     """The bottleneck's data gradient (as conv_bwd_data) and weight gradient in one pass; returns (rows, cpad), or None when
     the shape is outside the fused kernel (nothing launched).  dy_affine = (x_fd, B, C): dy + B * x + C is used instead of dy
-    (the pending linear part of the BatchNorm backward of dy's producer)."""
-    rows, cpad = C.c_int64(0), C.c_int64(0)
-    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    (the pending linear part of the BatchNorm backward of dy's producer).  dw=None: the per-slot partials stay in wgrad_ws for a
+    later reduce_batch; the return value is then (rows, cpad, nsplit)."""
+    rows, cpad, nsplit = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    assert dw is None or (dw.dtype == torch.float32 and dw.is_contiguous())
     rc = L.load().fdgan_conv1x1_bwd_data_weight(C.byref(dy_fd), pw_flipped.buf.data_ptr(), C.byref(fwd_x_fd),
                                                 C.byref(fwd_pro) if fwd_pro is not None else None, C.byref(dpre_fd), int(accumulate),
                                                 ws_bn.data_ptr() if ws_bn is not None else None, ws_bn.numel() if ws_bn is not None else 0,
-                                                C.byref(rows), C.byref(cpad), wgrad_ws.data_ptr(), wgrad_ws.numel(), dw.data_ptr(),
+                                                C.byref(rows), C.byref(cpad), wgrad_ws.data_ptr(), wgrad_ws.numel(),
+                                                dw.data_ptr() if dw is not None else None,
                                                 int(bool(dw_accumulate)), C.byref(dy_affine[0]) if dy_affine is not None else None,
                                                 dy_affine[1].data_ptr() if dy_affine is not None else None,
-                                                dy_affine[2].data_ptr() if dy_affine is not None else None, stream_ptr())
+                                                dy_affine[2].data_ptr() if dy_affine is not None else None, C.byref(nsplit), stream_ptr())
     if rc == L.FD_EUNSUPPORTED:
         return None
     L.check(rc, "conv1x1_bwd_data_weight")
-    return rows.value, cpad.value
+    return (rows.value, cpad.value) if dw is not None else (rows.value, cpad.value, nsplit.value)
+
+
+class ReduceTable:
+    """Every deferred [nsplit][numel] -> out reduction of a backward walk as ONE launch (fdgan_wgrad_reduce_batch).  jobs:
+    list of (partials tensor, out tensor, numel, nsplit, accumulate); the table is uploaded once and stays valid while those
+    tensors keep their addresses."""
+
+    def __init__(self, jobs, device):
+        self.keep = list(jobs)
+        tab = (L.FdReduceJob * len(jobs))()
+        first = 0
+        for t, (part, out, numel, nsplit, acc) in zip(tab, jobs):
+            assert part.dtype == torch.float32 and out.dtype == torch.float32 and part.numel() >= numel * nsplit and out.numel() >= numel
+            t.part, t.out, t.numel, t.nsplit, t.accumulate, t.first_group = part.data_ptr(), out.data_ptr(), numel, nsplit, int(bool(acc)), first
+            first += (numel + 63) // 64
+        self.groups = first
+        self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
+        self.key = tuple((p.data_ptr(), o.data_ptr(), n, s, a) for p, o, n, s, a in jobs)
+
+    def launch(self):
+        L.check(L.load().fdgan_wgrad_reduce_batch(self.table.data_ptr(), len(self.keep), self.groups, stream_ptr()), "wgrad_reduce_batch")
 
 
 def bn_bwd_coef(dgamma, dbeta, pro, channels, count, bsum, csum):

@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class FdganLibraryError(RuntimeError):
@@ -38,6 +38,11 @@ class FdPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
                 ("transposed", C.c_int32), ("flip", C.c_int32), ("layout", C.c_int32), ("dtype", C.c_int32), ("_pad", C.c_int32),
                 ("first_unit", C.c_int64)]
+
+
+class FdReduceJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("numel", C.c_int64), ("nsplit", C.c_int32), ("accumulate", C.c_int32),
+                ("first_group", C.c_int64)]
 
 
 class FdConvDesc(C.Structure):
@@ -139,7 +144,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_int64), C.POINTER(FdConvDesc), C.c_void_p]),
     "fdgan_conv1x1_bwd_data_weight": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdPrologue),
                                       C.POINTER(FdTensor), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(FdTensor), C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_wgrad_reduce_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_bn_bwd_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FdPrologue), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fdgan_affine_accumulate": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),

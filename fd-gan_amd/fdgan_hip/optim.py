@@ -131,7 +131,7 @@ class _Overlap:
         if tab is None:                     # first record of this walk: count every record's contributions
             self.walks.append(B)
             tab = self.tables[id(B)] = [[self.index[id(p)] for p in B.record_params(j) if id(p) in self.index]
-                                        for j in range(len(B.recs))]
+                                        for j in range(B.num_progress_records() if hasattr(B, "num_progress_records") else len(B.recs))]
             if self.pending is None:
                 self.pending = [0] * len(self.opt.params)
             for idxs in tab:
@@ -144,7 +144,8 @@ class _Overlap:
 
     def _send(self, k0, k1):
         for B in self.walks:                # weight gradients a walk put on its side stream must have landed
-            B.join_side()
+            if hasattr(B, "join_side"):
+                B.join_side()
         lo, hi = self.opt.offsets[k0], self.opt.offsets[k1]
         for k in range(k0, k1):
             self.sent[k] = True

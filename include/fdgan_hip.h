@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 7
+#define FDGAN_ABI_VERSION 8
 
 enum FdStatus {
   FD_OK = 0,
@@ -355,15 +355,31 @@ int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_flipped, cons
  * dy_affine_x != NULL: dy is not final yet -- the linear remainder of the BatchNorm backward of dy's own producer (norm2 of the
  * dense layer, fdgan_bn_bwd_finalize_coef's B and C) is still pending: the kernel uses dy + dy_affine_b[c] * dy_affine_x + dy_affine_c[c]
  * (dy_affine_x: that norm's input, the 128-channel bottleneck activation; rounded to bf16 as fdgan_affine_accumulate would have
- * stored it), which replaces that read-read-write pass over the gradient buffer.  dy itself is left as it is. */
+ * stored it), which replaces that read-read-write pass over the gradient buffer.  dy itself is left as it is.
+ * dw == NULL: the kernel's per-slot partials stay in wgrad_workspace ([*wsplit_out][128][C] fp32) and the caller sums them
+ * later -- fdgan_wgrad_reduce_batch does that for every such conv of a backward walk in ONE launch, off the chain of
+ * dependent launches (the weight gradient only feeds the optimizer). */
 int fdgan_conv1x1_bwd_data_weight(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro,
                                   const FdTensor* dpre, int accumulate, float* partial, int64_t capacity_floats, int64_t* rows_out,
                                   int64_t* cpad_out, float* wgrad_workspace, int64_t wgrad_workspace_floats, float* dw, int dw_accumulate,
-                                  const FdTensor* dy_affine_x, const float* dy_affine_b, const float* dy_affine_c, FdStream stream);
+                                  const FdTensor* dy_affine_x, const float* dy_affine_b, const float* dy_affine_c, int64_t* wsplit_out, FdStream stream);
 /* bsum[c] += B, csum[c] += C of dx = A*dpre + B*x + C for channels [0, channels): B = -gamma*rstd^2*dgamma/count,
  * C = -gamma*rstd*dbeta/count - B*mean (pro: the forward prologue's mean / var / gamma / eps). */
 int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue* pro, int64_t channels, int64_t count,
                       float* bsum, float* csum, FdStream stream);
+/* Sums [nsplit][numel] fp32 partial blocks into out[numel] (+= when accumulate) for a whole table of jobs in one launch, in
+ * the fixed order of the per-conv reduction (bitwise the same sums).  `jobs` lives in DEVICE memory; first_group = running
+ * sum of ceil(numel / 64) over the preceding jobs, total_groups = that sum over all jobs. */
+typedef struct FdReduceJob {
+  const float* part;
+  float* out;
+  int64_t numel;
+  int32_t nsplit;
+  int32_t accumulate;
+  int64_t first_group;
+} FdReduceJob;
+int fdgan_wgrad_reduce_batch(const FdReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream);
+
 /* dx += bsum[c] * x + csum[c] (x: NHWC fp16 activation, dx: NHWC bf16 gradient of equal shape). */
 int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
 /* Pooled prologues (pro->pool2, the transitions: BatchNorm + ReLU + 2x2 average in front of the 1x1 conv,
