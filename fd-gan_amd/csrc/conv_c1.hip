@@ -1,0 +1,264 @@
+// conv_c1.hip -- the ONE-filter convolution that ends both discriminators (nn.Conv2d(8 nf, 1, 4, 1, 1, bias=False) behind
+// LeakyReLU(0.2) and in front of the sigmoid: /root/reference/models/dehaze1113.py:221-223, models/dehaze22.py:147-149) and
+// its data gradient.
+//
+// On the implicit-GEMM kernels a single output channel is a 16- or 32-wide MFMA tile with one live row (forward:
+// conv4x4_bn32, 147 us at B = 16 @ 127x127, 31/32 of the matrix work on padding), and its data gradient is a K = 16 taps x 1
+// channel problem staged as sixteen 32-channel chunks (conv4x4_bn128_bwd: 297 us for 148 MB of output).  Both are really
+// vector-ALU / HBM problems:
+//   forward   y[p] = sum_tap sum_c a[p + tap][c] w[tap][c]: one thread per output pixel of an 8 x 32 tile; the activated halo
+//             tile of a 32-channel chunk sits in LDS as four planes of [pixel][8 channels] (consecutive lanes read consecutive
+//             16-byte slots: conflict-free), the chunk's 16 x 32 weights beside it (broadcast reads); v_dot2_f32_f16, fp32 sums.
+//   dgrad     dx[p][c] = act'(x[p][c]) * sum_tap dy[p + pad - tap] w[c][tap]: one thread per (pixel, 8 channels), the 16 x C
+//             filter as fp32 in LDS, the mask and the gradient buffer as whole 16-byte pieces of pixel rows.
+#include "conv_igemm.h"
+
+namespace {
+
+constexpr int C1_TH = 8, C1_TW = 32;           // output pixels per workgroup (256 threads: one each)
+
+struct C1FwdArgs {
+  const unsigned short* x;     // NHWC fp16 view
+  long long x_sn;
+  int x_sh, x_sw, H, W, Cin, nchunk;
+  const unsigned short* w;     // chunk32 fp16 image of the [1][Cin][KS][KS] filter
+  int pro_mode;
+  float slope, eps;
+  const float *mean, *var, *gamma, *beta;
+  float* y;                    // [N][1][Ho][Wo] fp32 (pre-sigmoid)
+  long long y_sn;
+  int y_sh, Ho, Wo, pad, tiles_x, tiles_y;
+  float e_slope;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(C1FwdArgs a) {
+  constexpr int IH = C1_TH + KS - 1, IW = C1_TW + KS - 1, NPIX = IH * IW, NPIXR = (NPIX + 15) / 16 * 16;
+  constexpr int PLANE = NPIXR * 16, IN_B = 4 * PLANE, W_B = KS * KS * 64;
+  extern __shared__ __attribute__((aligned(16))) char c1_lds[];
+  char* in_lds = c1_lds;                                   // [2][4 planes][NPIXR][16 B]
+  char* w_lds = c1_lds + 2 * IN_B;                          // [2][taps][4 groups][16 B]
+  float* sc_lds = reinterpret_cast<float*>(w_lds + 2 * W_B);   // [nchunk * 32] scale, shift
+  float* sh_lds = sc_lds + a.nchunk * 32;
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x;
+  tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y, n = tile / a.tiles_y;
+  const int oy0 = ty * C1_TH, ox0 = tx * C1_TW;
+  for (int c = tid; c < a.nchunk * 32; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      sc = 0.f;
+      if (c < a.Cin) {
+        const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+        sc = g / sqrtf(a.var[c] + a.eps);
+        sh = b - a.mean[c] * sc;
+      }
+    }
+    sc_lds[c] = sc, sh_lds[c] = sh;
+  }
+  __syncthreads();
+  const unsigned short* xn = a.x + (long long)n * a.x_sn;
+  constexpr int UNITS = NPIX * 4, UPT = (UNITS + 255) / 256;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 rin[UPT];
+  auto load = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + i * 256, p = u >> 2, kg = u & 3;           // the four 16-byte groups of a pixel are adjacent lanes: 64 B runs
+      const int py = p / IW, px = p - py * IW;
+      const int gy = oy0 - a.pad + py, gx = ox0 - a.pad + px;
+      const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && chunk * 32 + kg * 8 < a.Cin;
+      rin[i] = ok ? *reinterpret_cast<const u32x4*>(xn + (long long)gy * a.x_sh + (long long)gx * a.x_sw + chunk * 32 + kg * 8) : zero4;
+    }
+  };
+  auto store = [&](char* buf, char* wbuf, int chunk) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + i * 256, p = u >> 2, kg = u & 3;
+      if (u >= UNITS) continue;
+      const int py = p / IW, px = p - py * IW;
+      const int gy = oy0 - a.pad + py, gx = ox0 - a.pad + px;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && chunk * 32 + kg * 8 < a.Cin;
+      u32x4 v = rin[i];
+      if (a.pro_mode != 0) v = fd_xform8(v, sc_lds + chunk * 32 + kg * 8, sh_lds + chunk * 32 + kg * 8, a.slope);
+      lds_write16(buf + kg * PLANE + p * 16, ok ? v : zero4);          // zero padding applies to the ACTIVATED input
+    }
+    if (tid < KS * KS * 4) {   // the chunk's weights: tap tid / 4, 8-channel group tid % 4 (fragment image: cout row 0 = lanes 0, 16, 32, 48)
+      const int tap = tid >> 2, kg = tid & 3;
+      lds_write16(wbuf + tid * 16, *reinterpret_cast<const u32x4*>(a.w + ((long long)(chunk * KS * KS + tap) * 512 + kg * 16 * 8)));
+    }
+  };
+  const int ly = tid / C1_TW, lx = tid % C1_TW;
+  float acc4[4] = {0.f, 0.f, 0.f, 0.f};                    // four independent chains (v_dot2c accumulates in place)
+  load(0);
+  store(in_lds, w_lds, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    const bool more = chunk + 1 < a.nchunk;
+    if (more) load(chunk + 1);
+    const char* ib = in_lds + (chunk & 1) * IN_B;
+    const char* wb = w_lds + (chunk & 1) * W_B;
+#pragma unroll 1
+    for (int dy = 0; dy < KS; ++dy)        // one filter row at a time: fully unrolled, hipcc hoists all 128 fragment reads (448 B of scratch)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const int p = (ly + dy) * IW + lx + dx;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          // (a bit_cast of av[q] / wv[q] straight into the builtin made hipcc 7.2 use dword 0 for every q -- four identical
+          // v_dot2c_f32_f16 -- so the fragments are taken apart through a typed vector first)
+          const f16x8 av = __builtin_bit_cast(f16x8, lds_read16(ib + kg * PLANE + p * 16));
+          const f16x8 wv = __builtin_bit_cast(f16x8, lds_read16(wb + ((dy * KS + dx) * 4 + kg) * 16));
+          acc4[0] = __builtin_amdgcn_fdot2(__builtin_shufflevector(av, av, 0, 1), __builtin_shufflevector(wv, wv, 0, 1), acc4[0], false);
+          acc4[1] = __builtin_amdgcn_fdot2(__builtin_shufflevector(av, av, 2, 3), __builtin_shufflevector(wv, wv, 2, 3), acc4[1], false);
+          acc4[2] = __builtin_amdgcn_fdot2(__builtin_shufflevector(av, av, 4, 5), __builtin_shufflevector(wv, wv, 4, 5), acc4[2], false);
+          acc4[3] = __builtin_amdgcn_fdot2(__builtin_shufflevector(av, av, 6, 7), __builtin_shufflevector(wv, wv, 6, 7), acc4[3], false);
+        }
+      }
+    if (more) store(in_lds + ((chunk + 1) & 1) * IN_B, w_lds + ((chunk + 1) & 1) * W_B, chunk + 1);
+    __syncthreads();
+  }
+  const float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+  const int oy = oy0 + ly, ox = ox0 + lx;
+  if (oy < a.Ho && ox < a.Wo) a.y[(long long)n * a.y_sn + (long long)oy * a.y_sh + ox] = fmaxf(acc, a.e_slope * acc);
+}
+
+struct C1BwdArgs {
+  const unsigned short* dy;    // NHWC bf16 view, channel 0 used
+  long long dy_sn;
+  int dy_sh, dy_sw, Ho, Wo;
+  const unsigned short* w;     // chunk32 bf16 image of the flipped filter: cout' = C, cin' = 1
+  const unsigned short* x;     // forward input (fp16), the activation mask
+  long long x_sn;
+  int x_sh, x_sw;
+  unsigned short* g;           // gradient of x (bf16)
+  long long g_sn;
+  int g_sh, g_sw;
+  int H, W, C, C8, ks, pad, acc;   // pad: the FORWARD conv's
+  float slope;
+  long long total;
+  int ntile;
+};
+
+__global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char c1_lds[];
+  float* wl = reinterpret_cast<float*>(c1_lds);            // [taps][C8 * 8] fp32, forward tap order
+  const int kk = a.ks * a.ks, cp = a.C8 * 8;
+  for (int i = threadIdx.x; i < kk * cp; i += 256) {
+    const int t = i / cp, c = i - t * cp;
+    float v = 0.f;
+    if (c < a.C) {   // flipped image: Wf[cout' = c][cin' = 0][tap'] = W[0][c][kk - 1 - tap'];  fragment order, lane = c & 15 (cin' group 0), e = 0
+      const int tp = kk - 1 - t;
+      v = fd_cvt1<FmtG>(a.w[((long long)tp * a.ntile + (c >> 4)) * 512 + (c & 15) * 8]);
+    }
+    wl[i] = v;
+  }
+  __syncthreads();
+  // persistent workgroups (the 16 x C filter is converted once per workgroup, not once per 256 outputs); one thread = one pixel x
+  // four 8-channel pieces C32 apart (piece q of lane g is g + C32 q: for a fixed q adjacent lanes touch adjacent 16 bytes, so every
+  // load / store instruction covers whole runs of a pixel row): the 16 dy values and their index arithmetic are paid once per 32 outputs
+  const int C32 = (a.C8 + 3) / 4;
+  const long long units = a.total / a.C8 * C32;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int c32 = (int)(u % C32);
+    long long r = u / C32;
+    const int x = (int)(r % a.W);
+    r /= a.W;
+    const int y = (int)(r % a.H), n = (int)(r / a.H);
+    f32x8 da[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) da[q] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned short* dn = a.dy + (long long)n * a.dy_sn;
+    for (int ky = 0; ky < a.ks; ++ky) {
+      const int oy = y + a.pad - ky;
+      if (oy < 0 || oy >= a.Ho) continue;
+      for (int kx = 0; kx < a.ks; ++kx) {
+        const int ox = x + a.pad - kx;
+        if (ox < 0 || ox >= a.Wo) continue;
+        const float d = fd_cvt1<FmtG>(dn[(long long)oy * a.dy_sh + (long long)ox * a.dy_sw]);
+        const float* wt = wl + (ky * a.ks + kx) * cp + c32 * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c32 + q * C32 >= a.C8) break;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + q * C32 * 8), w1 = *reinterpret_cast<const f32x4*>(wt + q * C32 * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            da[q][e] = fmaf(d, w0[e], da[q][e]);
+            da[q][e + 4] = fmaf(d, w1[e], da[q][e + 4]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c8 = c32 + q * C32;
+      if (c8 >= a.C8) break;
+      const f32x8 fx = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(a.x + (long long)n * a.x_sn + (long long)y * a.x_sh + (long long)x * a.x_sw + c8 * 8));
+      unsigned short* gp = a.g + (long long)n * a.g_sn + (long long)y * a.g_sh + (long long)x * a.g_sw + c8 * 8;
+      f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[q][e] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
+      *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
+    }
+  }
+}
+
+}  // namespace
+
+// forward: Cout == 1 exactly, 4x4 (or 3x3) stride 1, NCHW fp32 output, no bias, no upsample
+bool conv_cout1_fits(const ConvArgs& a, int cout_total, int ksize, int stride, bool pool) {
+  return cout_total == 1 && a.Cout == 1 && (ksize == 4 || ksize == 3) && stride == 1 && !pool && a.out_nchw_f32 && a.bias == nullptr && !a.upsample &&
+         !a.grad_io && a.stats == nullptr && a.Cin % 8 == 0 && a.y_sw == 1 && FD_TUNE_GETENV("FDGAN_DEBUG_NO_C1") == nullptr;
+}
+
+int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* info, bool dry, hipStream_t stream) {
+  C1FwdArgs c{};
+  c.x = a.x, c.x_sn = a.x_sn, c.x_sh = a.x_sh, c.x_sw = a.x_sw, c.H = a.Hs, c.W = a.Ws, c.Cin = a.Cin, c.nchunk = a.nchunk;
+  c.w = a.w, c.pro_mode = a.pro_mode, c.slope = a.p_slope, c.eps = a.eps;
+  c.mean = a.p_mean, c.var = a.p_var, c.gamma = a.p_gamma, c.beta = a.p_beta;
+  c.y = static_cast<float*>(a.y), c.y_sn = a.y_sn, c.y_sh = a.y_sh, c.Ho = a.Ho, c.Wo = a.Wo, c.pad = a.pad, c.e_slope = a.e_slope;
+  c.tiles_x = (a.Wo + C1_TW - 1) / C1_TW, c.tiles_y = (a.Ho + C1_TH - 1) / C1_TH;
+  const int ih = C1_TH + ksize - 1, iw = C1_TW + ksize - 1, npixr = (ih * iw + 15) / 16 * 16;
+  const unsigned lds = 2u * 4 * npixr * 16 + 2u * ksize * ksize * 64 + a.nchunk * 32 * 8;
+  dim3 grid((unsigned)(nimg * c.tiles_x * c.tiles_y));
+  if (info) {
+    info->stats_rows = 0, info->stats_cpad = 0, info->grid_x = grid.x, info->grid_y = 1, info->lds_bytes = lds;
+  }
+  if (dry) return FD_OK;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (ksize == 4) return fd_launch(&conv_cout1_kernel<4>, "conv4x4_cout1", grid, dim3(256), lds, c, stream);
+  return fd_launch(&conv_cout1_kernel<3>, "conv3x3_cout1", grid, dim3(256), lds, c, stream);
+}
+
+// data gradient of a stride-1 conv with ONE forward filter behind an activation-only prologue: returns 1 when the shape is not this kernel's
+int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro, const FdTensor* dpre,
+                       int accumulate, const FdConvDesc* d, hipStream_t stream) {
+  const bool norm = fwd_pro && fwd_pro->mean;
+  const int pad_fwd = d->ksize - 1 - d->pad;
+  if (dy->c != 1 || norm || d->stride != 1 || d->ksize < 2 || d->ksize > 4 || pad_fwd < 0 || dpre->c % 8 != 0 ||
+      dpre->h != dy->h + d->ksize - 1 - 2 * pad_fwd || dpre->w != dy->w + d->ksize - 1 - 2 * pad_fwd || FD_TUNE_GETENV("FDGAN_DEBUG_NO_C1") != nullptr)
+    return 1;
+  const int act = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
+  C1BwdArgs c{};
+  c.dy = static_cast<const unsigned short*>(dy->ptr), c.dy_sn = dy->stride[0], c.dy_sh = (int)dy->stride[1], c.dy_sw = (int)dy->stride[2];
+  c.Ho = (int)dy->h, c.Wo = (int)dy->w;
+  c.w = static_cast<const unsigned short*>(w_packed_flipped);
+  c.x = static_cast<const unsigned short*>(fwd_x->ptr), c.x_sn = fwd_x->stride[0], c.x_sh = (int)fwd_x->stride[1], c.x_sw = (int)fwd_x->stride[2];
+  c.g = static_cast<unsigned short*>(dpre->ptr), c.g_sn = dpre->stride[0], c.g_sh = (int)dpre->stride[1], c.g_sw = (int)dpre->stride[2];
+  c.H = (int)dpre->h, c.W = (int)dpre->w, c.C = (int)dpre->c, c.C8 = (int)((dpre->c + 7) / 8), c.ks = d->ksize, c.pad = pad_fwd, c.acc = accumulate;
+  c.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
+  c.total = dpre->n * dpre->h * dpre->w * c.C8;
+  c.ntile = (int)((dpre->c + 15) / 16);
+  const unsigned lds = (unsigned)(d->ksize * d->ksize * c.C8 * 8 * 4);
+  if (lds > 64 * 1024) return 1;
+  const long long nb = (c.total / c.C8 * ((c.C8 + 3) / 4) + 255) / 256;
+  return fd_launch(&dgrad_cout1_kernel, "dgrad_cout1", dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, c, stream);
+}

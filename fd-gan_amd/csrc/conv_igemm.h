@@ -1001,6 +1001,11 @@ int conv_dispatch_k3_pw(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
                         hipStream_t stream);
 int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bool pool, FdConvInfo* info,
                      long long stats_cap, bool dry, hipStream_t stream);
+// the one-filter convolution that ends the discriminators, and its data gradient (conv_c1.hip)
+bool conv_cout1_fits(const ConvArgs& a, int cout_total, int ksize, int stride, bool pool);
+int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* info, bool dry, hipStream_t stream);
+int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro, const FdTensor* dpre,
+                       int accumulate, const FdConvDesc* d, hipStream_t stream);
 extern unsigned long long* g_fd_debug_timing;
 // tanh / sigmoid applied in place on what a conv stored (elementwise.hip)
 int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream);

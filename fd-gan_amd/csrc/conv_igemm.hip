@@ -26,6 +26,7 @@ static int conv_dispatch(ConvArgs& a, long long nimg, int cout_total, int ksize,
     return conv_dispatch_k1_xs(a, nimg, cout_total, pool, info, stats_cap, dry, stream);
   }
   if (w_layout != FD_WLAYOUT_CHUNK32) FD_FAIL(FD_EINVAL, "conv2d: unknown weight layout %d", w_layout);
+  if (conv_cout1_fits(a, cout_total, ksize, stride, pool)) return conv_cout1_launch(a, nimg, ksize, info, dry, stream);
   switch (ksize) {
     case 1: return conv_dispatch_k1(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
     case 3: return conv_dispatch_k3(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
@@ -253,6 +254,14 @@ extern "C" int fdgan_conv2d_bwd_data(const FdTensor* dy, const void* w_packed_fl
                "conv2d_bwd_data: fwd_x / dpre need 16-byte aligned pixel rows with the channels padded to a multiple of 8");
   const int act0 = fwd_pro ? fwd_pro->act : FD_ACT_NONE;
   FD_REQUIRE(act0 == FD_ACT_NONE || act0 == FD_ACT_RELU || act0 == FD_ACT_LEAKY02, "conv2d_bwd_data: prologue activation %d", act0);
+  {   // one forward filter behind an activation-only prologue (the discriminators' last conv): vector-ALU kernel, conv_c1.hip
+    const int rc1 = dgrad_cout1_launch(dy, w_packed_flipped, fwd_x, fwd_pro, dpre, accumulate, d, static_cast<hipStream_t>(stream));
+    if (rc1 != 1) {
+      if (rows_out) *rows_out = 0;
+      if (cpad_out) *cpad_out = 0;
+      return rc1;
+    }
+  }
   if (d->ksize == 1 && d->pad == 0 && dy->dtype == FD_BF16 && dy->n == dpre->n && dy->h == dpre->h && dy->w == dpre->w &&
       (d->cout <= 0 || d->cout == dpre->c) && conv1x1_bwd_fits(dy, fwd_x, dpre)) {
     FD_REQUIRE(!(fwd_pro && fwd_pro->mean) || (fwd_pro->var && partial), "conv2d_bwd_data: a BatchNorm prologue needs var and the partial-sum workspace");
