@@ -5,7 +5,7 @@ from fdgan_hip import engine as E
 
 def run(P_hw, C, Ct, N=16):
     dev = "cuda"
-    x = torch.randn(N, P_hw, P_hw, Ct, device=dev).bfloat16()
+    x = torch.randn(N, P_hw, P_hw, Ct, device=dev).half()
     d = torch.randn(N, P_hw, P_hw, Ct, device=dev).bfloat16()
     g = torch.zeros(N, P_hw, P_hw, Ct, device=dev).bfloat16()
     xv, dv, gv = E.View(x, 0, C), E.View(d, 0, C), E.View(g, 0, C)

@@ -7,7 +7,7 @@ ct = int(sys.argv[3]) if len(sys.argv) > 3 else c
 cy = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 ks = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 N, dev = 16, "cuda"
-x = torch.randn(N, hw, hw, ct, device=dev).bfloat16()
+x = torch.randn(N, hw, hw, ct, device=dev).half()
 G = torch.zeros(N, hw, hw, ct, device=dev).bfloat16()
 dy = torch.randn(N, hw, hw, cy, device=dev).bfloat16()
 w = torch.randn(cy, c, ks, ks, device=dev) * 0.05

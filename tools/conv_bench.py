@@ -29,8 +29,8 @@ def run(k, cin, cout, n, h, w, bn=False, relu=False, stats=False, pool=False, pi
     up = 2 if upsample else 1
     pitch_out = pitch_out or (cout + 7) // 8 * 8
     torch.manual_seed(1234)
-    x = (torch.randn(n, h, w, pitch_in, device=dev) * 0.7).to(torch.bfloat16)
-    y = torch.empty(n, ho * up, wo * up, pitch_out, dtype=torch.bfloat16, device=dev)
+    x = (torch.randn(n, h, w, pitch_in, device=dev) * 0.7).to(torch.float16)
+    y = torch.empty(n, ho * up, wo * up, pitch_out, dtype=torch.float16, device=dev)
     wt = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
     pw = E.PackedWeight(wt, cout, cin, k, layout=layout)
     pw.pack()

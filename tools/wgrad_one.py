@@ -7,7 +7,7 @@ ct = int(sys.argv[5]) if len(sys.argv) > 5 else cin
 N = 16
 dev = "cuda"
 torch.manual_seed(0)
-x = torch.randn(N, hw, hw, ct, device=dev).bfloat16()
+x = torch.randn(N, hw, hw, ct, device=dev).half()
 pad = ks // 2 if ks == 3 else (1 if ks == 4 else 0)
 ho = hw + 2 * pad - ks + 1
 dy = torch.randn(N, ho, ho, cout, device=dev).bfloat16()
