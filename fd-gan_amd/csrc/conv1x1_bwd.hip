@@ -382,7 +382,10 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   }
   // One step = one 64-pixel tile; the next tile's rows are requested right after the step's barrier.  (Requesting x / G TWO tiles
   // ahead in a third register set was tried in round 3: 76-368 B of scratch per lane whatever else was moved to LDS, and a
-  // scratch reload is a vmcnt(0): 2.4-3.6 TB/s instead of 4.1-5.6.)
+  // scratch reload is a vmcnt(0): 2.4-3.6 TB/s instead of 4.1-5.6.  Warming L2 two tiles ahead instead -- one dword per 128-byte
+  // line of the x / G rows, one register -- changed nothing, 4.60 against 4.72 TB/s over the 42 shapes: the kernel is not short of
+  // bytes in flight.  What the per-shape table does show: prefixes of C = 64 k channels stream at 4.9-6.0 TB/s, C = 64 k + 32 at
+  // 4.0-4.5 -- rows that end in half a 128-byte line -- against 6.1 TB/s for torch's own 2-read-1-write add on this board.)
   int d3 = 0;                                                  // tl mod 3
   auto step = [&](int tl, u32x4 (&xv)[2], u32x4 (&gv)[2], u32x4 (&xn)[2], u32x4 (&gn)[2], auto last) __attribute__((always_inline)) {
     const long long p0 = (long long)(slot + tl * nslots) * B1_PX;
