@@ -967,6 +967,18 @@ void fill_pro(const FdPrologue* pro, int& mode, float& slope, float& eps, const 
 extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
                                        float* dw, float* dbias, float* workspace, int64_t workspace_floats,
                                        int accumulate, FdStream stream) {
+  return fdgan_conv2d_bwd_weight_job(x, pro, dy, d, dw, dbias, workspace, workspace_floats, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int fdgan_wgrad_tr_reduce_batch(const FdTrReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream) {
+  FD_REQUIRE(jobs_device && njobs > 0 && njobs < (1 << 20) && total_groups > 0 && total_groups < (1ll << 31), "wgrad_tr_reduce_batch: empty job table");
+  return conv_wgrad_tr_reduce_batch(jobs_device, njobs, total_groups, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
+                                           float* dw, float* dbias, float* workspace, int64_t workspace_floats,
+                                           int accumulate, FdTrReduceJob* job, int defer, FdStream stream) {
+  if (job) *job = FdTrReduceJob{};
   if (int rc = check_view(x, "conv2d_bwd_weight(x)", FD_F16)) return rc;
   if (int rc = check_view(dy, "conv2d_bwd_weight(dy)")) return rc;
   FD_REQUIRE(d && dw, "conv2d_bwd_weight: NULL descriptor / dw");
@@ -1018,8 +1030,13 @@ extern "C" int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro,
     w.H = a.Hs, w.W = a.Ws, w.Cin = a.Cin, w.Cout = cout, w.Ho = a.Ho, w.Wo = a.Wo, w.pad = a.pad;
     w.pro_mode = a.pro_mode, w.p_slope = a.p_slope, w.eps = a.eps;
     w.p_mean = a.p_mean, w.p_var = a.p_var, w.p_gamma = a.p_gamma, w.p_beta = a.p_beta;
-    const int rc = conv_wgrad_tr_launch(trv, w, x->n, workspace, workspace_floats, dw, dbias, accumulate, static_cast<hipStream_t>(stream));
-    if (rc != 1) return rc;   // 1: workspace too small for this kernel's partials
+    const int rc = conv_wgrad_tr_launch(trv, w, x->n, workspace, workspace_floats, dw, dbias, accumulate, static_cast<hipStream_t>(stream),
+                                        job, defer);
+    if (rc != 1) {
+      if (job && dbias) job->part = nullptr;   // a bias gradient: nothing was deferred
+      return rc;
+    }
+    if (job) *job = FdTrReduceJob{};           // 1: workspace too small for this kernel's partials
   }
   // the dense-layer growth conv: all nine taps in one workgroup
   if (workspace != nullptr && dbias == nullptr && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !pool && cout <= 32 &&

@@ -993,7 +993,10 @@ int conv_wgrad_small_launch(const FdTensor* x, const FdTensor* dy, int cout, int
                             float* workspace, long long workspace_floats, long long* nsplit_out, hipStream_t stream);
 int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, bool pool);
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
-                         float* dbias, int accumulate, hipStream_t stream);
+                         float* dbias, int accumulate, hipStream_t stream, FdTrReduceJob* job = nullptr, int defer = 0);
+// job: filled with the description of the reduction over the kernel's partial sums; defer != 0 (and no dbias): that reduction is
+// NOT launched -- the caller runs a table of them later (conv_wgrad_tr_reduce_batch; jobs_device: the table in device memory)
+int conv_wgrad_tr_reduce_batch(const FdTrReduceJob* jobs_device, long long njobs, long long total_groups, hipStream_t stream);
 
 int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream);

@@ -775,16 +775,11 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) 
 
 // sum over items of the accumulator-order partials -> dw[co][ci][tap] (+= when accumulate): 64 partial-sum columns x 4
 // item lanes per workgroup, fixed summation order.  D layout of the MFMA: lane & 15 = cin, (lane >> 4) * 4 + r = cout.
-struct TrRedArgs {
-  const float* part;
-  float* out;
-  long long item_stride;   // floats per item = cin slices * z * NW * TAPS * 512
-  int items, zt, kyg, kyn, ks, nw, taps, Cin, Cout, accumulate;
-};
-__global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(TrRedArgs a) {
-  __shared__ float sh[4][64];
+// (TrRedArgs is the public FdTrReduceJob of include/fdgan_hip.h: a launcher asked to defer fills one instead of launching)
+typedef FdTrReduceJob TrRedArgs;
+__device__ __forceinline__ void tr_reduce_group(const TrRedArgs& a, long long group, float (&sh)[4][64]) {
   const int col = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long j = (long long)blockIdx.x * 64 + col;   // item_stride is a multiple of 64
+  const long long j = group * 64 + col;   // item_stride is a multiple of 64
   const float* src = a.part + j;
   float t = 0.f;
   int s_ = ty;
@@ -809,10 +804,33 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(TrRedArgs a) {
   const int z = (int)(q % a.zt), cslice = (int)(q / a.zt);
   const int co = (z / a.kyg) * 32 + ct * 16 + (lane >> 4) * 4 + r, ci = (cslice * a.nw + wave) * 16 + (lane & 15);
   const int tap = (z % a.kyg) * a.kyn * a.ks + tp;
-  if (co < a.Cout && ci < a.Cin) {
-    float* o = a.out + ((long long)co * a.Cin + ci) * (a.ks * a.ks) + tap;
+  if (co < a.cout && ci < a.cin) {
+    float* o = a.out + ((long long)co * a.cin + ci) * (a.ks * a.ks) + tap;
     *o = a.accumulate ? *o + t : t;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(TrRedArgs a) {
+  __shared__ float sh[4][64];
+  tr_reduce_group(a, blockIdx.x, sh);
+}
+// the same sums for a whole table of jobs (a backward walk's row-walking weight gradients): one launch instead of one per conv
+struct TrBatchArgs {
+  const TrRedArgs* jobs;
+  int njobs;
+};
+__global__ __launch_bounds__(256) void wgrad_tr_reduce_batch_kernel(TrBatchArgs b) {
+  __shared__ float sh[4][64];
+  __shared__ TrRedArgs job;
+  const TrRedArgs* jobs = b.jobs;
+  int lo = 0, hi = b.njobs - 1;                                 // last job whose first_group <= blockIdx.x (uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_group <= (long long)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  if (threadIdx.x == 0) job = jobs[lo];
+  __syncthreads();
+  tr_reduce_group(job, (long long)blockIdx.x - job.first_group, sh);
 }
 
 struct TrBiasRedArgs {
@@ -830,7 +848,7 @@ __global__ __launch_bounds__(64) void wgrad_tr_bias_reduce_kernel(TrBiasRedArgs 
 
 template <int KS, int KYN, int NW>
 int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, float* dbias, int accumulate,
-              hipStream_t stream, const char* name) {
+              hipStream_t stream, const char* name, FdTrReduceJob* job, int defer) {
   using C = G3Cfg<KS, KYN, NW>;
   a.xblocks = (a.Wo + G3_PB - 1) / G3_PB;
   const long long strips = nimg * a.xblocks, ci_tiles = (a.Cin + NW * 16 - 1) / (NW * 16), zt = (a.Cout + 31) / 32 * (KS / KYN);
@@ -867,8 +885,10 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   if (int rc = fd_launch(&conv_wgrad_tr_kernel<KS, KYN, NW>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(64 * NW),
                          C::LDS, a, stream))
     return rc;
-  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, KS / KYN, KYN, KS, NW, C::TAPS, a.Cin, a.Cout, accumulate};
-  if (int rc = fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream)) return rc;
+  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, KS / KYN, KYN, KS, NW, C::TAPS, a.Cin, a.Cout, accumulate, 0, item_stride / 64};
+  if (job) *job = r;
+  if (!(job && defer && !dbias))
+    if (int rc = fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream)) return rc;
   if (!dbias) return FD_OK;
   TrBiasRedArgs rb{a.bias_part, dbias, (int)items, (int)(ctiles * 32), a.Cout, accumulate};
   return fd_launch(&wgrad_tr_bias_reduce_kernel, "wgrad_tr_bias_reduce", dim3((unsigned)((a.Cout + 63) / 64)), dim3(64), 0, rb, stream);
@@ -876,7 +896,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
 
 template <bool RELU, int DBG = 0>
 int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, int accumulate, hipStream_t stream,
-              const char* name) {
+              const char* name, FdTrReduceJob* job = nullptr, int defer = 0) {
   a.xblocks = a.Wo / G3_PB;
   const long long strips = nimg * a.xblocks, ci_tiles = a.Cin / 128, zt = a.Cout / 32;
   const long long item_stride = ci_tiles * zt * 8 * 9 * 512;
@@ -902,13 +922,15 @@ int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   const long long items = strips * a.segs;
   if (int rc = fd_launch(&conv_wgrad_r3_kernel<RELU, DBG>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(512), R3_LDS, a, stream))
     return rc;
-  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 3, 3, 8, 9, a.Cin, a.Cout, accumulate};
+  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 3, 3, 8, 9, a.Cin, a.Cout, accumulate, 0, item_stride / 64};
+  if (job) *job = r;
+  if (job && defer) return FD_OK;
   return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
 }
 
 template <bool RELU>
 int r4_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, int accumulate, hipStream_t stream,
-              const char* name) {
+              const char* name, FdTrReduceJob* job = nullptr, int defer = 0) {
   a.xblocks = (a.Wo + R4_PX - 1) / R4_PX;
   const long long strips = nimg * a.xblocks, ci_tiles = a.Cin / 48, zt = a.Cout / 32;
   const long long item_stride = ci_tiles * zt * 3 * 16 * 512;
@@ -932,7 +954,9 @@ int r4_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   const long long items = strips * a.segs;
   if (int rc = fd_launch(&conv_wgrad_r4_kernel<RELU>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(192), R4_LDS, a, stream))
     return rc;
-  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 4, 4, 3, 16, a.Cin, a.Cout, accumulate};
+  TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 4, 4, 3, 16, a.Cin, a.Cout, accumulate, 0, item_stride / 64};
+  if (job) *job = r;
+  if (job && defer) return FD_OK;
   return fd_launch(&wgrad_tr_reduce_kernel, "wgrad_tr_reduce", dim3((unsigned)(item_stride / 64)), dim3(256), 0, r, stream);
 }
 
@@ -961,7 +985,7 @@ int conv_wgrad_tr_variant(int cout, int cin, int ksize, int stride, int pad, boo
 /* Weight gradient into dw (+= when accumulate) through `workspace`.  Returns 1 (nothing launched) when the workspace
  * cannot hold one partial per (image, column block): the caller uses the per-tap kernel then. */
 int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw,
-                         float* dbias, int accumulate, hipStream_t stream) {
+                         float* dbias, int accumulate, hipStream_t stream, FdTrReduceJob* job, int defer) {
   switch (variant) {
     case 8: {
       static const char* r3 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R3");   // tuning aid: '0' first-generation kernel
@@ -983,23 +1007,28 @@ int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* w
           }
         }
 #endif
-        if (a.pro_mode != 0 && a.p_slope == 0.f) return r3_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3");
-        return r3_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_leaky");
+        if (a.pro_mode != 0 && a.p_slope == 0.f) return r3_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3", job, defer);
+        return r3_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_leaky", job, defer);
       }
-      return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8");
+      return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8", job, defer);
     }
-    case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5");
-    case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3");
+    case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5", job, defer);
+    case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3", job, defer);
     case 9: {
       static const char* r4 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R4");   // tuning aid: '0' first-generation kernel
       if (dbias == nullptr && a.Cin % 48 == 0 && a.Cout % 32 == 0 && a.pad == 1 && a.Wo == a.W - 1 && a.Ho == a.H - 1 && !(r4 && r4[0] == '0')) {
         int rc;
-        if (a.pro_mode != 0 && a.p_slope == 0.f) rc = r4_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4");
-        else rc = r4_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4");
+        if (a.pro_mode != 0 && a.p_slope == 0.f) rc = r4_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4", job, defer);
+        else rc = r4_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad4x4_r4", job, defer);
         if (rc != 1) return rc;      // 1: the workspace cannot hold this kernel's partials -- the first-generation kernel may still fit
       }
-      return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr");
+      return g3_launch<4, 2, 9>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad4x4_tr", job, defer);
     }
   }
   FD_FAIL(FD_EINVAL, "conv_wgrad_tr_launch: variant %d", variant);
+}
+
+int conv_wgrad_tr_reduce_batch(const FdTrReduceJob* jobs_device, long long njobs, long long total_groups, hipStream_t stream) {
+  TrBatchArgs b{jobs_device, (int)njobs};
+  return fd_launch(&wgrad_tr_reduce_batch_kernel, "wgrad_tr_reduce_batch", dim3((unsigned)total_groups), dim3(256), 0, b, stream);
 }

@@ -52,6 +52,7 @@ IN_PLACE = _InPlace()
 
 # Called as PROGRESS_HOOK(plan_backward, record_index) after each record of a reverse walk is done: the optimizer's
 # gradient all-reduce rides on it (optim.FlatAdam.overlap), so RCCL runs while the rest of the backward computes.
+TR_DEFER_MAX = 1 << 24      # floats (64 MiB) of partial sums a record may keep private for the batched reduce
 PROGRESS_HOOK = None
 
 
@@ -139,7 +140,7 @@ class PlanBackward:
         # before a gradient slice is handed to the all-reduce).  At 64 x 64 and below, where every kernel of a dense layer is
         # launch-sized, this takes two launches per layer out of the serial chain.
         self.offload_wgrad = os.environ.get("FDGAN_NO_WGRAD_STREAM") is None and dev.type == "cuda" and not self.recompute
-        self.wstream = torch.cuda.Stream(device=dev) if self.offload_wgrad else None
+        self.wstream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("FDGAN_WGRAD_STREAM_PRIORITY", "0"))) if self.offload_wgrad else None
         self.ws_w = torch.empty(1 << 26, dtype=torch.float32, device=dev) if self.offload_wgrad else None
         self._w_pending = False
         # The fused bottleneck kernel's weight-gradient partials ([pixel slots][128][C] per dense layer) are summed by ONE
@@ -153,6 +154,14 @@ class PlanBackward:
         self.wparts = {}            # record index -> (private partial buffer, nsplit of its last launch)
         self.reduce_jobs = []
         self.reduce_table = None
+        # The same for the row-walking weight-gradient kernels on the side stream (the growth convs' 3x3, the discriminators' 3x3 /
+        # 4x4): 256 partial blocks of 147 KB per growth conv, whose 40 MB reduction was one more launch per layer.  Records
+        # whose partials fit TR_DEFER_MAX floats keep them in a private buffer; one launch on the side stream sums them all.
+        self._tr_seen = {}          # record index -> floats of partials (first walk)
+        self._tr_deferred = frozenset()
+        self.tr_parts = {}          # record index -> private partial buffer
+        self.tr_jobs = []
+        self.tr_table = None
         self.walks_done = 0
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
@@ -219,7 +228,7 @@ class PlanBackward:
 
     def deferred_records(self):
         """Records whose weight gradient leaves through the batched reduce at the end of the walk."""
-        return self._deferred_idx if self._deferred_idx is not None else frozenset()
+        return (self._deferred_idx | self._tr_deferred) if self._deferred_idx is not None else frozenset()
 
     def num_progress_records(self):
         """PROGRESS_HOOK is called with 0 .. len(recs): the last index is the pseudo-record of the batched reduce."""
@@ -310,8 +319,18 @@ class PlanBackward:
                 if side:
                     main = torch.cuda.current_stream(p.device)
                     self.wstream.wait_stream(main)            # dy is final (flushed) on the walk's stream
+                    idx = r.get("_idx")
                     with torch.cuda.stream(self.wstream):
-                        E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, dw_t, db, self.ws_w, True)
+                        if db is not None or idx is None or not self.defer_reduce:
+                            E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, dw_t, db, self.ws_w, True)
+                        elif idx in self._tr_deferred:      # partial sums stay in the record's own buffer until the batched launch
+                            job = E.conv_bwd_weight_job(x.fd, pro, dy_view.fd, desc, dw_t, self.tr_parts[idx], True, True)
+                            assert job is not None, "a deferred weight-gradient reduction changed kernels between walks"
+                            self.tr_jobs.append(job)
+                        else:
+                            job = E.conv_bwd_weight_job(x.fd, pro, dy_view.fd, desc, dw_t, self.ws_w, False, True)
+                            if job is not None and self._deferred_idx is None:
+                                self._tr_seen[idx] = job.items * job.item_stride
                     self._w_pending = True
                     if os.environ.get("FDGAN_WGRAD_SERIAL") is not None:      # debug aid: side stream, but no concurrency
                         self.join_side()
@@ -522,6 +541,7 @@ class PlanBackward:
         """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's
         outputs.  `grads`: dict parameter -> fp32 gradient, filled / accumulated."""
         self.reduce_jobs = []
+        self.tr_jobs = []
         for i in range(len(self.recs) - 1, -1, -1):
             r = self.recs[i]
             r["_idx"] = i
@@ -564,8 +584,19 @@ class PlanBackward:
             if self.reduce_table is None or self.reduce_table.key != key:
                 self.reduce_table = E.ReduceTable(self.reduce_jobs, self.plan.device)
             self.reduce_table.launch()
+        if self.tr_jobs:      # the side stream's weight gradients: their partial sums, one launch (on that stream, behind them)
+            key = tuple((j.part, j.out, j.item_stride, j.items, j.accumulate) for j in self.tr_jobs)
+            if self.tr_table is None or self.tr_table.key != key:
+                self.tr_table = E.TrReduceTable(self.tr_jobs, list(self.tr_parts.values()), self.plan.device)
+            with torch.cuda.stream(self.wstream):
+                self.tr_table.launch()
+            self._w_pending = True
         if self._deferred_idx is None and self.checks is None:
             self._deferred_idx = frozenset(self._fused_seen) if self.defer_reduce else frozenset()
+            if self.defer_reduce:
+                self._tr_deferred = frozenset(i for i, n in self._tr_seen.items() if n <= TR_DEFER_MAX)
+                for i in self._tr_deferred:
+                    self.tr_parts[i] = torch.empty(self._tr_seen[i], dtype=torch.float32, device=self.plan.device)
         self.walks_done += 1
         if PROGRESS_HOOK is not None:
             PROGRESS_HOOK(self, len(self.recs))

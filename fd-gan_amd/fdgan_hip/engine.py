@@ -382,6 +382,36 @@ def conv_bwd_weight(x_fd, pro, dy_fd, desc, dw, dbias=None, ws=None, accumulate=
                                              int(bool(accumulate)), stream_ptr()), "conv2d_bwd_weight")
 
 
+def conv_bwd_weight_job(x_fd, pro, dy_fd, desc, dw, ws, defer, accumulate=False):
+    """conv_bwd_weight that also returns the description (lib.FdTrReduceJob) of the kernel's final reduction over the partial sums
+    in `ws`, or None when the kernel chosen for the shape has none; defer: do not launch that reduction (TrReduceTable does)."""
+    job = L.FdTrReduceJob()
+    L.check(L.load().fdgan_conv2d_bwd_weight_job(C.byref(x_fd), C.byref(pro) if pro is not None else None, C.byref(dy_fd),
+                                                 C.byref(desc), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), int(bool(accumulate)),
+                                                 C.byref(job), int(bool(defer)), stream_ptr()), "conv2d_bwd_weight_job")
+    return job if job.part else None
+
+
+class TrReduceTable:
+    """The deferred reductions of a backward walk's row-walking weight gradients as ONE launch (fdgan_wgrad_tr_reduce_batch).
+    jobs: the lib.FdTrReduceJob structures conv_bwd_weight_job(defer=True) returned; keep: the tensors they point into."""
+
+    def __init__(self, jobs, keep, device):
+        self.keep, self.n = list(keep), len(jobs)
+        tab = (L.FdTrReduceJob * len(jobs))()
+        first = 0
+        for t, j in zip(tab, jobs):
+            C.memmove(C.byref(t), C.byref(j), C.sizeof(L.FdTrReduceJob))
+            t.first_group = first
+            first += j.groups
+        self.groups = first
+        self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
+        self.key = tuple((j.part, j.out, j.item_stride, j.items, j.accumulate) for j in jobs)
+
+    def launch(self):
+        L.check(L.load().fdgan_wgrad_tr_reduce_batch(self.table.data_ptr(), self.n, self.groups, stream_ptr()), "wgrad_tr_reduce_batch")
+
+
 def bn_act_bwd(da_fd, x_fd, pro, ws=None):
     """In place: da <- da * act'(bn(x)).  With a norm in `pro`, also fills `ws` with the partial sums and
     returns (rows, cpad) for bn_bwd_finalize."""

@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class FdganLibraryError(RuntimeError):
@@ -43,6 +43,12 @@ class FdPackJob(C.Structure):
 class FdReduceJob(C.Structure):
     _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("numel", C.c_int64), ("nsplit", C.c_int32), ("accumulate", C.c_int32),
                 ("first_group", C.c_int64)]
+
+
+class FdTrReduceJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("item_stride", C.c_int64), ("items", C.c_int32), ("zt", C.c_int32),
+                ("kyg", C.c_int32), ("kyn", C.c_int32), ("ks", C.c_int32), ("nw", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("accumulate", C.c_int32), ("first_group", C.c_int64), ("groups", C.c_int64)]
 
 
 class FdConvDesc(C.Structure):
@@ -147,6 +153,10 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(FdTensor), C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_wgrad_reduce_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_conv2d_bwd_weight_job": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor),
+                                              C.POINTER(FdConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                              C.POINTER(FdTrReduceJob), C.c_int, C.c_void_p]),
+    "fdgan_wgrad_tr_reduce_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_bn_bwd_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FdPrologue), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fdgan_affine_accumulate": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 8
+#define FDGAN_ABI_VERSION 9
 
 enum FdStatus {
   FD_OK = 0,
@@ -379,6 +379,26 @@ typedef struct FdReduceJob {
   int64_t first_group;
 } FdReduceJob;
 int fdgan_wgrad_reduce_batch(const FdReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream);
+/* The same for the row-walking weight-gradient kernels (3x3 / 4x4 stride 1: the growth conv, the dy blocks, the discriminators),
+ * whose partial sums are kept in MFMA accumulator order: fdgan_conv2d_bwd_weight_job is fdgan_conv2d_bwd_weight that also
+ * DESCRIBES its final reduction in *job (job->part == NULL when the kernel chosen for the shape has no such reduction, or
+ * produces a bias gradient: then everything has been launched as usual) and, with defer != 0, does not launch it: `workspace`
+ * then holds the partial sums until the caller has run fdgan_wgrad_tr_reduce_batch over a device table of such jobs
+ * (first_group = running sum of `groups` over the preceding jobs; everything else as the library filled it).  Same summation
+ * order as the per-conv launch: bitwise the same gradients.  Replaces, per training step, 55 reduction launches by one
+ * (torch.autograd's per-conv weight gradients at /root/reference/models/dehaze1113.py:711-724, :200-207). */
+typedef struct FdTrReduceJob {
+  const float* part;
+  float* out;
+  int64_t item_stride;
+  int32_t items, zt, kyg, kyn, ks, nw, taps, cin, cout, accumulate;
+  int64_t first_group;
+  int64_t groups;
+} FdTrReduceJob;
+int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
+                                float* dw, float* dbias, float* workspace, int64_t workspace_floats, int accumulate,
+                                FdTrReduceJob* job, int defer, FdStream stream);
+int fdgan_wgrad_tr_reduce_batch(const FdTrReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream);
 
 /* dx += bsum[c] * x + csum[c] (x: NHWC fp16 activation, dx: NHWC bf16 gradient of equal shape). */
 int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
