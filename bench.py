@@ -267,6 +267,7 @@ def train_bench(a, dp, dev, B, S):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         last_dev = ts.step(haze, gt, sync=False)   # the losses stay on the device: no host round trip inside the timed region
+    t_enq = time.perf_counter() - t0               # host time to ENQUEUE the steps: close to the total = the host is the limit
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0             # this rank alone (before the closing barrier)
     dp.barrier()
@@ -354,6 +355,7 @@ def train_bench(a, dp, dev, B, S):
                                       % (2 if world == 1 else 3, B, S, S),
                           "global_batch": world * B, "image": [3, S, S], "parallelism": "dp%d" % world,
                           "library_launches_per_step": n_launch, "library_gpu_ms_per_step_instrumented": round(lib_ms, 2),
+                          "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 3),
                           "gradient_exchange": comm,
                           "last_losses": {k: round(v, 4) for k, v in last.items()}},
                "roofline": roof, "step_roofline": step_roof, "cpu_baseline": None}
