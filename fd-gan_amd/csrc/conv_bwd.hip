@@ -910,7 +910,7 @@ struct GradEwArgs {
   unsigned short* dst;
   long long s_sn, r_sn, d_sn;
   int s_sh, s_sw, r_sh, r_sw, d_sh, d_sw;
-  int N, H, W, C8, mode;   // H, W: dst size
+  int N, H, W, C8, mode, C;   // H, W: dst size; C: channels of the view
 };
 __global__ __launch_bounds__(256) void grad_ew_kernel(GradEwArgs a) {
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -936,8 +936,9 @@ __global__ __launch_bounds__(256) void grad_ew_kernel(GradEwArgs a) {
   } else {
     const f32x8 s_ = ld(a.src, a.s_sn, a.s_sh, a.s_sw, y, x);
     const f32x8 rf = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(a.ref + n * a.r_sn + (long long)y * a.r_sh + (long long)x * a.r_sw + c8 * 8));   // a stored activation: fp16
+    const float neg = a.mode == 4 ? 0.2f : 0.f;       // 3: ReLU epilogue, 4: LeakyReLU(0.2) epilogue (sign(out) == sign(pre-activation))
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = rf[e] > 0.f ? s_[e] : 0.f;
+    for (int e = 0; e < 8; ++e) o[e] = (c8 * 8 + e >= a.C || rf[e] > 0.f) ? s_[e] : neg * s_[e];   // channels past C: untouched
   }
   *reinterpret_cast<u32x4*>(dp) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
 }
@@ -1391,15 +1392,15 @@ extern "C" int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n,
 extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref, const FdTensor* dst, FdStream stream) {
   if (int rc = check_view(src, "grad_ew(src)")) return rc;
   if (int rc = check_view(dst, "grad_ew(dst)")) return rc;
-  FD_REQUIRE(mode >= 0 && mode <= 3, "grad_ew: mode %d", mode);
+  FD_REQUIRE(mode >= 0 && mode <= 4, "grad_ew: mode %d", mode);
   FD_REQUIRE(src->n == dst->n && src->c == dst->c, "grad_ew: batch / channel mismatch");
-  if (mode == 0 || mode == 3) FD_REQUIRE(src->h == dst->h && src->w == dst->w, "grad_ew: shape mismatch");
+  if (mode == 0 || mode >= 3) FD_REQUIRE(src->h == dst->h && src->w == dst->w, "grad_ew: shape mismatch");
   if (mode == 1) FD_REQUIRE(src->h == dst->h / 2 && src->w == dst->w / 2, "grad_ew(unpool): src must be half of dst");
   if (mode == 2) FD_REQUIRE(src->h == dst->h * 2 && src->w == dst->w * 2, "grad_ew(sum-pool): src must be twice dst");
   GradEwArgs a{};
   a.src = static_cast<const unsigned short*>(src->ptr);
   a.s_sn = src->stride[0], a.s_sh = (int)src->stride[1], a.s_sw = (int)src->stride[2];
-  if (mode == 3) {
+  if (mode >= 3) {
     if (int rc = check_view(ref, "grad_ew(ref)", FD_F16)) return rc;
     FD_REQUIRE(ref->n == dst->n && ref->h == dst->h && ref->w == dst->w && ref->c == dst->c, "grad_ew: ref shape mismatch");
     a.ref = static_cast<const unsigned short*>(ref->ptr);
@@ -1407,7 +1408,7 @@ extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref,
   }
   a.dst = static_cast<unsigned short*>(dst->ptr);
   a.d_sn = dst->stride[0], a.d_sh = (int)dst->stride[1], a.d_sw = (int)dst->stride[2];
-  a.N = (int)dst->n, a.H = (int)dst->h, a.W = (int)dst->w, a.C8 = (int)((dst->c + 7) / 8), a.mode = mode;
+  a.N = (int)dst->n, a.H = (int)dst->h, a.W = (int)dst->w, a.C8 = (int)((dst->c + 7) / 8), a.mode = mode, a.C = (int)dst->c;
   const long long total = (long long)a.N * a.H * a.W * a.C8;
   return fd_launch(&grad_ew_kernel, "grad_ew", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));

@@ -258,7 +258,10 @@ class PlanBackward:
             self._w_pending = False
 
     def G(self, view):
-        return E.View(self.gbuf[view.buf.data_ptr()], view.c0, view.c)
+        g = self.gbuf[view.buf.data_ptr()]
+        if isinstance(view, E.StridedView):      # one parity of a transposed conv's output: the same pixels of the gradient buffer
+            return E.StridedView(g, view.c0, view.c, *view.geom)
+        return E.View(g, view.c0, view.c)
 
     def zero_(self):
         skip = self.nozero if self.checks is None else ()
@@ -426,6 +429,8 @@ class PlanBackward:
                                        d["coef"][1, x.c0:x.c0 + cin],
                                        sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                                        sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
+                for lo, hi in meta.get("identity", ()):      # table entries that are constants, not batch statistics: no
+                    d["coef"][:, x.c0 + lo:x.c0 + hi].zero_()  # correction terms (finished values behind a BatchNorm + Dropout2d pass)
                 d["dirty"].update(range(x.c0, x.c0 + cin))
             if check:
                 self.flush(x)
@@ -528,6 +533,9 @@ class PlanBackward:
             else:
                 rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
                 E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, **sinks)
+            for lo, hi in meta.get("identity", ()):      # constants, not batch statistics (see conv_backward): dx = A * dpre there
+                dg[lo:hi].zero_()
+                dbt[lo:hi].zero_()
             E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
         else:
             if meta["act"] != L.ACT_NONE and masked is None:
@@ -535,6 +543,30 @@ class PlanBackward:
             E.grad_ew(E.GRAD_ADD, Tv, gx)
         if check:
             self._finish_check(rec, x, gx_before, dx_ref)
+
+    # ---- the legacy networks' ops ---------------------------------------------------------------
+    def _legacy_backward(self, r, grads):
+        src, dst = r["src"], r["dst"]
+        gs, gd = self.G(src), self.G(dst)
+        if r["kind"] == "pyramid":        # four-scale head: G[x] += ..., the four 1x1 filters' gradients to their owner
+            dw, db = E.pyramid_pool4_bwd(src, r["w"], r["b"], r["k0"], r["slope"], gd, gs)
+            r["sink"](grads, dw, db)
+        elif r["kind"] == "bn_dropout":   # y = mask * bn(raw): the raw tensor has this one consumer, its gradient is stored
+            dg, db = E.bn_dropout_bwd(src, r["mean"], r["var"], r["gamma"], r["eps"], r["mask"], gd, gs)
+            bn = r["bn"]
+            if bn is not None and bn.weight is not None and bn.weight.requires_grad:
+                grad_target(grads, bn.weight).add_(dg)
+                grad_target(grads, bn.bias).add_(db)
+        else:                             # MaxPool2d(3, 2, 1)(relu(bn(x))): route, then the prologue's backward in place
+            pro, bn = r["pro"], r["bn"]
+            E.maxpool3s2_bwd(src, pro, gd, gs)
+            rows, cpad = E.bn_act_bwd(gs.fd, src.fd, pro, self.ws_bn)
+            dg = torch.empty(src.c, dtype=torch.float32, device=src.buf.device)
+            dbt = torch.empty(src.c, dtype=torch.float32, device=src.buf.device)
+            train_bn = bn.weight is not None and bn.weight.requires_grad
+            E.bn_bwd_finalize(self.ws_bn, rows, cpad, src.c, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
+                              sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            E.bn_bwd_apply(gs.fd, src.fd, pro, dg, dbt, gs.fd, accumulate=False)
 
     # ---- the whole plan ------------------------------------------------------------------------
     def run(self, grads, skip_dx_of=()):
@@ -553,10 +585,21 @@ class PlanBackward:
                 self.flush(r["dst"])
                 E.maxpool2_bwd(r["src"], self.G(r["dst"]), self.G(r["src"]))
                 continue
+            if r["kind"] in ("pyramid", "bn_dropout", "maxpool3"):      # the legacy DCPDN networks' own ops (csrc/legacy_bwd.hip)
+                self.flush(r["dst"])
+                self._legacy_backward(r, grads)
+                if PROGRESS_HOOK is not None:
+                    PROGRESS_HOOK(self, i)
+                continue
             if i in self.recompute:
                 self.recs[self.recompute[i]]["rerun"]()
             y = r["y"]
             need_dx = id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of
+            if y is None:      # a conv that stores a network output (NCHW fp32): the caller seeded its gradient (`_dy`, already
+                self.conv_backward(r, r["_dy"], grads, need_dx=need_dx)      # through the output activation's derivative)
+                if PROGRESS_HOOK is not None:
+                    PROGRESS_HOOK(self, i)
+                continue
             pending = self._pending_for_fused(r, need_dx)
             if pending is None:
                 self.flush(y)
@@ -571,6 +614,8 @@ class PlanBackward:
             if r["e_act"] == L.ACT_RELU:
                 if not self.relu_premask:
                     E.grad_ew(E.GRAD_RELU_MASK, dyv, dyv, ref=y)
+            elif r["e_act"] == L.ACT_LEAKY02:
+                E.grad_ew(E.GRAD_LEAKY_MASK, dyv, dyv, ref=y)
             elif r["e_act"] != L.ACT_NONE:
                 raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
             self.conv_backward(r, dyv, grads, need_dx=need_dx, dy_pending=pending)

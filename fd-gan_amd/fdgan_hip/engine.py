@@ -161,7 +161,7 @@ def prologue_without_side_effects(pro):
     m = pro._meta
     q = make_prologue(act=m["act"], pool=m["pool"], mean=m["mean"], var=m["var"], gamma=m["gamma"], beta=m["beta"],
                       eps=m["eps"])
-    q._meta.update(bn=m["bn"], stats=m["stats"], batch_stats=m.get("batch_stats", False))
+    q._meta.update(bn=m["bn"], stats=m["stats"], batch_stats=m.get("batch_stats", False), identity=m.get("identity", ()))
     return q
 
 
@@ -289,16 +289,64 @@ def bn_dropout(x, mean, var, gamma, beta, eps, mask, y):
                                            C.byref(y.fd), stream_ptr()), "bn_dropout_nhwc")
 
 
+def maxpool3s2_bwd(x, pro, dy, da):
+    """da (written) = gradient w.r.t. act(bn(x)) of MaxPool2d(3, 2, 1): dy routed to each window's first maximum."""
+    L.check(L.load().fdgan_maxpool3s2_bwd(C.byref(x.fd), C.byref(pro) if pro is not None else None, C.byref(dy.fd), C.byref(da.fd), stream_ptr()),
+            "maxpool3s2_bwd")
+
+
+def pyramid_pool4_bwd(x, weight, bias, k0, slope, dy, dx):
+    """dx += the head's input gradient; returns (dweight (4, C), dbias (4,)) fp32."""
+    n, h, w, c = x.shape
+    tiles = n * (h // k0) * (w // k0)
+    dwp = torch.empty((tiles, 4, c), dtype=torch.float32, device=x.buf.device)
+    dbp = torch.empty((tiles, 4), dtype=torch.float32, device=x.buf.device)
+    t = C.c_int64(0)
+    L.check(L.load().fdgan_pyramid_pool4_bwd(C.byref(x.fd), weight.data_ptr(), bias.data_ptr(), int(k0), float(slope), C.byref(dy.fd), C.byref(dx.fd),
+                                             dwp.data_ptr(), dbp.data_ptr(), C.byref(t), stream_ptr()), "pyramid_pool4_bwd")
+    assert t.value == tiles
+    return dwp.sum(0), dbp.sum(0)
+
+
+def bn_dropout_bwd(x, mean, var, gamma, eps, mask, dy, dx):
+    """Backward of y = mask * bn(x) (batch statistics): dx written; returns (dgamma, dbeta) or (None, None) without a norm."""
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    dg = db = None
+    if mean is not None:
+        dg = torch.empty(x.c, dtype=torch.float32, device=x.buf.device)
+        db = torch.empty(x.c, dtype=torch.float32, device=x.buf.device)
+    L.check(L.load().fdgan_bn_dropout_bwd(C.byref(x.fd), ptr(mean), ptr(var), ptr(gamma), float(eps), ptr(mask), C.byref(dy.fd), C.byref(dx.fd),
+                                          ptr(dg), ptr(db), stream_ptr()), "bn_dropout_bwd")
+    return dg, db
+
+
+def scatter_dehaze_bwd(x, tran, atp, window_mean, slope, eps, g_dehaze2, g_atp, g_cat):
+    """Gradients (d_tran, d_atp), both (N, 3, H, W) fp32, of dehaze22.py:699-715; g_dehaze2 / g_atp: fp32 NCHW or None, g_cat:
+    gradient View of the refine input (its channels 0-2 are J's) or None."""
+    n, _, h, w = x.shape
+    d_tran, d_atp = torch.empty_like(tran), torch.empty_like(atp)
+    scratch = torch.empty(n * 3 * max(w // h, 1) * h, dtype=torch.float32, device=x.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for t in (g_dehaze2, g_atp):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (n, 3, h, w))
+    L.check(L.load().fdgan_scatter_dehaze_bwd(x.data_ptr(), tran.data_ptr(), atp.data_ptr(), window_mean.data_ptr(), n, h, w, float(slope),
+                                              float(eps), ptr(g_dehaze2), ptr(g_atp), C.byref(g_cat.fd) if g_cat is not None else None,
+                                              d_tran.data_ptr(), d_atp.data_ptr(), scratch.data_ptr(), scratch.numel(), stream_ptr()),
+            "scatter_dehaze_bwd")
+    return d_tran, d_atp
+
+
 class StridedView:
     """An NHWC 16-bit view that steps over rows and pixels of its buffer: channels [c0, c0 + c) of the pixels
     (y0 + sy i, x0 + sx j), i < h, j < w -- the output positions of one parity of a stride-2 transposed convolution."""
-    __slots__ = ("buf", "c0", "c", "fd")
+    __slots__ = ("buf", "c0", "c", "fd", "geom")
 
     def __init__(self, buf, c0, c, y0, x0, sy, sx, h, w):
         assert buf.dtype in _FD_DTYPE and buf.dim() == 4 and buf.is_contiguous()
         n, hh, ww, ctot = buf.shape
         assert y0 + sy * (h - 1) < hh and x0 + sx * (w - 1) < ww and c0 + c <= ctot
         self.buf, self.c0, self.c = buf, c0, c
+        self.geom = (y0, x0, sy, sx, h, w)
         t = L.FdTensor()
         t.ptr = buf.data_ptr() + 2 * ((y0 * ww + x0) * ctot + c0)
         t.n, t.h, t.w, t.c = n, h, w, c
@@ -309,6 +357,11 @@ class StridedView:
     @property
     def shape(self):
         return self.fd.n, self.fd.h, self.fd.w, self.c
+
+    def torch_nchw(self):
+        """fp32 NCHW copy (debug / tests)."""
+        y0, x0, sy, sx, h, w = self.geom
+        return self.buf[:, y0:y0 + sy * h:sy, x0:x0 + sx * w:sx, self.c0:self.c0 + self.c].permute(0, 3, 1, 2).float().contiguous()
 
 
 class Plan:
@@ -546,7 +599,7 @@ def out_act_bwd(dout, out, act, g_view):
             "out_act_bwd")
 
 
-GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK = 0, 1, 2, 3
+GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK, GRAD_LEAKY_MASK = 0, 1, 2, 3, 4
 
 
 def grad_ew(mode, src, dst, ref=None):

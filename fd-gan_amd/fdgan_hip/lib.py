@@ -94,6 +94,13 @@ SIGNATURES = {
     "fdgan_pyramid_pool4": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_bn_dropout_nhwc": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                               C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_maxpool3s2_bwd": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_pyramid_pool4_bwd": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.POINTER(FdTensor),
+                                          C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_bn_dropout_bwd": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.POINTER(FdTensor),
+                                       C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdgan_scatter_dehaze_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "fdgan_plan_create": (C.c_void_p, []),
     "fdgan_plan_destroy": (None, [C.c_void_p]),
     "fdgan_plan_begin": (C.c_int, [C.c_void_p]),

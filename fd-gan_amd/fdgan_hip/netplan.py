@@ -134,8 +134,12 @@ class NetPlan:
         self.keep += [src, dst]
         self.records.append(dict(kind="maxpool", src=src, dst=dst))
 
-    def op(self, fn):
-        self._ops.append((fn, 0, dict(label="op", flops=0.0, flops_done=0.0, bytes=0)))
+    def op(self, fn, record=None, need=0):
+        """An arbitrary launch sequence.  record: what the reverse walk needs to know about it (fdgan_hip/backward.py: kinds
+        "pyramid", "bn_dropout", "maxpool3" with `src` / `dst` views); need: floats of the shared workspace it uses."""
+        self._ops.append((fn, need, dict(label="op", flops=0.0, flops_done=0.0, bytes=0)))
+        if record is not None:
+            self.records.append(record)
 
     # ---- build / run ------------------------------------------------------------------
     def finish(self):

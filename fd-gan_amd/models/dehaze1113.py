@@ -19,6 +19,7 @@ from fdgan_hip.backward import PlanBackward, autograd_grads
 from fdgan_hip.netplan import ChanStats, NetPlan, bn_flags
 
 from . import tv_densenet121 as _tv
+from fdgan_hip.backward import grad_target
 
 
 class _PlannedModule(nn.Module):
@@ -544,6 +545,7 @@ class _DenseBase(_PlannedModule):
         P.xs = A(h2 + 3, w2 + 3, 16, zero=True)
         P.xs_in = E.StridedView(P.xs, 0, 16, 2, 2, 1, 1, h2, w2)
         P.w0 = torch.zeros((64, 16, 4, 4), dtype=torch.float32, device=dev)
+        P.w0.requires_grad_(self.conv0.weight.requires_grad)      # a derived filter: its gradient is mapped back to conv0's (`_derived_grads`)
         c0 = A(h2, w2, 64)
         st0 = ChanStats(64, dev)
         P.conv(E.View(P.xs), P.weight(P.w0, 64, 16, 4), E.View(c0), 4, pad=0, stats=st0 if train else None, label="conv0")
@@ -558,6 +560,7 @@ class _DenseBase(_PlannedModule):
         P._ops.append((lambda: (E.maxpool3s2(E.View(c0), pro0, x0, P.ws if train else None),
                                 E.bn_finalize(P.ws, pool_info, 64, n * h4 * w4, st1.mean, st1.var, 0) if train else None),
                        pool_rows * 64 * 2 if train else 0, dict(label="pool0", flops=0.0, flops_done=0.0, bytes=n * h2 * w2 * 64 * 2 * 5 // 4)))
+        P.records.append(dict(kind="maxpool3", src=E.View(c0), dst=x0, pro=pro0, bn=self.norm0))
         P.st0, P.cnt0 = st0, n * h2 * w2
         # ---- encoder
         blk2, bott2 = A(h8, w8, 512), A(h8, w8, 128)
@@ -603,8 +606,46 @@ class _DenseBase(_PlannedModule):
 
     def forward(self, x):
         if _wants_grad(self, x):
-            raise NotImplementedError("models.%s runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): call it "
-                                      "under torch.no_grad()" % type(self).__name__)
+            if x.requires_grad:
+                raise NotImplementedError("models.%s: the gradient w.r.t. the input image is not produced on the HIP path" % type(self).__name__)
+            return _apply_plan_function(self, x)
+        return self._forward_plan(x)[1]
+
+    def _autograd_forward(self, x):
+        P, out = self._forward_plan(x)
+        return out, (P, out)
+
+    def _autograd_backward(self, state, dout):
+        """torch.autograd through dehaze1113.py:431-570 / :572-699 (dehaze22.py:531-660), train-mode BatchNorm: the recorded plan
+        walked in reverse (fdgan_hip/backward.py) -- the encoder's and decoder's dense blocks on the generator's own backward
+        kernels, the stem's MaxPool2d(3, 2, 1) and the four-scale head on csrc/legacy_bwd.hip."""
+        if not self.training:
+            raise NotImplementedError("%s backward is built for train-mode BatchNorm" % type(self).__name__)
+        P, out = state
+        B = _plan_backward(P)
+        B.zero_()
+        n, _, h, w = out.shape
+        g8 = E.new_grad(n, h, w, 8, out.device)
+        E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))                   # tanh(refine3(.)) (:569, :698)
+        last = P.records[-1]
+        assert last["kind"] == "conv" and last["y"] is None
+        last["_dy"] = E.View(g8, 0, 3)
+        grads = {}
+        B.run(grads, skip_dx_of={P.xs.data_ptr()})
+        self._derived_grads(P, grads)
+        return None, grads
+
+    def _derived_grads(self, P, grads):
+        """Gradients of the filters the plan derives from parameters, mapped back to those parameters."""
+        g0 = grads.pop(P.w0, None)
+        if g0 is not None:                                                  # inverse of _stem_filter
+            g8 = torch.zeros((64, 3, 8, 8), dtype=torch.float32, device=g0.device)
+            for dy in range(2):
+                for dx in range(2):
+                    g8[:, :, dy::2, dx::2] = g0[:, dy * 2 + dx:12:4]
+            grads[self.conv0.weight] = g8[:, :, 1:, 1:].contiguous()
+
+    def _forward_plan(self, x):
         P = self._plan_for(x)
         w7 = self.conv0.weight
         with torch.no_grad():
@@ -623,7 +664,25 @@ class _DenseBase(_PlannedModule):
                 bn.running_mean.mul_(1 - m).add_(P.st0.mean, alpha=m)
                 bn.running_var.mul_(1 - m).add_(P.st0.var, alpha=m * P.cnt0 / max(P.cnt0 - 1, 1))
                 bn.num_batches_tracked.add_(1)
-            return P.out.clone()
+            return P, P.out.clone()
+
+
+def _pyramid_sink(convs):
+    """Gradient sink of a four-scale head's 1x1 filters (backward.py, record kind "pyramid")."""
+    def sink(grads, dw, db):
+        for i, conv in enumerate(convs):
+            if conv.weight.requires_grad:
+                grad_target(grads, conv.weight).add_(dw[i].view_as(conv.weight))
+            if conv.bias is not None and conv.bias.requires_grad:
+                grad_target(grads, conv.bias).add_(db[i:i + 1])
+    return sink
+
+
+def _permuted_final_grad(P, grads, conv):
+    """The final filter of a four-scale head reads [features (20) | pyramid (4)]; the reference's order is pyramid first."""
+    g = grads.pop(P.wfinal, None)
+    if g is not None:
+        grads[conv.weight] = torch.cat([g[:, 20:], g[:, :20]], dim=1).contiguous()
 
 
 class _DensePyramid(_DenseBase):
@@ -647,11 +706,18 @@ class _DensePyramid(_DenseBase):
             conv = getattr(self, nm)
             P.copies += [(P.pw[i], conv.weight.view(20)), (P.pb[i:i + 1], conv.bias)]
         x20, y4 = E.View(P.head, 0, 20), E.View(P.head, 20, 4)
-        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4))
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4),
+             record=dict(kind="pyramid", src=x20, dst=y4, w=P.pw, b=P.pb, k0=32, slope=0.2,
+                         sink=_pyramid_sink([getattr(self, nm) for nm in ("conv1010", "conv1020", "conv1030", "conv1040")])))
         P.wfinal = torch.zeros((3, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.wfinal.requires_grad_(self.refine3.weight.requires_grad)
         P.conv(E.View(P.head), P.weight(P.wfinal, 3, 24, 3), None, 3, pad=1, bias=self.refine3.bias, e_act=L.ACT_TANH,
                y_fd=E.nchw_f32_view(P.out), label="refine3")
         P.keep += [x20, y4]
+
+    def _derived_grads(self, P, grads):
+        super()._derived_grads(P, grads)
+        _permuted_final_grad(P, grads, self.refine3)
 
     def _refresh_tail(self, P):
         wf = self.refine3.weight

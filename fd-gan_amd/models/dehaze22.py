@@ -16,8 +16,9 @@ import torch.nn as nn
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
 from fdgan_hip.netplan import ChanStats, NetPlan
+from fdgan_hip.backward import grad_target
 from models.dehaze1113 import (BottleneckBlock, TransitionBlock, _DensePyramid, _Named, _PlannedModule, _apply_plan_function,
-                               _plan_backward, _wants_grad)
+                               _permuted_final_grad, _plan_backward, _pyramid_sink, _wants_grad)
 
 
 def blockUNet(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
@@ -143,16 +144,42 @@ _TAP = {0: (3, 1, None), 1: (None, 2, 0)}
 
 
 def _phase_filters(w_t, out):
-    """w_t: ConvTranspose2d weight (cin, cout, 4, 4) -> out (4, cout, cin, 3, 3): the conv filters of parities (a, b)."""
+    """w_t: ConvTranspose2d weight (cin, cout, 4, 4) -> out: four (cout, cin, 3, 3) tensors, the conv filters of parities (a, b)."""
     wt = w_t.detach().permute(1, 0, 2, 3)
-    out.zero_()
     for a in range(2):
         for b in range(2):
+            f = out[a * 2 + b]
+            f.zero_()
             for ty, ky in enumerate(_TAP[a]):
                 for tx, kx in enumerate(_TAP[b]):
                     if ky is not None and kx is not None:
-                        out[a * 2 + b, :, :, ty, tx] = wt[:, :, ky, kx]
+                        f[:, :, ty, tx] = wt[:, :, ky, kx]
     return out
+
+
+def _phase_filter_grads(dfilt, w_t):
+    """Inverse of _phase_filters for gradients: four (cout, cin, 3, 3) -> (cin, cout, 4, 4) (every tap of the transposed filter sits in
+    exactly one parity filter); a missing entry of dfilt counts as zero."""
+    g = torch.zeros_like(w_t)
+    for a in range(2):
+        for b in range(2):
+            d = dfilt[a * 2 + b]
+            if d is None:
+                continue
+            for ty, ky in enumerate(_TAP[a]):
+                for tx, kx in enumerate(_TAP[b]):
+                    if ky is not None and kx is not None:
+                        g[:, :, ky, kx] = d[:, :, ty, tx].permute(1, 0)
+    return g
+
+
+class _BnTable:
+    """What backward.py reads off a BatchNorm module, for a per-channel table that holds two norms side by side: `weight` / `bias`
+    are the table's gamma / beta rows (leaves that receive the table-wide dgamma / dbeta; `_UNet._table_grads` hands the halves to
+    the modules they came from)."""
+
+    def __init__(self, gamma, beta):
+        self.weight, self.bias = gamma, beta
 
 
 class _Stats:
@@ -197,8 +224,8 @@ class _UNet(_PlannedModule):
     def _tconv(self, P, src, pro, w_param, cout, cin, dst_buf, c0, hin, win, e_act, stats, count, label):
         """ConvTranspose2d(4, 2, 1) of `src` (View, hin x win) into channels [c0, c0 + cout) of dst_buf (2 hin x 2 win)."""
         dev = dst_buf.device
-        filt = torch.zeros((4, cout, cin, 3, 3), dtype=torch.float32, device=dev)
-        P.derived.append((w_param, filt))
+        filt = [torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=dev).requires_grad_(w_param.requires_grad) for _ in range(4)]
+        P.derived.append((w_param, filt))     # leaves: the reverse walk leaves their gradients under these keys (`_derived_grads`)
         ws4 = [P.weight(filt[i], cout, cin, 3) for i in range(4)]
         ys = [E.StridedView(dst_buf, c0, cout, a, b, 2, 2, hin, win) for a in range(2) for b in range(2)]
         desc = E.conv_desc(3, 1, 1, e_act, False, cout=cout, w_layout=ws4[0].layout)
@@ -222,6 +249,9 @@ class _UNet(_PlannedModule):
         P._ops.append((run, need, dict(label=label, k=4, cin=cin, cout=cout, n=n, h_out=2 * hin, w_out=2 * win,
                                        flops=2.0 * n * (2 * hin) * (2 * win) * cout * cin * 4, flops_done=2.0 * n * hin * win * 4 * cout * cin * 9,
                                        bytes=n * hin * win * cin * 2 + n * 4 * hin * win * cout * 2)))
+        for i in range(4):     # what the reverse walk sees: four stride-1 convolutions whose outputs interleave
+            P.records.append(dict(kind="conv", x=src, w=ws4[i], y=ys[i], k=3, pad=1, stride=1, bias=None, pro=pro_rest, e_act=e_act,
+                                  upsample=False, rerun=None))
         P.keep += [src, pro, pro_rest, ws4, ys, desc, filt]
 
     def _build_plan(self, shape, dev):
@@ -233,6 +263,7 @@ class _UNet(_PlannedModule):
                              % (type(self).__name__, h, w))
         nf, ce, cd = self.nf, self.ce, self.cd
         train = self.training
+        keep = self.__dict__.get("_plan_keep", False)      # this plan will be walked in reverse (models.dehaze1113._PlannedModule)
         if train and n * (h // 256) * (w // 256) < 2:
             raise ValueError("train-mode BatchNorm at the 1x1 bottleneck needs more than one value per channel (batch >= 2 at 256x256)")
         r8 = lambda v: (v + 7) // 8 * 8
@@ -288,43 +319,89 @@ class _UNet(_PlannedModule):
                 pro = P.bn_prologue(enc_bn[8], enc_stats[8], n * hs[8] * ws_[8], act=L.ACT_RELU)
             else:
                 src, cin = E.View(cat[k]), cd[k + 1] + ce[k - 1]
-                t = tab[k]
-                pro = E.make_prologue(act=L.ACT_RELU, mean=t["mean"], var=t["var"], gamma=t["gamma"], beta=t["beta"], eps=1e-5)
+                pro = self._table_prologue(P, k, train)
             dst, cout = cat[k - 1], cd[k]
             bn = dec_bn.get(k)
             drop = train and k >= 6
             left = _Stats(tab[k - 1]["mean"][:cout], tab[k - 1]["var"][:cout])
             st = left if (bn is not None and train and not drop) else (ChanStats(cout, dev) if (bn is not None and train) else None)
-            self._tconv(P, src, pro, blk.tconv.weight, cout, cin, dst, 0, hs[k], ws_[k], L.ACT_NONE, st, n * hs[k - 1] * ws_[k - 1], "dlayer%d" % k)
+            # a plan that is trained through keeps the raw transposed-conv output of the dropout levels (BatchNorm's backward needs
+            # it; at most 8 x 8 pixels); an inference plan finishes it in place
+            raw = E.new_act(n, hs[k - 1], ws_[k - 1], cout, dev) if (drop and keep) else None
+            self._tconv(P, src, pro, blk.tconv.weight, cout, cin, raw if raw is not None else dst, 0, hs[k], ws_[k], L.ACT_NONE, st,
+                        n * hs[k - 1] * ws_[k - 1], "dlayer%d" % k)
             if bn is not None and train:
                 P.running.append((bn, st.mean, st.var, n * hs[k - 1] * ws_[k - 1]))
-            if drop:        # BatchNorm + Dropout2d applied in place: the consumer sees finished values (identity entries in its table)
+            if drop:        # BatchNorm + Dropout2d applied in one pass: the consumer sees finished values (identity entries in its table)
                 mask = torch.ones((n, cout), dtype=torch.float32, device=dev)
                 P.masks.append(mask)
                 v = E.View(dst, 0, cout)
+                u = E.View(raw) if raw is not None else v
+                rec = dict(kind="bn_dropout", src=u, dst=v, mean=st.mean if bn is not None else None, var=st.var if bn is not None else None,
+                           gamma=bn.weight if bn is not None else None, eps=bn.eps if bn is not None else 0.0, mask=mask, bn=bn) if raw is not None else None
                 if bn is not None:
-                    P.op(lambda v=v, st=st, bn=bn, mask=mask: E.bn_dropout(v, st.mean, st.var, bn.weight, bn.bias, bn.eps, mask, v))
+                    P.op(lambda v=v, u=u, st=st, bn=bn, mask=mask: E.bn_dropout(u, st.mean, st.var, bn.weight, bn.bias, bn.eps, mask, v), record=rec)
                 else:
-                    P.op(lambda v=v, mask=mask: E.bn_dropout(v, None, None, None, None, 0.0, mask, v))
-                P.keep += [v, mask, st]
+                    P.op(lambda v=v, u=u, mask=mask: E.bn_dropout(u, None, None, None, None, 0.0, mask, v), record=rec)
+                P.keep += [v, u, mask, st]
             elif bn is not None:
                 P.copies += [(tab[k - 1]["gamma"][:cout], bn.weight), (tab[k - 1]["beta"][:cout], bn.bias)]
                 if not train:
                     P.copies += [(tab[k - 1]["mean"][:cout], bn.running_mean), (tab[k - 1]["var"][:cout], bn.running_var)]
-        t = tab[1]
-        P.last_pro = E.make_prologue(act=L.ACT_RELU, mean=t["mean"], var=t["var"], gamma=t["gamma"], beta=t["beta"], eps=1e-5)
+        P.last_pro = self._table_prologue(P, 1, train)
         self._build_head(P, n, h, w, dev)
         P.keep += [cat, out8, tab, enc_stats]
         return P.finish()
+
+    def _table_prologue(self, P, k, train):
+        """BatchNorm + ReLU over the concat buffer of level k: [decoder norm of dlayer k+1 | encoder norm of layer k] side by side
+        (identity entries where the left half holds finished values: a dropout level, or the norm-free dlayer8 / level-1 encoder)."""
+        t, cl = P.tab[k], self.cd[k + 1]
+        pro = E.make_prologue(act=L.ACT_RELU, mean=t["mean"], var=t["var"], gamma=t["gamma"], beta=t["beta"], eps=1e-5)
+        if train:
+            ident = []
+            if k + 1 >= 6 or k + 1 == 8:            # dlayer 8 / 7 / 6: BatchNorm (if any) + Dropout2d already applied
+                ident.append((0, cl))
+            if k == 1:                               # layer1 has no norm
+                ident.append((cl, cl + self.ce[0]))
+            for nm in ("gamma", "beta"):
+                t[nm].requires_grad_(True)
+            pro._meta.update(bn=_BnTable(t["gamma"], t["beta"]), batch_stats=True, identity=ident)
+        return pro
+
+    def _table_grads(self, P, grads):
+        """dgamma / dbeta of the side-by-side tables -> the BatchNorm modules the halves belong to."""
+        for k in range(1, 8):
+            t, cl = P.tab[k], self.cd[k + 1]
+            dg, db = grads.pop(t["gamma"], None), grads.pop(t["beta"], None)
+            if dg is None:
+                continue
+            halves = []
+            if k + 1 <= 5:                           # left half: the decoder norm of dlayer k+1 (no dropout there)
+                halves.append((getattr(self, "dlayer%d" % (k + 1))[0].bn, 0, cl))
+            if k >= 2:                               # right half: the encoder norm of layer k
+                halves.append((getattr(self, "layer%d" % k)[0].bn, cl, cl + self.ce[k - 1]))
+            for bn, lo, hi in halves:
+                if bn.weight.requires_grad:
+                    grad_target(grads, bn.weight).add_(dg[lo:hi])
+                    grad_target(grads, bn.bias).add_(db[lo:hi])
+
+    def _derived_grads(self, P, grads):
+        for w_t, filt in P.derived:
+            if not w_t.requires_grad:
+                continue
+            d = [grads.pop(f, None) for f in filt]
+            if any(x is not None for x in d):
+                grad_target(grads, w_t).add_(_phase_filter_grads(d, w_t))
 
     def _run(self, x):
         P = self._plan_for(x)
         with torch.no_grad():
             for w_t, filt in P.derived:
                 ver = w_t._version
-                if getattr(filt, "_src_version", None) != (ver, w_t.data_ptr()):
+                if getattr(filt[0], "_src_version", None) != (ver, w_t.data_ptr()):
                     _phase_filters(w_t, filt)
-                    filt._src_version = (ver, w_t.data_ptr())
+                    filt[0]._src_version = (ver, w_t.data_ptr())
             for dst, src_t in P.copies:
                 dst.copy_(src_t.detach())
             forced = self.__dict__.get("_forced_dropout_masks")     # tests: the masks the oracle used, order dlayer8, 7, 6
@@ -343,10 +420,32 @@ class _UNet(_PlannedModule):
             return self._finish(P, x)
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("models.dehaze22.%s runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): "
-                                      "call it under torch.no_grad()" % type(self).__name__)
+        if _wants_grad(self, x):
+            if x.requires_grad:
+                raise NotImplementedError("models.dehaze22.%s: the gradient w.r.t. the input image is not produced on the HIP path" % type(self).__name__)
+            return _apply_plan_function(self, x)
         return self._run(x)
+
+    def _autograd_forward(self, x):
+        out = self._run(x)
+        return out, (self._plan_for(x), out)
+
+    def _autograd_backward(self, state, dout):
+        """torch.autograd through dehaze22.py:205-362 / :364-488 (train mode): the plan walked in reverse -- every transposed conv as
+        its four parity convolutions (their filter gradients gathered back into the (cin, cout, 4, 4) parameter), the side-by-side
+        BatchNorm tables' dgamma / dbeta handed to the two modules each table was built from, BatchNorm + Dropout2d and the pooling
+        head on csrc/legacy_bwd.hip."""
+        if not self.training:
+            raise NotImplementedError("%s backward is built for train-mode BatchNorm" % type(self).__name__)
+        P, out = state
+        B = _plan_backward(P)
+        B.zero_()
+        grads = {}
+        self._seed_head(P, B, out, dout)
+        B.run(grads, skip_dx_of={P.xin.data_ptr()})
+        self._derived_grads(P, grads)
+        self._table_grads(P, grads)
+        return None, grads
 
 
 class G(_UNet):
@@ -374,8 +473,11 @@ class G(_UNet):
             conv = getattr(self, nm)
             P.copies += [(P.pw[i], conv.weight.view(20)), (P.pb[i:i + 1], conv.bias)]
         x20, y4 = E.View(head, 0, 20), E.View(head, 20, 4)
-        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 16, 0.2, y4))
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 16, 0.2, y4),
+             record=dict(kind="pyramid", src=x20, dst=y4, w=P.pw, b=P.pb, k0=16, slope=0.2,
+                         sink=_pyramid_sink([getattr(self, nm) for nm in ("conv1010", "conv1020", "conv1030", "conv1040")])))
         P.wfinal = torch.zeros((self.output_nc, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.wfinal.requires_grad_(self.dlayerfinal.dlayer1.conv.weight.requires_grad)
         P.out = torch.empty((n, self.output_nc, h, w), dtype=torch.float32, device=dev)
         P.conv(E.View(head), P.weight(P.wfinal, self.output_nc, 24, 3), None, 3, pad=1, e_act=L.ACT_TANH, y_fd=E.nchw_f32_view(P.out),
                label="dlayerfinal")
@@ -393,6 +495,18 @@ class G(_UNet):
 
     def _finish(self, P, x):
         return P.out.clone()
+
+    def _seed_head(self, P, B, out, dout):
+        n, c, h, w = out.shape
+        g8 = E.new_grad(n, h, w, (c + 7) // 8 * 8, out.device)
+        E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))          # tanh(dlayerfinal(.)) (:356-361)
+        last = P.records[-1]
+        assert last["kind"] == "conv" and last["y"] is None
+        last["_dy"] = E.View(g8, 0, c)
+
+    def _derived_grads(self, P, grads):
+        super()._derived_grads(P, grads)
+        _permuted_final_grad(P, grads, self.dlayerfinal.dlayer1.conv)
 
 
 class G2(_UNet):
@@ -413,6 +527,11 @@ class G2(_UNet):
         out = torch.empty((x.shape[0], self.output_nc, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
         E.to_nchw(E.View(P.head, 0, self.output_nc), out)
         return out
+
+    def _seed_head(self, P, B, out, dout):
+        """The output IS the head buffer (LeakyReLU epilogue of dlayer1's parity convolutions): its gradient is dout, NHWC bf16;
+        the epilogue's mask is applied by the walk."""
+        E.to_nhwc(dout, E.View(B.gbuf[P.head.data_ptr()]))          # the padding channels of the 8-channel buffer become zeros
 
 
 class Dense(_DensePyramid):

@@ -253,6 +253,25 @@ int fdgan_pyramid_pool4(const FdTensor* x, const float* weight, const float* bia
                         FdStream stream);
 int fdgan_bn_dropout_nhwc(const FdTensor* x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                           const float* mask, const FdTensor* y, FdStream stream);
+/* Reverse mode of the four entry points above (csrc/legacy_bwd.hip; torch.autograd through dehaze22.py:343-356, :540-543, :60-63,
+ * :699-715).  Gradients are NHWC bf16 views like every activation gradient.
+ * fdgan_maxpool3s2_bwd: da (N x H x W x C, written) = gradient w.r.t. act(bn(x)): each position collects dy of the windows whose
+ *   FIRST maximum (scan order, ATen's rule) it is; continue with fdgan_bn_act_bwd / fdgan_bn_bwd_finalize / fdgan_bn_bwd_apply.
+ * fdgan_pyramid_pool4_bwd: dx += the head's input gradient; dw_part [tiles][4][C] / db_part [tiles][4] = per-tile partial sums of
+ *   the four 1x1 filters' gradients (tiles = N * H/k0 * W/k0, returned in *tiles_out; sum them over the first axis).
+ * fdgan_bn_dropout_bwd: x = the RAW values the forward normalised, dy = gradient of mask * bn(x); dx written, dgamma / dbeta [C]
+ *   written (batch statistics: the full BatchNorm backward).  mean == NULL: dx = mask * dy.
+ * fdgan_scatter_dehaze_bwd: gradients w.r.t. the transmission map and G2's output (both N x 3 x H x W fp32, written) from the
+ *   gradients of `dehaze2` and `atp` (fp32 NCHW, either may be NULL) and of the refine input's J channels (g_cat channels 0-2,
+ *   may be NULL); window_mean as fdgan_scatter_dehaze left it; scratch >= N * 3 * (W / H) * H floats. */
+int fdgan_maxpool3s2_bwd(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdTensor* da, FdStream stream);
+int fdgan_pyramid_pool4_bwd(const FdTensor* x, const float* weight, const float* bias, int k0, float slope, const FdTensor* dy,
+                            const FdTensor* dx, float* dw_part, float* db_part, int64_t* tiles_out, FdStream stream);
+int fdgan_bn_dropout_bwd(const FdTensor* x, const float* mean, const float* var, const float* gamma, float eps, const float* mask,
+                         const FdTensor* dy, const FdTensor* dx, float* dgamma, float* dbeta, FdStream stream);
+int fdgan_scatter_dehaze_bwd(const float* x, const float* tran, const float* atp, const float* window_mean, int64_t n, int64_t h,
+                             int64_t w, float slope, float eps, const float* g_dehaze2, const float* g_atp, const FdTensor* g_cat,
+                             float* d_tran, float* d_atp, float* scratch, int64_t scratch_floats, FdStream stream);
 
 /* ---- plan: record once, replay many ----------------------------------------- */
 /* Between fdgan_plan_begin and fdgan_plan_end every launching entry point above,
@@ -304,7 +323,7 @@ int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n);
  *                   return (sigmoid map of D: s(1-s); tanh image of FDGAN: 1-t^2).
  *  plumbing         fdgan_grad_ew: 0 dst += src (several consumers of one tensor, torch.cat), 1 dst = src[y/2][x/2]/4
  *                   (prologue avg-pool), 2 dst = 2x2 sum of src (nearest-upsample epilogue), 3 dst = src * (ref > 0)
- *                   (ReLU epilogue, ref = the stored output). */
+ *                   (ReLU epilogue, ref = the stored output), 4 dst = src * (ref > 0 ? 1 : 0.2) (LeakyReLU epilogue). */
 int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTensor* dy, const FdConvDesc* d,
                             float* dw, float* dbias, float* workspace, int64_t workspace_floats, int accumulate,
                             FdStream stream);

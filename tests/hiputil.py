@@ -121,6 +121,8 @@ def op_reference(r, dy_view, meta):
         a = xr
         if meta.get("bn") is not None:
             a = F.batch_norm(a, None, None, meta["gamma"].detach(), meta["beta"].detach(), True, 0.0, meta["eps"])
+            for lo, hi in meta.get("identity", ()):      # table entries that are constants (mean 0, var 1 - eps, gamma 1, beta 0), not statistics
+                a = torch.cat([a[:, :lo], xr[:, lo:hi], a[:, hi:]], 1)
         if meta["act"] == ACT_RELU:
             a = torch.relu(a)
         elif meta["act"] == ACT_LEAKY02:

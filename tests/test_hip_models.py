@@ -1246,3 +1246,247 @@ def test_legacy_dehaze_matches_oracle_and_golden(golden_dir):
     for tag in ("eval", "train"):
         assert rep[tag + "_tran_rel_rms_vs_oracle"] < 2e-2 and rep[tag + "_atp_rel_rms_vs_oracle"] < 2e-2, rep
         assert rep[tag + "_dehaze2_rel_rms_vs_oracle"] < 4e-2 and rep[tag + "_dehaze_rel_rms_vs_oracle"] < 6e-2, rep
+
+
+def _functional_grads(forward, sd, x, cot):
+    """Reference gradients of a functional oracle (oracle/legacy_ref.py): every floating-point entry of the state dict that is not a
+    running statistic is a leaf; returns {key: gradient} for those the output depends on."""
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    out = forward(sdg)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    cots = cot if isinstance(cot, (tuple, list)) else (cot,)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    return {k: v.grad for k, v in sdg.items() if getattr(v, "grad", None) is not None}
+
+
+def _legacy_grad_report(net, ref_grads):
+    """rel-rms of every parameter gradient against the oracle's; parameters the oracle gives no gradient must have none (or zeros)."""
+    rep, norms = {}, {}
+    for k, p in net.named_parameters():
+        g = ref_grads.get(k)
+        if g is None or float(g.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None and p.grad.shape == g.shape, k
+        rep[k] = rel_rms(p.grad.cpu(), g)
+        norms[k] = float(g.norm())
+    return rep, norms
+
+
+def _legacy_grad_summary(net, ref, watch):
+    """Network-level agreement with the fp32 oracle's autograd.  These networks are ill-conditioned in train mode (BatchNorm over
+    a dozen values at the 1/32 bottleneck, random weights): the fp16 FORWARD already differs from the fp32 oracle by 2-5 % rel-rms
+    there, and every gradient below the head inherits that noise (measured: 4 % at the last conv growing smoothly to 50 % at the
+    stem, with norm ratios of 1.00 +- 0.03 throughout).  So the per-op checks carry the exactness claim; here we ask for what a
+    wrong formula, a dropped term or a mis-routed gradient would break: every parameter has a gradient of the right size
+    (norm ratio), the whole gradient points the oracle's way (cosine), and the parameters next to the loss agree closely."""
+    rep, norms = _legacy_grad_report(net, ref)
+    params = dict(net.named_parameters())
+    big = [k for k in rep if norms[k] > 1e-3 * max(norms.values())]          # analytically-zero gradients (a bias in front of a BatchNorm) excluded
+    ratios = sorted(float(params[k].grad.norm()) / norms[k] for k in big)
+    dot = sum(float((params[k].grad.cpu() * ref[k]).sum()) for k in rep)
+    cos = dot / (sum(float(params[k].grad.norm()) ** 2 for k in rep) ** 0.5 * sum(norms[k] ** 2 for k in rep) ** 0.5)
+    vals = sorted(rep[k] for k in big)
+    out = {"parameters": len(rep), "compared": len(big), "median_rel_rms": vals[len(vals) // 2], "cosine": cos,
+           "norm_ratio_p05": ratios[len(ratios) // 20], "norm_ratio_median": ratios[len(ratios) // 2], "norm_ratio_p95": ratios[len(ratios) * 19 // 20]}
+    out.update({k: rep.get(k) for k in watch})
+    return out
+
+
+def _assert_legacy_grads(summary, head_tol=0.12):
+    assert summary["cosine"] > 0.8, summary
+    assert 0.85 < summary["norm_ratio_p05"] and summary["norm_ratio_p95"] < 1.2 and abs(summary["norm_ratio_median"] - 1.0) < 0.05, summary
+    assert summary["refine3.weight" if "refine3.weight" in summary else "head"] < head_tol, summary
+
+
+@pytest.mark.parametrize("nm,mod,cls,tail", [("dense1113", "dehaze1113", "Dense", "bn"), ("dense2_1113", "dehaze1113", "Dense2", "pyramid"),
+                                            ("dense22", "dehaze22", "Dense", "pyramid")])
+def test_legacy_dense_backward(nm, mod, cls, tail):
+    """SURVEY 8f rank 4, reverse mode: `loss.backward()` through the DCPDN `Dense` networks on the HIP path (train-mode BatchNorm) --
+    the stem's MaxPool2d(3, 2, 1) + norm0 backward and the 7x7 filter's gradient through its space-to-depth image, the dense
+    blocks on the generator's kernels, decoder blocks with BatchNorm, the four-scale head (csrc/legacy_bwd.hip) -- every parameter
+    gradient against torch.autograd over the fp32 oracle (itself 0.0 from the real reference, MANIFEST.json)."""
+    import importlib
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = getattr(importlib.import_module("models." + mod), cls)()
+    fill_state_dict(net, seed=6)
+    with torch.no_grad():
+        net.refine3.weight.mul_(0.1), net.refine3.bias.mul_(0.1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV).train()
+    x = det_input((2, 3, 64, 96), seed=33)
+    cot = det_input((2, 3, 64, 96), seed=7, lo=-1.0, hi=1.0)
+    ref = _functional_grads(lambda sdg: legacy_ref.dense_forward(sdg, x.clone(), True, tail), sd, x, cot)
+    y = net(x.to(DEV))
+    assert y.requires_grad and y.shape == (2, 3, 64, 96)
+    (y * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    summary = _legacy_grad_summary(net, ref, ("refine3.weight", "refine3.bias", "conv_refin.weight", "conv1010.weight", "conv0.weight", "norm0.bias"))
+    # the same walk once more with every convolution record verified IN PLACE against torch.autograd on the same device tensors
+    # (the op's two gradients in isolation: no forward noise in the way)
+    from models.dehaze1113 import _plan_backward
+    B = _plan_backward(net._plan_for(x.to(DEV)))
+    B.checks, B.check_reference = [], hiputil_op_reference
+    net.zero_grad()
+    (net(x.to(DEV)) * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    checks, B.checks = B.checks, None
+    summary.update(ops_checked=len(checks), op_dw_worst=max(o["dw"] for o in checks), op_dx_worst=max(o.get("dx", 0.0) for o in checks),
+                   ops_worst_dx=sorted(checks, key=lambda o: -o.get("dx", 0.0))[:4])
+    _report("legacy_%s_backward" % nm, summary)
+    assert summary["parameters"] > 300 and summary["ops_checked"] > 100, summary
+    assert summary["op_dw_worst"] < 5e-3 and summary["op_dx_worst"] < 3e-2, summary      # dx: 2.4 % on a 2 x 3-pixel BatchNorm'd op (12 values per channel)
+    _assert_legacy_grads(summary)
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV).requires_grad_(True))
+
+
+def test_legacy_backward_kernels_match_autograd():
+    """csrc/legacy_bwd.hip against torch.autograd on the same fp16-representable values: MaxPool2d(3, 2, 1)(relu(bn(x))) with the
+    train-mode BatchNorm backward behind it (as backward.py chains it), the four-scale head, BatchNorm + Dropout2d, the scattering model."""
+    import torch.nn.functional as F
+    from fdgan_hip import engine as E
+    from fdgan_hip import lib as L
+    torch.manual_seed(11)
+    rep = {}
+    # ---- maxpool3s2 + BatchNorm(batch statistics) + ReLU
+    n, h, w, c = 2, 18, 22, 16
+    x = torch.randn(n, c, h, w).half().float()
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.max_pool2d(F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5)), 3, 2, 1)
+    dy = torch.randn_like(y).bfloat16().float()
+    (y * dy).sum().backward()
+    xb = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    mean, var = x.mean((0, 2, 3)).to(DEV), x.var((0, 2, 3), unbiased=False).to(DEV)
+    pro = E.make_prologue(act=L.ACT_RELU, mean=mean, var=var, gamma=gamma.to(DEV), beta=beta.to(DEV), eps=1e-5)
+    dyb = dy.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    gs = torch.zeros(n, h, w, c, dtype=torch.bfloat16, device=DEV)
+    xv, gv = E.View(xb), E.View(gs)
+    E.maxpool3s2_bwd(xv, pro, E.View(dyb), gv)
+    ws = torch.empty(1 << 20, device=DEV)
+    rows, cpad = E.bn_act_bwd(gv.fd, xv.fd, pro, ws)
+    dg, dbt = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    E.bn_bwd_finalize(ws, rows, cpad, c, dg, dbt)
+    E.bn_bwd_apply(gv.fd, xv.fd, pro, dg, dbt, gv.fd, accumulate=False)
+    torch.cuda.synchronize()
+    rep["maxpool3_dx"] = rel_rms(gs.float().permute(0, 3, 1, 2).cpu(), xr.grad)
+    rep["maxpool3_dgamma"] = rel_rms(dg.cpu(), gr.grad)
+    rep["maxpool3_dbeta"] = rel_rms(dbt.cpu(), br.grad)
+    # ---- four-scale head
+    for k0, (hh, ww) in ((16, (32, 48)), (32, (64, 32))):
+        xs = torch.randn(2, 20, hh, ww).half().float()
+        wt, bs = (torch.randn(4, 20) * 0.3), torch.randn(4) * 0.1
+        xq, wq, bq = xs.clone().requires_grad_(True), wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+        outs = []
+        for j, k in enumerate((k0, k0 // 2, k0 // 4, k0 // 8)):
+            pz = F.conv2d(F.avg_pool2d(xq, k), wq[j].view(1, 20, 1, 1), bq[j:j + 1])
+            outs.append(F.interpolate(F.leaky_relu(pz, 0.2), size=(hh, ww), mode="nearest"))
+        d4 = torch.randn(2, 4, hh, ww).bfloat16().float()
+        (torch.cat(outs, 1) * d4).sum().backward()
+        buf = torch.zeros(2, hh, ww, 24, dtype=torch.float16, device=DEV)
+        buf[..., :20] = xs.permute(0, 2, 3, 1).half().to(DEV)
+        g = torch.zeros(2, hh, ww, 24, dtype=torch.bfloat16, device=DEV)
+        g[..., 20:] = d4.permute(0, 2, 3, 1).bfloat16().to(DEV)
+        dw, db = E.pyramid_pool4_bwd(E.View(buf, 0, 20), wt.to(DEV), bs.to(DEV), k0, 0.2, E.View(g, 20, 4), E.View(g, 0, 20))
+        torch.cuda.synchronize()
+        got_dx = g[..., :20].float().cpu().permute(0, 3, 1, 2)
+        rep["pyramid%d_dx" % k0] = rel_rms(got_dx, xq.grad)
+        E.pyramid_pool4_bwd(E.View(buf, 0, 20), wt.to(DEV), bs.to(DEV), k0, 0.2, E.View(g, 20, 4), E.View(g, 0, 20))   # ACCUMULATES into dx
+        torch.cuda.synchronize()
+        rep["pyramid%d_dx_twice" % k0] = rel_rms(g[..., :20].float().cpu().permute(0, 3, 1, 2), 2.0 * xq.grad)
+        rep["pyramid%d_dw" % k0] = rel_rms(dw.cpu(), wq.grad)
+        rep["pyramid%d_db" % k0] = rel_rms(db.cpu(), bq.grad)
+    # ---- BatchNorm (batch statistics) + Dropout2d
+    x = torch.randn(3, 12, 4, 4).half().float()
+    gamma, mask = torch.rand(12) + 0.5, (torch.rand(3, 12) > 0.5).float() * 2.0
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), torch.zeros(12, requires_grad=True)
+    y = F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5) * mask[:, :, None, None]
+    dy = torch.randn_like(y).bfloat16().float()
+    (y * dy).sum().backward()
+    xb = torch.zeros(3, 4, 4, 16, dtype=torch.float16, device=DEV)
+    xb[..., :12] = x.permute(0, 2, 3, 1).half().to(DEV)
+    dyb = torch.zeros(3, 4, 4, 16, dtype=torch.bfloat16, device=DEV)
+    dyb[..., :12] = dy.permute(0, 2, 3, 1).bfloat16().to(DEV)
+    dxb = torch.zeros_like(dyb)
+    mean, var = x.mean((0, 2, 3)).to(DEV), x.var((0, 2, 3), unbiased=False).to(DEV)
+    dg, db = E.bn_dropout_bwd(E.View(xb, 0, 12), mean, var, gamma.to(DEV), 1e-5, mask.to(DEV), E.View(dyb, 0, 12), E.View(dxb, 0, 12))
+    torch.cuda.synchronize()
+    rep["bn_dropout_dx"] = rel_rms(dxb[..., :12].float().permute(0, 3, 1, 2).cpu(), xr.grad)
+    rep["bn_dropout_dgamma"] = rel_rms(dg.cpu(), gr.grad)
+    rep["bn_dropout_dbeta"] = rel_rms(db.cpu(), br.grad)
+    dg2, _ = E.bn_dropout_bwd(E.View(xb, 0, 12), None, None, None, 0.0, mask.to(DEV), E.View(dyb, 0, 12), E.View(dxb, 0, 12))
+    torch.cuda.synchronize()
+    assert dg2 is None
+    rep["dropout_only_dx"] = rel_rms(dxb[..., :12].float().permute(0, 3, 1, 2).cpu(), dy * mask[:, :, None, None])
+    # ---- scattering model: J = (I - A) / (|t| + eps) + A, A = leaky(mean of atp over H x H windows)
+    n, h, w = 2, 8, 16
+    xi, tr, at = torch.rand(n, 3, h, w), torch.randn(n, 3, h, w).sign() * (torch.rand(n, 3, h, w) + 0.5), torch.randn(n, 3, h, w)
+    tq, aq = tr.clone().requires_grad_(True), at.clone().requires_grad_(True)
+    A = F.interpolate(F.leaky_relu(F.avg_pool2d(aq, h), 0.2), size=(h, w), mode="nearest")
+    J = (xi - A) / (tq.abs() + 1e-10) + A
+    g2, ga = torch.randn(n, 3, h, w), torch.randn(n, 3, h, w)
+    gc = torch.randn(n, 3, h, w).bfloat16().float()
+    (J * g2 + A * ga + J * gc).sum().backward()
+    wm = torch.zeros(n * 3 * (w // h), device=DEV)
+    cat = torch.zeros(n, h, w, 8, dtype=torch.float16, device=DEV)
+    atp_out, d2 = torch.empty(n, 3, h, w, device=DEV), torch.empty(n, 3, h, w, device=DEV)
+    E.scatter_dehaze(xi.to(DEV), tr.to(DEV), at.to(DEV), 0.2, 1e-10, wm, atp_out, d2, E.View(cat))
+    gcat = torch.zeros(n, h, w, 8, dtype=torch.bfloat16, device=DEV)
+    gcat[..., :3] = gc.permute(0, 2, 3, 1).bfloat16().to(DEV)
+    dt, da = E.scatter_dehaze_bwd(xi.to(DEV), tr.to(DEV), at.to(DEV), wm, 0.2, 1e-10, g2.to(DEV), ga.to(DEV), E.View(gcat))
+    torch.cuda.synchronize()
+    rep["scatter_dtran"] = rel_rms(dt.cpu(), tq.grad)
+    rep["scatter_datp"] = rel_rms(da.cpu(), aq.grad)
+    _report("legacy_backward_kernels", rep)
+    assert max(rep.values()) < 1e-2, rep
+
+
+@pytest.mark.parametrize("kind", ["G2", "G"])
+def test_legacy_unets_backward(kind):
+    """SURVEY 8f rank 4, reverse mode: `loss.backward()` through the pix2pix U-Nets (dehaze22.py:205-362, :364-488), train mode with the
+    oracle's Dropout2d masks: 4x4 stride-2 encoder convs, every ConvTranspose2d as four parity convolutions on strided gradient views
+    (filter gradients gathered back into the (cin, cout, 4, 4) parameter), the side-by-side BatchNorm tables, BatchNorm + Dropout2d
+    and the pooling head -- op by op against torch.autograd on the same tensors, and every parameter against the fp32 oracle."""
+    import models.dehaze22 as net22
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = getattr(net22, kind)(3, 3, 8)
+    fill_state_dict(net, seed=5)
+    if kind == "G":
+        with torch.no_grad():
+            net.dlayerfinal.dlayer1.conv.weight.mul_(0.3)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV).train()
+    x = det_input((4, 3, 256, 256), seed=21)
+    cot = det_input((4, 3, 256, 256), seed=7, lo=-1.0, hi=1.0)
+    torch.manual_seed(3)
+    masks = [(torch.rand(4, 64) > 0.5).float() * 2.0 for _ in range(3)]
+    ref = _functional_grads(lambda sdg: legacy_ref.unet_forward(sdg, x.clone(), True, kind, masks=list(masks))[0], sd, x, cot)
+    net.__dict__["_forced_dropout_masks"] = [m.to(DEV) for m in masks]
+    y = net(x.to(DEV))
+    assert y.requires_grad and y.shape == (4, 3, 256, 256)
+    (y * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    head = "dlayerfinal.dlayer1.conv.weight" if kind == "G" else "dlayer1.dlayer1.tconv.weight"
+    summary = _legacy_grad_summary(net, ref, (head, "dlayer2.dlayer2.tconv.weight", "dlayer2.dlayer2.bn.weight", "dlayer7.dlayer7.bn.weight",
+                                              "dlayer8.dlayer8.tconv.weight", "layer8.layer8.conv.weight", "layer2.layer2.bn.bias", "layer1.layer1.weight",
+                                              "conv1010.weight"))
+    summary["head"] = summary[head]
+    from models.dehaze1113 import _plan_backward
+    B = _plan_backward(net._plan_for(x.to(DEV)))
+    B.checks, B.check_reference = [], hiputil_op_reference
+    net.zero_grad()
+    (net(x.to(DEV)) * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    checks, B.checks = B.checks, None
+    summary.update(ops_checked=len(checks), op_dw_worst=max(o["dw"] for o in checks), op_dx_worst=max(o.get("dx", 0.0) for o in checks),
+                   ops_worst_dx=sorted(checks, key=lambda o: -o.get("dx", 0.0))[:4])
+    _report("legacy_%s_backward" % kind, summary)
+    assert summary["ops_checked"] >= 8 + 4 * 8, summary
+    assert summary["op_dw_worst"] < 5e-3 and summary["op_dx_worst"] < 3e-2, summary
+    _assert_legacy_grads(summary)
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV).requires_grad_(True))
