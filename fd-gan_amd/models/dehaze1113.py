@@ -441,7 +441,7 @@ class FDGAN(_PlannedModule):
 
 
 # ---------------------------------------------------------------------------------------
-# legacy DCPDN network `Dense`, forward only
+# legacy DCPDN network `Dense`: forward, and backward in train mode
 # ---------------------------------------------------------------------------------------
 class BottleneckBlock(nn.Module):
     """dehaze1113.py:234-254 / dehaze22.py:491-510: BN-ReLU-1x1 (4 x out), BN-ReLU-3x3, concat.  Parameter container with
@@ -508,7 +508,7 @@ def _stem_filter(w7, out):
 
 
 class _DenseBase(_PlannedModule):
-    """The DCPDN `Dense` network (dehaze1113.py:431-570, :572-699; dehaze22.py:531-660), forward only, on the generator's own
+    """The DCPDN `Dense` network (dehaze1113.py:431-570, :572-699; dehaze22.py:531-660), forward and train-mode backward, on the generator's own
     machinery: torchvision's dense blocks and transitions on concat buffers, BatchNorm in the consumers' prologues.  New
     here: the DenseNet stem -- the 7x7 stride-2 conv runs as a 4x4 stride-1 conv on the space-to-depth image (exact: a
     zero-extended 8x8 window), norm0 / relu0 / MaxPool2d(3, 2, 1) as `fdgan_maxpool3s2_nhwc` -- and decoder blocks WITH

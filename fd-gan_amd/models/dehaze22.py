@@ -1,7 +1,7 @@
 """`models.dehaze22` surface of the reference (/root/reference/models/dehaze22.py): the pix2pix
 PatchGAN discriminator `D(nc, nf)` (:114-156, `D_tran` :159-201 is the same network) and, from the
 DCPDN-era generators of that file (not on FD-GAN's hot path), the two U-Nets
-`G` (:205-362) and `G2` (:364-488) -- forward only, on the same primitives: 4x4 stride-2 convolutions,
+`G` (:205-362) and `G2` (:364-488) -- forward and (train mode) backward, on the same primitives: 4x4 stride-2 convolutions,
 ConvTranspose2d(4, 2, 1) as four stride-1 3x3 convolutions (one per output parity, strided output
 views), train- or eval-mode BatchNorm folded into the consumers' prologues, train-mode Dropout2d,
 the multi-scale pooling head as one kernel -- and `Dense` (:531-660, built in models/dehaze1113.py).
@@ -16,9 +16,9 @@ import torch.nn as nn
 from fdgan_hip import engine as E
 from fdgan_hip import lib as L
 from fdgan_hip.netplan import ChanStats, NetPlan
-from fdgan_hip.backward import grad_target
+from fdgan_hip.backward import autograd_grads, grad_target
 from models.dehaze1113 import (BottleneckBlock, TransitionBlock, _DensePyramid, _Named, _PlannedModule, _apply_plan_function,
-                               _permuted_final_grad, _plan_backward, _pyramid_sink, _wants_grad)
+                               _bump_generation, _check_generation, _permuted_final_grad, _plan_backward, _pyramid_sink, _wants_grad)
 
 
 def blockUNet(in_c, out_c, name, transposed=False, bn=False, relu=True, dropout=False):
@@ -190,7 +190,8 @@ class _Stats:
 
 
 class _UNet(_PlannedModule):
-    """The 8-level pix2pix U-Net shared by `G` and `G2` (dehaze22.py:205-362, :364-488), forward only.
+    """The 8-level pix2pix U-Net shared by `G` and `G2` (dehaze22.py:205-362, :364-488); `loss.backward()` works in train mode
+    (`_autograd_backward`).
 
     Buffers (NHWC bf16): level k = 1..7 owns ONE concat buffer cat_k = [dout_{k+1} | out_k] at H / 2^k -- the encoder conv of
     level k stores out_k into its right half, the decoder's transposed conv of level k+1 stores dout_{k+1} into the left
@@ -539,7 +540,7 @@ class Dense(_DensePyramid):
 
 
 class dehaze(_PlannedModule):
-    """dehaze22.py:662-753, forward only: transmission t = Dense(x), airlight A = G2(x) pooled over H x H windows, the
+    """dehaze22.py:662-753 (forward, and backward in train mode): transmission t = Dense(x), airlight A = G2(x) pooled over H x H windows, the
     scattering model inverted per pixel, J = (x - A) / (|t| + 1e-10) + A, then refine1 / refine2, the four-scale head and
     tanh(refine3).  Returns (dehaze, tran, atp, dehaze2) like the reference.  `tran_est` (a G) is registered and never called
     (:665), as there.  The two sub-networks run their own plans; the plan here is the tail."""
@@ -573,8 +574,11 @@ class dehaze(_PlannedModule):
         P.pw = torch.zeros((4, 20), dtype=torch.float32, device=dev)
         P.pb = torch.zeros((4,), dtype=torch.float32, device=dev)
         x20, y4 = E.View(P.head, 0, 20), E.View(P.head, 20, 4)
-        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4))
+        P.op(lambda: E.pyramid_pool4(x20, P.pw, P.pb, 32, 0.2, y4),
+             record=dict(kind="pyramid", src=x20, dst=y4, w=P.pw, b=P.pb, k0=32, slope=0.2,
+                         sink=_pyramid_sink([getattr(self, nm) for nm in ("conv1010", "conv1020", "conv1030", "conv1040")])))
         P.wfinal = torch.zeros((3, 24, 3, 3), dtype=torch.float32, device=dev)
+        P.wfinal.requires_grad_(self.refine3.weight.requires_grad)
         P.out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
         P.conv(E.View(P.head), P.weight(P.wfinal, 3, 24, 3), None, 3, pad=1, bias=self.refine3.bias, e_act=L.ACT_TANH,
                y_fd=E.nchw_f32_view(P.out), label="refine3")
@@ -583,15 +587,28 @@ class dehaze(_PlannedModule):
         return P.finish()
 
     def forward(self, x):
-        if _wants_grad(self, x):
-            raise NotImplementedError("models.dehaze22.dehaze runs forward only on the HIP path (legacy DCPDN network, SURVEY 8f rank 4): "
-                                      "call it under torch.no_grad()")
         if x.shape[3] < x.shape[2]:
             raise ValueError("dehaze pools the airlight over H x H windows (dehaze22.py:705): W >= H required, got %dx%d" % tuple(x.shape[2:]))
+        if _wants_grad(self, x):
+            # autograd composes the three pieces: the two sub-networks are planned modules with their own reverse walks, the tail
+            # (scattering model + refinement) is one more autograd.Function; `tran` is returned as the sub-network produced it
+            if x.requires_grad:
+                raise NotImplementedError("models.dehaze22.dehaze: the gradient w.r.t. the input image is not produced on the HIP path")
+            xf = x.detach().float().contiguous()
+            tran = self.tran_dense(xf)
+            atp_raw = self.atp_est(xf)
+            params = tuple(p for nm, p in self.named_parameters() if p.requires_grad and not nm.startswith(("tran_dense.", "atp_est.", "tran_est.")))
+            out, atp, dehaze2 = _DehazeTail.apply(self, xf, tran, atp_raw, *params)
+            return out, tran, atp, dehaze2
         with torch.no_grad():
             xf = x.detach().float().contiguous()
             tran = self.tran_dense(xf)
             atp_raw = self.atp_est(xf)
+            return self._tail(xf, tran, atp_raw)[1]
+
+    def _tail(self, xf, tran, atp_raw):
+        """Scattering model + refinement on finished sub-network outputs (no autograd): (plan, (dehaze, tran, atp, dehaze2))."""
+        with torch.no_grad():
             P = self._plan_for(xf)
             for i, nm in enumerate(("conv1010", "conv1020", "conv1030", "conv1040")):
                 conv = getattr(self, nm)
@@ -605,4 +622,41 @@ class dehaze(_PlannedModule):
             atp, dehaze2 = torch.empty_like(xf), torch.empty_like(xf)
             E.scatter_dehaze(xf, tran, atp_raw, 0.2, 1e-10, P.wmean, atp, dehaze2, E.View(P.cat6))
             P.launch()
-            return P.out.clone(), tran, atp, dehaze2
+            return P, (P.out.clone(), tran, atp, dehaze2)
+
+    def _tail_backward(self, P, xf, tran, atp_raw, out, g_out, g_atp, g_dehaze2):
+        """Reverse of `_tail`: the refinement plan walked in reverse, then the scattering model (csrc/legacy_bwd.hip)."""
+        B = _plan_backward(P)
+        B.zero_()
+        n, c, h, w = out.shape
+        g8 = E.new_grad(n, h, w, 8, out.device)
+        E.out_act_bwd(g_out, out, L.ACT_TANH, E.View(g8))                  # tanh(refine3(.)) (:752)
+        last = P.records[-1]
+        assert last["kind"] == "conv" and last["y"] is None
+        last["_dy"] = E.View(g8, 0, 3)
+        grads = {}
+        B.run(grads)
+        _permuted_final_grad(P, grads, self.refine3)
+        d_tran, d_atp = E.scatter_dehaze_bwd(xf, tran, atp_raw, P.wmean, 0.2, 1e-10, g_dehaze2, g_atp, B.G(E.View(P.cat6)))
+        return d_tran, d_atp, grads
+
+
+class _DehazeTail(torch.autograd.Function):
+    """The part of `dehaze` between its sub-networks' outputs and its own: (x, tran, atp_raw) -> (dehaze, atp, dehaze2)."""
+
+    @staticmethod
+    def forward(ctx, module, xf, tran, atp_raw, *params):
+        tran_c, atp_c = tran.detach().contiguous(), atp_raw.detach().contiguous()
+        P, (out, _, atp, dehaze2) = module._tail(xf, tran_c, atp_c)
+        ctx.module, ctx.plan, ctx.params = module, P, params
+        ctx.gen = _bump_generation(P)
+        ctx.save_for_backward(xf, tran_c, atp_c, out)
+        return out, atp, dehaze2
+
+    @staticmethod
+    def backward(ctx, g_out, g_atp, g_dehaze2):
+        _check_generation(ctx.plan, ctx.gen)
+        xf, tran, atp_raw, out = ctx.saved_tensors
+        f = lambda g: g.detach().float().contiguous()
+        d_tran, d_atp, grads = ctx.module._tail_backward(ctx.plan, xf, tran, atp_raw, out, f(g_out), f(g_atp), f(g_dehaze2))
+        return (None, None, d_tran, d_atp) + autograd_grads(grads, ctx.params)

@@ -1490,3 +1490,48 @@ def test_legacy_unets_backward(kind):
     _assert_legacy_grads(summary)
     with pytest.raises(NotImplementedError):
         net(x.to(DEV).requires_grad_(True))
+
+
+def test_legacy_dehaze_backward(golden_dir):
+    """SURVEY 8f rank 4, reverse mode: `dehaze` (dehaze22.py:662-753) under autograd -- Dense and G2 as planned modules with their own
+    reverse walks, the scattering model J = (I - A) / (|t| + eps) + A and the refinement tail as one more autograd.Function -- with a
+    cotangent on each of the four outputs; every parameter against torch.autograd over the fp32 oracle, the tail's convolutions op
+    by op against torch.autograd on the same tensors.  `tran_est` (registered, never called, :665) must stay without gradients."""
+    import models.dehaze22 as net22
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = net22.dehaze(3, 3, 64)
+    fill_state_dict(net, seed=8)
+    with torch.no_grad():
+        net.tran_dense.refine3.weight.mul_(0.05), net.tran_dense.refine3.bias.fill_(1.0), net.refine3.weight.mul_(0.02)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV).train()
+    x = det_input((4, 3, 256, 256), seed=41)
+    cots = [det_input((4, 3, 256, 256), seed=50 + i, lo=-1.0, hi=1.0) * sc for i, sc in enumerate((1.0, 0.3, 0.3, 0.3))]
+    torch.manual_seed(4)
+    masks = [(torch.rand(4, 64) > 0.5).float() * 2.0 for _ in range(3)]
+    ref = _functional_grads(lambda sdg: legacy_ref.dehaze_forward(sdg, x.clone(), True, list(masks))[:4], sd, x, cots)
+    net.atp_est.__dict__["_forced_dropout_masks"] = [m.to(DEV) for m in masks]
+    ys = net(x.to(DEV))
+    assert len(ys) == 4 and all(t.requires_grad and t.shape == (4, 3, 256, 256) for t in ys)
+    sum((y * c.to(DEV)).sum() for y, c in zip(ys, cots)).backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is None for p in net.tran_est.parameters())
+    summary = _legacy_grad_summary(net, ref, ("refine3.weight", "refine1.weight", "refine2.bias", "conv1020.weight", "tran_dense.refine3.weight",
+                                              "tran_dense.conv0.weight", "atp_est.dlayer1.dlayer1.tconv.weight", "atp_est.layer1.layer1.weight"))
+    from models.dehaze1113 import _plan_backward
+    with torch.no_grad():
+        P = net._plan_for(x.to(DEV))
+    B = _plan_backward(P)
+    B.checks, B.check_reference = [], hiputil_op_reference
+    net.zero_grad()
+    ys = net(x.to(DEV))
+    sum((y * c.to(DEV)).sum() for y, c in zip(ys, cots)).backward()
+    torch.cuda.synchronize()
+    checks, B.checks = B.checks, None
+    summary.update(ops_checked=len(checks), op_dw_worst=max(o["dw"] for o in checks), op_dx_worst=max(o.get("dx", 0.0) for o in checks))
+    _report("legacy_dehaze_backward", summary)
+    assert summary["ops_checked"] == 3 and summary["op_dw_worst"] < 5e-3 and summary["op_dx_worst"] < 3e-2, summary
+    _assert_legacy_grads(summary)
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV).requires_grad_(True))
