@@ -191,5 +191,9 @@ class NetPlan:
 
 
 def bn_flags(module):
-    """Cache key part: the train/eval state of every BatchNorm under `module`."""
-    return tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+    """Cache key part: the train/eval state of every BatchNorm under `module`.  The list of norms is found once per module
+    (walking 800 sub-modules per forward call was 0.4 ms of host time, four times per training step)."""
+    bns = module.__dict__.get("_fd_bn_list")
+    if bns is None or bns[0] != len(module._modules):
+        bns = module.__dict__["_fd_bn_list"] = (len(module._modules), [m for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)])
+    return tuple(m.training for m in bns[1])

