@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
 // pixels (6 %); row halo per segment: 14 rows.  Rows are requested FS_PF ahead so a wave has several loads in flight.
 constexpr int FSR_W = 256, FSR_PF = 3;
 
+
 struct FsRowArgs {
   const float* x;
   float* y;
@@ -127,11 +128,25 @@ __device__ __forceinline__ float fsr_at(const float* plane, int y, int x, int H,
   return (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] : 0.f;
 }
 
-template <int R>
+// Lane crossing by DPP instead of the LDS line (DPP = true): lane i takes the 4-pixel piece of lane i - 1 / i + 1 with ONE
+// v_mov_b32_dpp wave_shr:1 / wave_shl:1 per component (a whole-wave shift: gfx9's DPP has it; lane 0 / 63 keep `old`, which
+// is the halo piece read out of the edge lanes with v_readlane), and the pieces two lanes away by shifting the shifted value
+// once more: 16 DPP moves + 16 readlanes per row against one 16-byte LDS write and five 16-byte LDS reads.
+__device__ __forceinline__ float fs_wave_shr1(float old, float v) {   // lane i <- lane i - 1; lane 0 <- old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fs_wave_shl1(float old, float v) {   // lane i <- lane i + 1; lane 63 <- old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fs_lane(float v, int k) {             // the value lane k holds, in every lane
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
+template <int R, bool DPP>
 __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
   constexpr bool BLUR = R == 7;
   constexpr int NTAP = 2 * R + 1;
-  __shared__ __attribute__((aligned(16))) float line[8 + FSR_W + 8];
+  __shared__ __attribute__((aligned(16))) float line[DPP ? 4 : 8 + FSR_W + 8];
   const int lane = threadIdx.x;
   int item = blockIdx.x;
   const int strip = item % a.strips;
@@ -179,18 +194,30 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
       if (iy >= last) continue;          // (a `break` here kept the loop rolled: the ring went to scratch memory)
       const f4 v = pv[j % FSR_PF], hv = ph[j % FSR_PF];
       fetch(iy + FSR_PF, pv[j % FSR_PF], ph[j % FSR_PF]);     // FSR_PF rows ahead (rows past `last` are harmless reads inside the plane / zeros)
-      // the row through the wave's LDS line (one wave: LDS operations complete in program order)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      *reinterpret_cast<f4*>(&line[8 + 4 * lane]) = v;
-      if (lane < 4) *reinterpret_cast<f4*>(&line[hslot]) = hv;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       float win[20];                                    // columns cx - 8 .. cx + 11
+      if (DPP) {
+        // pieces of lanes i - 2, i - 1, i, i + 1, i + 2; past the wave's ends: the halo pieces lanes 0 .. 3 fetched
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const f4 t = *reinterpret_cast<const f4*>(&line[4 * lane + 4 * q]);
-        win[4 * q] = t[0], win[4 * q + 1] = t[1], win[4 * q + 2] = t[2], win[4 * q + 3] = t[3];
+        for (int e = 0; e < 4; ++e) {
+          const float m1 = fs_wave_shr1(fs_lane(hv[e], 1), v[e]);        // lane 0 <- left halo piece x0 - 4 .. x0 - 1
+          const float m2 = fs_wave_shr1(fs_lane(hv[e], 0), m1);          // lane 0 <- x0 - 8 .. x0 - 5, lane 1 <- lane 0's m1
+          const float p1 = fs_wave_shl1(fs_lane(hv[e], 2), v[e]);        // lane 63 <- right halo piece x0 + 256 .. + 259
+          const float p2 = fs_wave_shl1(fs_lane(hv[e], 3), p1);
+          win[e] = m2, win[4 + e] = m1, win[8 + e] = v[e], win[12 + e] = p1, win[16 + e] = p2;
+        }
+      } else {
+        // the row through the wave's LDS line (one wave: LDS operations complete in program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        *reinterpret_cast<f4*>(&line[8 + 4 * lane]) = v;
+        if (lane < 4) *reinterpret_cast<f4*>(&line[hslot]) = hv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          const f4 t = *reinterpret_cast<const f4*>(&line[4 * lane + 4 * q]);
+          win[4 * q] = t[0], win[4 * q + 1] = t[1], win[4 * q + 2] = t[2], win[4 * q + 3] = t[3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       f4 hsum;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -305,8 +332,17 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
     r.seg_rows = (int)((a.H + segs - 1) / segs);
     r.segs = (a.H + r.seg_rows - 1) / r.seg_rows;
     const unsigned grid = (unsigned)(planes * r.strips * r.segs);
-    if (a.mode == 0) return fd_launch(&freqsplit_rows_kernel<7>, name, dim3(grid), dim3(64), 0, r, stream);
-    return fd_launch(&freqsplit_rows_kernel<1>, name, dim3(grid), dim3(64), 0, r, stream);
+    // Lane crossing: measured both ways (tools/freqsplit_bench.py, B=4 @1024^2 / B=16 @256^2, round 3).  Laplacian (3 taps: the
+    // crossing IS the kernel): DPP wave shifts 21.6 / 8.4 us (4.66 / 3.0 TB/s) against 24.2 / 10.7 us through the LDS line.
+    // Blur (15 taps): 45.9 us with DPP against 41.9 us -- its row costs 160 vector instructions either way (60 v_pk_fma_f32 and
+    // as many register moves pairing the sliding window for them), it is ALU-bound at 3 waves per SIMD, and the 32 extra
+    // v_mov_dpp / v_readlane per row cost more than the five ds_read_b128 whose latency the other waves hide.
+    static const char* dpp_env = FD_TUNE_GETENV("FDGAN_DEBUG_FS_DPP");   // tuning aid: '0' the LDS line, '1' DPP wave shifts
+    const bool dpp = dpp_env ? dpp_env[0] == '1' : a.mode == 1;
+    if (a.mode == 0) return dpp ? fd_launch(&freqsplit_rows_kernel<7, true>, name, dim3(grid), dim3(64), 0, r, stream)
+                                : fd_launch(&freqsplit_rows_kernel<7, false>, name, dim3(grid), dim3(64), 0, r, stream);
+    return dpp ? fd_launch(&freqsplit_rows_kernel<1, true>, name, dim3(grid), dim3(64), 0, r, stream)
+               : fd_launch(&freqsplit_rows_kernel<1, false>, name, dim3(grid), dim3(64), 0, r, stream);
   }
   return fd_launch(&freqsplit_kernel, name, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)planes), dim3(256), 0, a,
                    stream);
