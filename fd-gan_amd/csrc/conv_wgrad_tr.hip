@@ -583,8 +583,26 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) 
 #define inv(k) invb[(k) * 192]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ci0 = blockIdx.x * 48, co0 = (int)blockIdx.z * 32;
-  const int item = blockIdx.y;
+  // XCD-aware work numbering.  The 27 workgroups of one item (3 cin tiles x 9 cout slices for D's 144 -> 288) read the SAME x and
+  // dy rows; as a (3, items, 9) grid they were dispatched round-robin over the 8 XCDs and far apart in time, and every one of
+  // them pulled its rows from HBM: rocprofv3 FETCH_SIZE 2.29 GB per launch for 224 MB of input (round 2's PMC file).  Launched
+  // 1-D, workgroup L goes to XCD L % 8 and is that XCD's (L / 8)-th: consecutive slots of one XCD walk the 27 pieces of one
+  // item, so the rows are fetched once into that XCD's L2 and hit there 26 times.
+  const int vgx = a.vgx, vgz = a.vgz;
+  int bx, bz, item;
+  {
+    const int L = (int)blockIdx.x, per = vgx * vgz, slot = L >> 3;
+    const int it8 = slot / per;
+    int sub = slot - it8 * per;
+    item = it8 * 8 + (L & 7);
+    if (a.dbg_skip & 256) {                          // tuning aid: the plain (cin tile, item, cout slice) order of a 3-D grid
+      sub = (L % vgx) + vgx * (L / (vgx * ((a.vgy + 7) / 8 * 8)));
+      item = (L / vgx) % ((a.vgy + 7) / 8 * 8);
+    }
+    if (item >= a.vgy) return;                       // padding of the last group of 8 items (whole workgroup)
+    bx = sub % vgx, bz = sub / vgx;
+  }
+  const int ci0 = bx * 48, co0 = bz * 32;
   const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
   const int y_begin = seg * a.seg_rows, y_end = min(a.Ho, y_begin + a.seg_rows);
   const int nsteps = y_end - y_begin + 3;          // input rows y_begin - 1 .. y_end + 1
@@ -763,7 +781,7 @@ __global__ __launch_bounds__(192, 2) void conv_wgrad_r4_kernel(WgradRowsArgs a) 
     step(j + 3, IC<3>{});
   }
   r3_wait_vm<0>();
-  float* blk = a.part + ((((long long)item * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * 3 + wave) * (16 * 512) + lane;
+  float* blk = a.part + ((((long long)item * vgx + bx) * vgz + bz) * 3 + wave) * (16 * 512) + lane;
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
@@ -944,7 +962,7 @@ int r4_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   a.segs = (int)((a.Ho + a.seg_rows - 1) / a.seg_rows);
   a.part = workspace;
   a.bias_part = nullptr;
-  a.dbg_skip = 0;
+  a.dbg_skip = FD_TUNE_GETENV("FDGAN_DEBUG_R4_PLAIN") != nullptr ? 256 : 0;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_r4_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -952,7 +970,9 @@ int r4_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
     attr_done = true;
   }
   const long long items = strips * a.segs;
-  if (int rc = fd_launch(&conv_wgrad_r4_kernel<RELU>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(192), R4_LDS, a, stream))
+  a.vgx = (int)ci_tiles, a.vgy = (int)items, a.vgz = (int)zt;
+  const long long grid1 = (items + 7) / 8 * 8 * ci_tiles * zt;
+  if (int rc = fd_launch(&conv_wgrad_r4_kernel<RELU>, name, dim3((unsigned)grid1), dim3(192), R4_LDS, a, stream))
     return rc;
   TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, 1, 4, 4, 3, 16, a.Cin, a.Cout, accumulate, 0, item_stride / 64};
   if (job) *job = r;
