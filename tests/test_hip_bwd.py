@@ -437,6 +437,42 @@ def test_weight_gradient_is_bitwise_reproducible_at_full_size(E, n, cin, cout, h
     assert rel_rms(outs[0].cpu(), wref.grad.cpu()) < 2e-3
 
 
+def test_deferred_weight_gradient_reductions_are_bitwise_the_immediate_ones(E):
+    """fdgan_conv2d_bwd_weight_job(defer) + ONE fdgan_wgrad_tr_reduce_batch over a table of jobs (what a backward walk does for its
+    row-walking weight gradients, include/fdgan_hip.h ABI v9) against the per-conv launch with its own reduction: three shapes in
+    one table (the growth conv, D's 4x4 144 -> 288, D's 3x3 72 -> 144), accumulate on and off -- bitwise equal."""
+    from fdgan_hip import lib as L
+    torch.manual_seed(1)
+    cases = [(2, 128, 32, 128, 128, 3, False), (2, 144, 288, 63, 63, 4, True), (2, 72, 144, 64, 64, 3, False)]
+    jobs, keep, want, got = [], [], [], []
+    for n, cin, cout, h, w, k, acc in cases:
+        pad = 1
+        ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+        x = torch.randn(n, h, w, cin, device=DEV).to(torch.float16)
+        dy = (torch.randn(n, ho, wo, cout, device=DEV) * 0.1).to(torch.bfloat16)
+        pro = E.make_prologue(act=L.ACT_RELU)
+        desc = E.conv_desc(k, 1, pad, cout=cout)
+        base = torch.randn(cout, cin, k, k, device=DEV) if acc else torch.zeros(cout, cin, k, k, device=DEV)
+        ref, out = base.clone(), base.clone()
+        ws0 = torch.empty(1 << 25, dtype=torch.float32, device=DEV)
+        info = E.conv_bwd_weight_job(E.View(x).fd, pro, E.View(dy).fd, desc, ref, ws0, False, acc)      # immediate: launches its reduction
+        assert info is not None, "shape left the row-walking kernels"
+        ws1 = torch.full((info.items * info.item_stride,), float("nan"), dtype=torch.float32, device=DEV)   # exactly what the job needs
+        job = E.conv_bwd_weight_job(E.View(x).fd, pro, E.View(dy).fd, desc, out, ws1, True, acc)          # deferred: partial sums only
+        assert job is not None and job.items == info.items and job.item_stride == info.item_stride
+        torch.cuda.synchronize()
+        assert torch.equal(out, base)                      # nothing reduced yet
+        jobs.append(job)
+        keep += [x, dy, ws1, out]
+        want.append(ref)
+        got.append(out)
+    table = E.TrReduceTable(jobs, keep, torch.device(DEV))
+    table.launch()
+    torch.cuda.synchronize()
+    for (n, cin, cout, h, w, k, acc), a, b in zip(cases, want, got):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b), (cin, cout, k, float((a - b).abs().max()))
+
+
 def test_streaming_kernels_are_reproducible_beside_a_busy_second_stream(E):
     """The training step runs two HIP streams, so every hand-pipelined kernel shares CUs with another kernel's waves -- among
     them the filter-direct convolutions, which raise their wave priority around the MFMA blocks.  A wave that is held back at
