@@ -56,6 +56,14 @@ TR_DEFER_MAX = 1 << 24      # floats (64 MiB) of partial sums a record may keep 
 PROGRESS_HOOK = None
 
 
+def _constant_entries(meta, cin):
+    """Channel ranges of a BatchNorm prologue whose (mean, var) are CONSTANTS rather than statistics of the batch: the whole norm in
+    eval mode (running statistics), the `identity` entries of a side-by-side table (models/dehaze22.py).  There the backward is
+    dx = gamma * rstd * dpre: dgamma / dbeta are formed as always (the norm's own parameters still learn), the two correction
+    terms -dbeta / M - xhat * dgamma / M, which differentiate the statistics, do not exist."""
+    return meta.get("identity", ()) if meta.get("batch_stats", False) else ((0, cin),)
+
+
 def grad_sink(p):
     """The fp32 tensor gradients of `p` may be added into directly, or None: FlatAdam marks its parameters with
     `_fd_grad_sink` (= their `.grad` view); anything else goes through autograd's own accumulation."""
@@ -374,8 +382,6 @@ class PlanBackward:
         ddesc = E.conv_desc(k, 1, k - 1 - pad, cout=cin, w_layout=L.WLAYOUT_CHUNK32)
         fusable = not meta["pool"] and x.c0 % 8 == 0 and self.fuse_mask
         bn = meta.get("bn")
-        if fusable and bn is not None and not meta.get("batch_stats", False):
-            raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
         if fusable:
             mask_act = meta["act"]
             if self.relu_premask and bn is None and mask_act == L.ACT_NONE and r.get("_post_relu", False):
@@ -429,7 +435,7 @@ class PlanBackward:
                                        d["coef"][1, x.c0:x.c0 + cin],
                                        sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                                        sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
-                for lo, hi in meta.get("identity", ()):      # table entries that are constants, not batch statistics: no
+                for lo, hi in _constant_entries(meta, cin):  # table entries that are constants, not batch statistics: no
                     d["coef"][:, x.c0 + lo:x.c0 + hi].zero_()  # correction terms (finished values behind a BatchNorm + Dropout2d pass)
                 d["dirty"].update(range(x.c0, x.c0 + cin))
             if check:
@@ -497,7 +503,7 @@ class PlanBackward:
         Tv = E.View(T, 0, cin)
         gx = self.G(x)
         bn = meta.get("bn")
-        if meta["pool"] and bn is not None and meta.get("batch_stats", False):
+        if meta["pool"] and bn is not None:
             # pooled prologue (transitions): T is the gradient w.r.t. the 2x2-averaged activation at HALF resolution.  Two
             # passes over the full-resolution input, both un-pooling and masking on the fly: the sums, then dx -- no
             # full-resolution dpre tensor (it was written, masked in place and re-read: four more passes)
@@ -509,6 +515,9 @@ class PlanBackward:
             rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn)
             E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                               sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            for lo, hi in _constant_entries(meta, cin):
+                dg[lo:hi].zero_()
+                dbt[lo:hi].zero_()
             E.bn_bwd_apply(Tv.fd, x.fd, pool_pro, dg, dbt, gx.fd, accumulate=True)
             if check:
                 self._finish_check(rec, x, gx_before, dx_ref)
@@ -518,8 +527,6 @@ class PlanBackward:
             E.grad_ew(E.GRAD_UNPOOL, Tv, E.View(T2, 0, cin))
             T, Tv = T2, E.View(T2, 0, cin)
         if bn is not None:
-            if not meta.get("batch_stats", False):
-                raise NotImplementedError("backward through eval-mode BatchNorm (the reference trains in train mode)")
             act_pro = E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
                                       beta=meta["beta"], eps=meta["eps"])
             dg = torch.empty(cin, dtype=torch.float32, device=p.device)
@@ -533,7 +540,7 @@ class PlanBackward:
             else:
                 rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
                 E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, **sinks)
-            for lo, hi in meta.get("identity", ()):      # constants, not batch statistics (see conv_backward): dx = A * dpre there
+            for lo, hi in _constant_entries(meta, cin):  # constants, not batch statistics (see conv_backward): dx = A * dpre there
                 dg[lo:hi].zero_()
                 dbt[lo:hi].zero_()
             E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
@@ -566,6 +573,9 @@ class PlanBackward:
             train_bn = bn.weight is not None and bn.weight.requires_grad
             E.bn_bwd_finalize(self.ws_bn, rows, cpad, src.c, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                               sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
+            for lo, hi in _constant_entries(pro._meta, src.c):
+                dg[lo:hi].zero_()
+                dbt[lo:hi].zero_()
             E.bn_bwd_apply(gs.fd, src.fd, pro, dg, dbt, gs.fd, accumulate=False)
 
     # ---- the whole plan ------------------------------------------------------------------------

@@ -427,9 +427,7 @@ class FDGAN(_PlannedModule):
         """Gradients of every parameter that receives one (11.8 M of 13.98 M; conv0, dense_block31, dense_norm31
         and the dy blocks' bn1/bn2 never do).  The gradient w.r.t. the input image is not produced
         (returns None): the generator's input is data."""
-        if not self.training:
-            raise NotImplementedError("FDGAN backward is built for train-mode BatchNorm (the reference never calls .eval())")
-        P, out = state
+        P, out = state      # train- or eval-mode BatchNorm (eval: running statistics are constants, backward.py:_constant_entries)
         B = _plan_backward(P)
         B.zero_()
         n, _, h, w = out.shape
@@ -626,11 +624,9 @@ class _DenseBase(_PlannedModule):
         return out, (P, out)
 
     def _autograd_backward(self, state, dout):
-        """torch.autograd through dehaze1113.py:431-570 / :572-699 (dehaze22.py:531-660), train-mode BatchNorm: the recorded plan
+        """torch.autograd through dehaze1113.py:431-570 / :572-699 (dehaze22.py:531-660), train- or eval-mode BatchNorm: the recorded plan
         walked in reverse (fdgan_hip/backward.py) -- the encoder's and decoder's dense blocks on the generator's own backward
         kernels, the stem's MaxPool2d(3, 2, 1) and the four-scale head on csrc/legacy_bwd.hip."""
-        if not self.training:
-            raise NotImplementedError("%s backward is built for train-mode BatchNorm" % type(self).__name__)
         P, out = state
         B = _plan_backward(P)
         B.zero_()
@@ -871,8 +867,6 @@ class D(_PlannedModule):
         (fdgan_hip/backward.py); the gradient w.r.t. the 9-channel input -- what the generator's adversarial loss
         needs -- comes from the any-stride direct kernel (layer1 is 4x4 stride 2)."""
         P, out, need_dx = state
-        if not (self.main.layer2.layer2.bn.training and self.main.layer3.layer3.bn.training):
-            raise NotImplementedError("D backward is built for train-mode BatchNorm (the reference never calls .eval())")
         B = _plan_backward(P)
         B.zero_()
         n, _, h5, w5 = out.shape

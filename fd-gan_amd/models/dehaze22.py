@@ -112,8 +112,6 @@ class D(_PlannedModule):
         """dehaze22.py:114-156 under autograd (train-mode BatchNorm).  The 4x4 stride-2 data gradients use the
         any-stride direct kernel."""
         P, out, need_dx = state
-        if not self.main.layer4.bn.training:
-            raise NotImplementedError("dehaze22.D backward is built for train-mode BatchNorm")
         B = _plan_backward(P)
         B.zero_()
         n, _, h5, w5 = out.shape
