@@ -18,6 +18,16 @@ def timed(x_fd, pro, dy_fd, desc, dw, dbias=None, ws=None, accumulate=False):
     rec.append(((int(x_fd.n), int(dy_fd.h), int(dy_fd.w), int(x_fd.c), int(dy_fd.c), int(desc.ksize), int(desc.stride), pool,
                  ws is not None), e0, e1))
 E.conv_bwd_weight = timed
+orig_job = E.conv_bwd_weight_job
+def timed_job(x_fd, pro, dy_fd, desc, dw, ws, defer, accumulate=False):
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    r = orig_job(x_fd, pro, dy_fd, desc, dw, ws, defer, accumulate)
+    e1.record()
+    rec.append(((int(x_fd.n), int(dy_fd.h), int(dy_fd.w), int(x_fd.c), int(dy_fd.c), int(desc.ksize), int(desc.stride), False, True), e0, e1))
+    return r
+E.conv_bwd_weight_job = timed_job
+os.environ["FDGAN_NO_WGRAD_STREAM"] = "1"      # events of a launch on the walk's own stream
 import fdgan_hip.backward as BW
 BW.E = E
 
