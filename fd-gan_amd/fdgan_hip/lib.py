@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class FdganLibraryError(RuntimeError):
@@ -101,6 +101,10 @@ SIGNATURES = {
                                        C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdgan_scatter_dehaze_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                            C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "fdgan_allreduce_unique_id": (C.c_int, [C.c_void_p]),
+    "fdgan_allreduce_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdgan_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "fdgan_allreduce_comm_destroy": (C.c_int, [C.c_void_p]),
     "fdgan_plan_create": (C.c_void_p, []),
     "fdgan_plan_destroy": (None, [C.c_void_p]),
     "fdgan_plan_begin": (C.c_int, [C.c_void_p]),

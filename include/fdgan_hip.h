@@ -32,17 +32,14 @@
  *    stride[2] (the pixel pitch) must be a multiple of 8 elements and ptr 16-byte
  *    aligned.  Network input / output may be NCHW fp32 (dtype FD_F32).
  *
- * What is deliberately NOT behind this boundary: the data-parallel gradient exchange.
- * The reference's only multi-GPU mechanism is nn.DataParallel (demo.py:89); a trainer
- * built on it would reduce gradients with torch.distributed.  The training path here
- * keeps parameters and gradients in two flat fp32 buffers (fdgan_adam_step below
- * takes exactly those), so the exchange is a handful of large torch.distributed
- * all_reduce calls on slices of one buffer -- RCCL on its own stream, overlapped with
- * the backward walk (fdgan_hip/optim.py: FlatAdam.overlap).  An fdgan_allreduce_*
- * entry point would have to own an ncclComm_t, a bootstrap (ncclUniqueId exchange)
- * and a stream: state and rendezvous the host framework already has, with nothing
- * for a gfx950 kernel to add.  A host that is not PyTorch calls ncclAllReduce on the
- * same two buffers.
+ * The data-parallel gradient exchange (fdgan_allreduce_*; the reference's only multi-GPU mechanism is
+ * nn.DataParallel, demo.py:89).  The training path keeps parameters and gradients in two flat fp32 buffers
+ * (fdgan_adam_step below takes exactly those), so the exchange is a handful of large sums over slices of one
+ * buffer.  The Python host of this repository issues them through torch.distributed -- RCCL on its own stream,
+ * overlapped with the backward walk (fdgan_hip/optim.py: FlatAdam.overlap): the framework already owns the
+ * communicator and the rendezvous.  A host that is NOT PyTorch uses the four entry points at the end of this
+ * header: a thin wrapper of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy, RCCL looked up
+ * with dlopen at the first call (no link-time dependency).
  */
 #ifndef FDGAN_HIP_H
 #define FDGAN_HIP_H
@@ -54,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 9
+#define FDGAN_ABI_VERSION 10
 
 enum FdStatus {
   FD_OK = 0,
@@ -525,6 +522,17 @@ int fdgan_debug_timing(void* device_buf);
  * per sample, may be NULL) its launcher name, and disarms.  One timer per process; not thread-safe. */
 int fdgan_kernel_timer_arm(const char* name, int stride, int max_samples);
 int fdgan_kernel_timer_read(int capacity, int* n_out, int* matching_launches_out, int* call_index, float* ms, char* names48);
+
+/* ---- data-parallel gradient exchange for non-PyTorch hosts (csrc/allreduce.hip) ----------------------------------
+ * One process per GPU.  Rank 0 obtains the 128-byte id and hands it to the other ranks out of band (file, TCP, an
+ * existing store); every rank then creates its communicator (collective: all `world` ranks must call), sums its
+ * gradient buffer IN PLACE on its own stream (asynchronous; divide by `world` afterwards, e.g. in the optimizer step)
+ * and destroys the communicator at exit.  FD_EUNSUPPORTED when librccl.so cannot be loaded. */
+#define FDGAN_ALLREDUCE_ID_BYTES 128
+int fdgan_allreduce_unique_id(void* id128);
+int fdgan_allreduce_comm_create(const void* id128, int rank, int world, void** comm);
+int fdgan_allreduce_sum_f32(void* comm, float* buf, int64_t count, FdStream stream);
+int fdgan_allreduce_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -140,3 +140,31 @@ def test_bench_py_single_rank_through_rccl(tmp_path):
     ex = d["config"]["gradient_exchange"]
     assert ex["backend"] == "nccl" and ex["rccl_ranks"] == 1 and ex["bytes_per_step"] > 4e7 and ex["isolated_ms_per_step"] > 0
     assert len(ex["ms_per_step_by_rank"]) == 1 and all(abs(v) < 1e4 for v in d["config"]["last_losses"].values())
+
+
+@pytest.mark.gpu
+def test_c_abi_allreduce_one_rank_communicator():
+    """include/fdgan_hip.h fdgan_allreduce_*: the RCCL wrapper a non-PyTorch host would use for the gradient exchange,
+    as far as ONE GPU lets it be exercised: unique id, a world-size-1 communicator, an in-place fp32 sum on a side stream (the
+    identity at world 1), destroy; and the error path (bad rank) through fdgan_last_error."""
+    import ctypes as C
+    import torch
+    from fdgan_hip import lib as L
+    lib = L.load()
+    ident = C.create_string_buffer(128)
+    L.check(lib.fdgan_allreduce_unique_id(ident), "allreduce_unique_id")
+    assert any(ident.raw), "empty unique id"
+    comm = C.c_void_p()
+    assert lib.fdgan_allreduce_comm_create(ident, 3, 2, C.byref(comm)) < 0 and b"rank" in lib.fdgan_last_error()
+    L.check(lib.fdgan_allreduce_comm_create(ident, 0, 1, C.byref(comm)), "allreduce_comm_create")
+    assert comm.value
+    dev = torch.device("cuda", 0)
+    buf = torch.arange(1 << 20, dtype=torch.float32, device=dev) * 0.5
+    want = buf.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        L.check(lib.fdgan_allreduce_sum_f32(comm, buf.data_ptr(), buf.numel(), side.cuda_stream), "allreduce_sum_f32")
+    side.synchronize()
+    assert torch.equal(buf, want)
+    L.check(lib.fdgan_allreduce_comm_destroy(comm), "allreduce_comm_destroy")
