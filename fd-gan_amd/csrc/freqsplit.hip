@@ -378,6 +378,12 @@ extern "C" int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t
   return launch(a, n * c, static_cast<hipStream_t>(stream), "laplacian3");
 }
 
+/* Laplacian's backward under autograd (loss.py:286-301): the operator is self-adjoint -- a symmetric 3x3 kernel with zero
+ * padding -- so dx = Laplacian(dy).  A separate entry point because SURVEY 8(b) names one and a binding reads better with it. */
+extern "C" int fdgan_laplacian3_bwd(const float* dy, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream) {
+  return fdgan_laplacian3_fwd(dy, dx, n, c, h, w, stream);
+}
+
 extern "C" int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w,
                                        const FdTensor* y, int use_input_norm, FdStream stream) {
   FD_REQUIRE(img && y && y->ptr, "fusion_input_nhwc: NULL pointer");

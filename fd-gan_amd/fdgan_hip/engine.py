@@ -246,6 +246,13 @@ def laplacian3(x):
     return y
 
 
+def laplacian3_bwd(dy):
+    n, c, h, w = dy.shape
+    dx = torch.empty_like(dy)
+    L.check(L.load().fdgan_laplacian3_bwd(dy.data_ptr(), dx.data_ptr(), n, c, h, w, stream_ptr()), "laplacian3_bwd")
+    return dx
+
+
 def fusion_input_nhwc(img, view, use_input_norm=True):
     """img: NCHW fp32 (n,c,h,w) -> channels [img | LF | HF] of the NHWC fp16 view (D's input)."""
     n, c, h, w = img.shape

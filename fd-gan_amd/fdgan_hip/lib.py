@@ -141,6 +141,7 @@ SIGNATURES = {
     "fdgan_blur15_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                    C.c_void_p]),
     "fdgan_laplacian3_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_laplacian3_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_fusion_input_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(FdTensor),
                                           C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_weight": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor),

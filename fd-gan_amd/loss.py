@@ -179,7 +179,7 @@ class _LaplacianFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return E.laplacian3(dy.detach().float().contiguous())     # self-adjoint: symmetric kernel, zero padding
+        return E.laplacian3_bwd(dy.detach().float().contiguous())     # self-adjoint: symmetric kernel, zero padding
 
 
 def fusion_input(img, use_input_norm=True):

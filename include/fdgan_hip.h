@@ -506,6 +506,8 @@ int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t
  * reflection halo back; `tmp` is n*c*h*w floats of caller-owned scratch. */
 int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w,
                      int use_input_norm, FdStream stream);
+/* dx = Laplacian(dy): the operator is self-adjoint (symmetric kernel, zero padding); loss.py:286-301 under autograd. */
+int fdgan_laplacian3_bwd(const float* dy, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
 int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w, const FdTensor* y,
                             int use_input_norm, FdStream stream);
 
