@@ -13,6 +13,11 @@ IV.A.1 version-1 object headers, messages 0x0001 dataspace, 0x0003 datatype, 0x0
 
 Supported datasets: fixed-point and IEEE floating point of 1 / 2 / 4 / 8 bytes, either endianness, contiguous or compact
 layout.  Chunked / filtered datasets raise NotImplementedError naming the dataset (the reference never writes them).
+
+UNVERIFIED AGAINST libhdf5: neither h5py nor any libhdf5 tool exists in the build image, so every fixture under tests/golden/h5
+was written by this module and the round trip reader <-> writer is all the tests can check; the byte layout was checked by
+hand against the format specification only.  `datasets/pix2pix.py` prefers h5py whenever it is importable; before relying on
+this module for real RESIDE files, read one h5py-written sample with it and open one file it wrote with h5py / h5dump.
 """
 import struct
 
