@@ -529,6 +529,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
   const int tid = threadIdx.x;
   const int grp = tid & 7, slot = tid >> 3;   // 8 channel groups (64 channels) x 32 pixels per pass
   const long long HW = (long long)a.H * a.W;
+  const unsigned HWu = (unsigned)HW, Wu = (unsigned)a.W;
   {   // one 64-channel chunk per blockIdx.y: the per-channel setup is paid once per workgroup
     const int c8_0 = blockIdx.y * 8;
     const int c8 = c8_0 + grp;
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
         const long long p = p0 + k * stride;
         dp[k] = nullptr;
         if (p < a.P) {
-          const long long n = p / HW, r = p - n * HW;
-          const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
+          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
           dp[k] = a.da + n * a.da_sn + (long long)(a.pool ? y >> 1 : y) * a.da_sh + (long long)(a.pool ? xx >> 1 : xx) * a.da_sw + c8 * 8;
           dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
           xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
@@ -705,6 +706,7 @@ struct BnApplyArgs {
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
   const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
   const long long HW = (long long)a.H * a.W;
+  const unsigned HWu = (unsigned)HW, Wu = (unsigned)a.W;
   {   // one 64-channel chunk per blockIdx.y
     const int c8 = blockIdx.y * 8 + grp;
     if (c8 >= a.C8) return;
@@ -732,8 +734,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
         const long long p = p0 + k * stride;
         op[k] = nullptr;
         if (p < a.P) {
-          const long long n = p / HW, r = p - n * HW;
-          const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
+          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
+          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
           dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)(a.pool ? y >> 1 : y) * a.dp_sh +
                                                   (long long)(a.pool ? xx >> 1 : xx) * a.dp_sw + c8 * 8);
           xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
@@ -1151,6 +1153,7 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
   a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
   a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
   a.P = (long long)x->n * x->h * x->w;
+  FD_REQUIRE(a.P < (1ll << 31), "bn_act_bwd: more than 2^31 pixels");
   fill_pro(pro, a.pro_mode, a.slope, a.eps, a.mean, a.var, a.gamma, a.beta);
   a.cpad = a.C8 * 8;
   long long rows = (a.P + 31) / 32;
@@ -1244,12 +1247,17 @@ struct AffineAccArgs {
   int H, W, C, C8;
   long long P;
   const float *bsum, *csum;
+  int gpp, dense;   // channel groups per pixel in a workgroup pass (<= 8); both views pixel-dense
 };
 __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
-  const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
-  const long long HW = (long long)a.H * a.W;
-  const int c8 = blockIdx.y * 8 + grp;
-  if (c8 >= a.C8) return;
+  // G channel groups x (256 / G) pixels per workgroup pass: a 32-channel slice (G = 4) keeps all 256 threads busy (the fixed
+  // 8 x 32 split left half of them idle); pixel offsets are p * pitch on pixel-dense views (every concat buffer is), 32-bit
+  // (image, row, column) arithmetic otherwise -- the 64-bit divisions of the first version were most of its instructions
+  const int G = a.gpp, ppp = 256 / G;
+  const int slot = (int)threadIdx.x / G, grp = (int)threadIdx.x - slot * G;
+  const int c8 = blockIdx.y * G + grp;
+  if (slot >= ppp || c8 >= a.C8) return;
+  const unsigned HWu = (unsigned)(a.H * a.W), Wu = (unsigned)a.W;
   float B[8], Cc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -1257,8 +1265,8 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
     B[e] = c < a.C ? a.bsum[c] : 0.f;
     Cc[e] = c < a.C ? a.csum[c] : 0.f;
   }
-  const long long stride = (long long)gridDim.x * 32;
-  for (long long p0 = (long long)blockIdx.x * 32 + slot; p0 < a.P; p0 += 4 * stride) {
+  const long long stride = (long long)gridDim.x * ppp;
+  for (long long p0 = (long long)blockIdx.x * ppp + slot; p0 < a.P; p0 += 4 * stride) {
     u32x4 xv[4], gv[4];
     unsigned short* op[4];
 #pragma unroll
@@ -1266,10 +1274,17 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
       const long long p = p0 + k * stride;
       op[k] = nullptr;
       if (p < a.P) {
-        const long long n = p / HW, r = p - n * HW;
-        const int y = (int)(r / a.W), xx = (int)(r - (long long)y * a.W);
-        xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
-        op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+        long long xo, go;
+        if (a.dense) {
+          xo = p * a.x_sw, go = p * a.dx_sw;
+        } else {
+          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;
+          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);
+          xo = n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw;
+          go = n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw;
+        }
+        xv[k] = *reinterpret_cast<const u32x4*>(a.x + xo + c8 * 8);
+        op[k] = a.dx + go + c8 * 8;
         gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
       }
     }
@@ -1305,8 +1320,13 @@ extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, con
   a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
   a.P = (long long)x->n * x->h * x->w;
   a.bsum = bsum, a.csum = csum;
-  const long long chunks = (a.C8 + 7) / 8;
-  long long rows = (a.P + 31) / 32, cap = 512 / chunks;
+  FD_REQUIRE(a.P < (1ll << 31), "affine_accumulate: more than 2^31 pixels");
+  auto pixel_dense = [](const FdTensor* t) { return t->stride[1] == t->w * t->stride[2] && t->stride[0] == t->h * t->stride[1]; };
+  a.dense = pixel_dense(x) && pixel_dense(dx) ? 1 : 0;
+  a.gpp = a.C8 < 8 ? a.C8 : 8;
+  const int ppp = 256 / a.gpp;
+  const long long chunks = (a.C8 + a.gpp - 1) / a.gpp;
+  long long rows = (a.P + ppp - 1) / ppp, cap = 1024 / chunks;      // ~4 workgroups per CU in all
   if (cap < 16) cap = 16;
   if (rows > cap) rows = cap;
   return fd_launch(&affine_acc_kernel, "affine_accumulate", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
@@ -1337,6 +1357,7 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   a.dx_sn = dx->stride[0], a.dx_sh = (int)dx->stride[1], a.dx_sw = (int)dx->stride[2];
   a.H = (int)x->h, a.W = (int)x->w, a.C = (int)x->c, a.C8 = (int)((x->c + 7) / 8);
   a.P = (long long)x->n * x->h * x->w;
+  FD_REQUIRE(a.P < (1ll << 31), "bn_bwd_apply: more than 2^31 pixels");
   a.eps = pro->eps;
   a.inv_m = 1.f / (float)a.P;
   a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.dbeta = dbeta, a.dgamma = dgamma;
