@@ -29,7 +29,6 @@ struct FsArgs {
   float mean[3], istd[3];
   int tiles_x, tiles_y;
   int mode;         // 0 blur, 1 laplacian, 2 fused NHWC
-  int rgb16;        // fused: the view has >= 16 channels and 16-byte aligned pixels (one 32-byte store per pixel)
 };
 
 __device__ __forceinline__ int reflect(int i, int n) {   // nn.ReflectionPad2d: -i -> i, n-1+i -> n-1-i
@@ -85,6 +84,9 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
         }
       hf = s - 9.f * ctr;
     }
+    // (mode 2's three 2-byte stores per pixel and plane: a form with all three planes per workgroup, the nine values staged in LDS
+    // and ONE 32-byte store per pixel was measured in round 3 -- 39.8 against 35.7 us at 16 x 3 x 256^2, 124 against 140 us at
+    // 4 x 3 x 1024^2: the kernel is bound by its 46 x 46 halo tile and scalar LDS reads, not by the stores)
     if (a.mode == 0) {
       a.y[(long long)plane * a.H * a.W + (long long)oy * a.W + ox] = lf;
     } else if (a.mode == 1) {
@@ -99,68 +101,6 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
       q[a.C + ch] = (unsigned short)(b01 >> 16);          // LF(img)
       q[2 * a.C + ch] = (unsigned short)(b2 & 0xffffu);   // HF(img)
     }
-  }
-}
-
-// ---- fused Fusion-D input, all three colour channels per workgroup --------------------------------------------------------
-// fdgan_fusion_input_nhwc for RGB images: [img | LF(img) | HF(img)] = 9 of the 16 channels of D's NHWC fp16 input.  The kernel
-// above handles one plane per workgroup and so stores three 2-byte values per pixel and plane (172 us at 4 x 3 x 1024^2, 0.09 of
-// HBM); here a workgroup walks the three planes of its 32 x 32 tile through the same LDS tiles, keeps the nine values of its four
-// pixels in registers and writes each pixel ONCE: 32 bytes (nine values + the seven padding zeros), two 16-byte stores.
-__global__ __launch_bounds__(256) void fusion_input_rgb_kernel(FsArgs a) {
-  __shared__ float tin[FS_E][FS_E + 1];
-  __shared__ float tmp[FS_E][FS_T + 1];
-  const int n = blockIdx.y;
-  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-  const int x0 = tx * FS_T, y0 = ty * FS_T;
-  const int tid = threadIdx.x;
-  float val[4][9];   // [pixel of this thread][img r g b | lf r g b | hf r g b]
-  for (int ch = 0; ch < 3; ++ch) {
-    const float* xp = a.x + ((long long)n * 3 + ch) * a.H * a.W;
-    for (int i = tid; i < FS_E * FS_E; i += 256) {
-      const int r = i / FS_E, c = i - r * FS_E;
-      tin[r][c] = xp[(long long)reflect(y0 - FS_R + r, a.H) * a.W + reflect(x0 - FS_R + c, a.W)];
-    }
-    __syncthreads();
-    for (int i = tid; i < FS_E * FS_T; i += 256) {
-      const int r = i / FS_T, c = i - r * FS_T;
-      float s_ = 0.f;
-#pragma unroll
-      for (int t = 0; t < 15; ++t) s_ = fmaf(a.g[t], tin[r][c + t], s_);
-      tmp[r][c] = s_;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + 256 * q, r = i / FS_T, c = i - r * FS_T;
-      const int oy = y0 + r, ox = x0 + c;
-      float lf = 0.f;
-#pragma unroll
-      for (int t = 0; t < 15; ++t) lf = fmaf(a.g[t], tmp[r + t][c], lf);
-      if (a.norm) lf = (lf - a.mean[ch]) * a.istd[ch];
-      const float ctr = tin[r + FS_R][c + FS_R];
-      float s_ = 0.f;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int yy = oy + dy, xx = ox + dx;
-          s_ += (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? tin[r + FS_R + dy][c + FS_R + dx] : 0.f;
-        }
-      val[q][ch] = ctr, val[q][3 + ch] = lf, val[q][6 + ch] = s_ - 9.f * ctr;
-    }
-    __syncthreads();   // the tiles are overwritten by the next plane
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid + 256 * q, r = i / FS_T, c = i - r * FS_T;
-    const int oy = y0 + r, ox = x0 + c;
-    if (oy >= a.H || ox >= a.W) continue;
-    unsigned short* qp = a.y_nhwc + n * a.yn_sn + oy * a.yn_sh + ox * a.yn_sw;
-    const f32x8 lo = {val[q][0], val[q][1], val[q][2], val[q][3], val[q][4], val[q][5], val[q][6], val[q][7]};
-    const f32x8 hi = {val[q][8], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<u32x4*>(qp) = fd_pk8<FmtA>(lo);
-    *reinterpret_cast<u32x4*>(qp + 8) = fd_pk8<FmtA>(hi);
   }
 }
 
@@ -407,8 +347,6 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
     return dpp ? fd_launch(&freqsplit_rows_kernel<1, true>, name, dim3(grid), dim3(64), 0, r, stream)
                : fd_launch(&freqsplit_rows_kernel<1, false>, name, dim3(grid), dim3(64), 0, r, stream);
   }
-  if (a.mode == 2 && a.C == 3 && a.rgb16)
-    return fd_launch(&fusion_input_rgb_kernel, name, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(planes / 3)), dim3(256), 0, a, stream);
   return fd_launch(&freqsplit_kernel, name, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)planes), dim3(256), 0, a,
                    stream);
 }
@@ -466,8 +404,6 @@ extern "C" int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, i
   a.C = (int)c;
   a.norm = use_input_norm ? 1 : 0;
   a.mode = 2;
-  // all 16 channels of the pixel are written (9 values + 7 zeros): only when they belong to this view
-  a.rgb16 = (y->c >= 16 && ((uintptr_t)y->ptr & 15) == 0 && y->stride[2] % 8 == 0 && y->stride[1] % 8 == 0 && y->stride[0] % 8 == 0) ? 1 : 0;
   return launch(a, n * c, static_cast<hipStream_t>(stream), "fusion_input");
 }
 

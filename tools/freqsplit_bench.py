@@ -17,7 +17,4 @@ for (b, s) in ((16, 256), (4, 1024)):
     tb, tl = t(lambda: E.blur15(x, True)), t(lambda: E.laplacian3(x))
     with torch.no_grad():
         tf = t(lambda: fusion_input(x))
-    buf = E.new_act(b, s, s, 16, torch.device("cuda"), zero=True)
-    t9, t16 = t(lambda: E.fusion_input_nhwc(x, E.View(buf, 0, 9))), t(lambda: E.fusion_input_nhwc(x, E.View(buf)))
-    print(f"B={b} @{s}x{s}: fusion_input_nhwc (image in, 9 NHWC fp16 channels out) per-plane kernel {t9:7.1f} us | RGB kernel, one 32-byte store per pixel {t16:7.1f} us")
     print(f"B={b} @{s}x{s}: blur15 {tb:7.1f} us {byts/tb/1e3:7.1f} GB/s | laplacian3 {tl:7.1f} us {byts/tl/1e3:7.1f} GB/s | fusion_input (img+LF+HF, 4 planes moved) {tf:7.1f} us {2*byts/tf/1e3:7.1f} GB/s")
