@@ -142,66 +142,93 @@ struct C1BwdArgs {
   int ntile;
 };
 
+// KS x KS taps; one thread = TWO horizontally adjacent pixels x four 8-channel pieces C32 apart (piece q of lane g is g + C32 q: for a
+// fixed q adjacent lanes touch adjacent 16 bytes, so every load / store instruction covers whole runs of a pixel row).
+// Round 3 (PMC: 1650 vector instructions per wave and unit, half of the LDS cycles bank conflicts): the dy taps of both pixels are
+// fetched first, with 32-bit offsets and zeros outside the image, so the tap loop has no branches; the FMAs are packed
+// (v_pk_fma_f32, the tap value broadcast); a filter fragment read from LDS serves both pixels; and the LDS image is
+// [tap][low / high half][piece][4 floats], so the lanes of a read touch consecutive 16-byte slots (the [tap][channel] image
+// made every ds_read_b128 a two-way conflict).
+template <int KS>
 __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char c1_lds[];
-  float* wl = reinterpret_cast<float*>(c1_lds);            // [taps][C8 * 8] fp32, forward tap order
-  const int kk = a.ks * a.ks, cp = a.C8 * 8;
-  for (int i = threadIdx.x; i < kk * cp; i += 256) {
+  float* wl = reinterpret_cast<float*>(c1_lds);            // [taps][2][C8][4] fp32, forward tap order
+  constexpr int KK = KS * KS;
+  const int cp = a.C8 * 8;
+  for (int i = threadIdx.x; i < KK * cp; i += 256) {
     const int t = i / cp, c = i - t * cp;
     float v = 0.f;
-    if (c < a.C) {   // flipped image: Wf[cout' = c][cin' = 0][tap'] = W[0][c][kk - 1 - tap'];  fragment order, lane = c & 15 (cin' group 0), e = 0
-      const int tp = kk - 1 - t;
+    if (c < a.C) {   // flipped image: Wf[cout' = c][cin' = 0][tap'] = W[0][c][KK - 1 - tap'];  fragment order, lane = c & 15 (cin' group 0), e = 0
+      const int tp = KK - 1 - t;
       v = fd_cvt1<FmtG>(a.w[((long long)tp * a.ntile + (c >> 4)) * 512 + (c & 15) * 8]);
     }
-    wl[i] = v;
+    wl[((t * 2 + ((c >> 2) & 1)) * a.C8 + (c >> 3)) * 4 + (c & 3)] = v;
   }
   __syncthreads();
-  // persistent workgroups (the 16 x C filter is converted once per workgroup, not once per 256 outputs); one thread = one pixel x
-  // four 8-channel pieces C32 apart (piece q of lane g is g + C32 q: for a fixed q adjacent lanes touch adjacent 16 bytes, so every
-  // load / store instruction covers whole runs of a pixel row): the 16 dy values and their index arithmetic are paid once per 32 outputs
-  const int C32 = (a.C8 + 3) / 4;
-  const long long units = a.total / a.C8 * C32;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int c32 = (int)(u % C32);
-    long long r = u / C32;
-    const int x = (int)(r % a.W);
-    r /= a.W;
-    const int y = (int)(r % a.H), n = (int)(r / a.H);
-    f32x8 da[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) da[q] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int C32 = (a.C8 + 3) / 4, W2 = (a.W + 1) / 2;
+  const unsigned units = (unsigned)a.total;                 // N * H * ceil(W / 2) * C32 (launcher: < 2^31)
+  for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
+    const int c32 = (int)(u % (unsigned)C32);
+    unsigned r = u / (unsigned)C32;
+    const int x = 2 * (int)(r % (unsigned)W2);
+    r /= (unsigned)W2;
+    const int y = (int)(r % (unsigned)a.H), n = (int)(r / (unsigned)a.H);
+    const bool two = x + 1 < a.W;
     const unsigned short* dn = a.dy + (long long)n * a.dy_sn;
-    for (int ky = 0; ky < a.ks; ++ky) {
-      const int oy = y + a.pad - ky;
-      if (oy < 0 || oy >= a.Ho) continue;
-      for (int kx = 0; kx < a.ks; ++kx) {
-        const int ox = x + a.pad - kx;
-        if (ox < 0 || ox >= a.Wo) continue;
-        const float d = fd_cvt1<FmtG>(dn[(long long)oy * a.dy_sh + (long long)ox * a.dy_sw]);
-        const float* wt = wl + (ky * a.ks + kx) * cp + c32 * 8;
+    f32x2 da[2][4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (c32 + q * C32 >= a.C8) break;
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + q * C32 * 8), w1 = *reinterpret_cast<const f32x4*>(wt + q * C32 * 8 + 4);
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            da[q][e] = fmaf(d, w0[e], da[q][e]);
-            da[q][e + 4] = fmaf(d, w1[e], da[q][e + 4]);
-          }
-        }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) da[p][q][k] = f32x2{0.f, 0.f};
+    // the mask operand (the forward input of these 2 x 32 channels) is requested now and used after the taps
+    u32x4 xv[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c8 = c32 + q * C32 < a.C8 ? c32 + q * C32 : c32;
+        const int xp = p == 1 && !two ? x : x + p;
+        xv[p][q] = *reinterpret_cast<const u32x4*>(a.x + (long long)n * a.x_sn + (long long)y * a.x_sh + (long long)xp * a.x_sw + c8 * 8);
+      }
+    // (the tap loop stays rolled: unrolled, hipcc hoists all 128 filter reads and spills -- 256 registers and 584 bytes of scratch)
+#pragma unroll 1
+    for (int t = 0; t < KK; ++t) {
+      const int ky = t / KS, kx = t - ky * KS;
+      const int oy = y + a.pad - ky, ox = x + a.pad - kx;
+      const bool rok = oy >= 0 && oy < a.Ho;
+      const int off = oy * a.dy_sh + ox * a.dy_sw;
+      const float e0 = rok && ox >= 0 && ox < a.Wo ? fd_cvt1<FmtG>(dn[off]) : 0.f;                     // zeros outside the image:
+      const float e1 = rok && ox + 1 >= 0 && ox + 1 < a.Wo ? fd_cvt1<FmtG>(dn[off + a.dy_sw]) : 0.f;   // no branch around the FMAs
+      const f32x2 d0 = {e0, e0}, d1 = {e1, e1};
+      const float* wt = wl + (t * 2 * a.C8 + c32) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c8 = c32 + q * C32 < a.C8 ? c32 + q * C32 : c32;      // past the last piece: piece c32 again (result unused)
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + (c8 - c32) * 4), w1 = *reinterpret_cast<const f32x4*>(wt + (a.C8 + c8 - c32) * 4);
+        const f32x2 wa = {w0[0], w0[1]}, wb = {w0[2], w0[3]}, wc = {w1[0], w1[1]}, wd = {w1[2], w1[3]};
+        da[0][q][0] = __builtin_elementwise_fma(d0, wa, da[0][q][0]), da[0][q][1] = __builtin_elementwise_fma(d0, wb, da[0][q][1]);
+        da[0][q][2] = __builtin_elementwise_fma(d0, wc, da[0][q][2]), da[0][q][3] = __builtin_elementwise_fma(d0, wd, da[0][q][3]);
+        da[1][q][0] = __builtin_elementwise_fma(d1, wa, da[1][q][0]), da[1][q][1] = __builtin_elementwise_fma(d1, wb, da[1][q][1]);
+        da[1][q][2] = __builtin_elementwise_fma(d1, wc, da[1][q][2]), da[1][q][3] = __builtin_elementwise_fma(d1, wd, da[1][q][3]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c8 = c32 + q * C32;
-      if (c8 >= a.C8) break;
-      const f32x8 fx = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(a.x + (long long)n * a.x_sn + (long long)y * a.x_sh + (long long)x * a.x_sw + c8 * 8));
-      unsigned short* gp = a.g + (long long)n * a.g_sn + (long long)y * a.g_sh + (long long)x * a.g_sw + c8 * 8;
-      f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
+    for (int p = 0; p < 2; ++p) {
+      if (p == 1 && !two) break;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[q][e] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
-      *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
+      for (int q = 0; q < 4; ++q) {
+        const int c8 = c32 + q * C32;
+        if (c8 >= a.C8) break;
+        const f32x8 fx = fd_cvt8<FmtA>(xv[p][q]);
+        unsigned short* gp = a.g + (long long)n * a.g_sn + (long long)y * a.g_sh + (long long)(x + p) * a.g_sw + c8 * 8;
+        f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[p][q][e >> 1][e & 1] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
+        *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
+      }
     }
   }
 }
@@ -255,10 +282,15 @@ int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const F
   c.g = static_cast<unsigned short*>(dpre->ptr), c.g_sn = dpre->stride[0], c.g_sh = (int)dpre->stride[1], c.g_sw = (int)dpre->stride[2];
   c.H = (int)dpre->h, c.W = (int)dpre->w, c.C = (int)dpre->c, c.C8 = (int)((dpre->c + 7) / 8), c.ks = d->ksize, c.pad = pad_fwd, c.acc = accumulate;
   c.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
-  c.total = dpre->n * dpre->h * dpre->w * c.C8;
+  c.total = dpre->n * dpre->h * ((dpre->w + 1) / 2) * ((c.C8 + 3) / 4);      // units: (image, row, pixel pair, piece group)
   c.ntile = (int)((dpre->c + 15) / 16);
   const unsigned lds = (unsigned)(d->ksize * d->ksize * c.C8 * 8 * 4);
-  if (lds > 64 * 1024) return 1;
-  const long long nb = (c.total / c.C8 * ((c.C8 + 3) / 4) + 255) / 256;
-  return fd_launch(&dgrad_cout1_kernel, "dgrad_cout1", dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), lds, c, stream);
+  if (lds > 64 * 1024 || c.total >= (1ll << 31) || dy->n * dy->stride[0] >= (1ll << 31)) return 1;
+  const long long nb = (c.total + 255) / 256;
+  const dim3 grid((unsigned)(nb < 2048 ? nb : 2048));
+  switch (d->ksize) {
+    case 4: return fd_launch(&dgrad_cout1_kernel<4>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+    case 3: return fd_launch(&dgrad_cout1_kernel<3>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+    default: return fd_launch(&dgrad_cout1_kernel<2>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+  }
 }
