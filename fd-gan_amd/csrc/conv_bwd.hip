@@ -878,14 +878,13 @@ struct OutActBwdArgs {
   int N, C, H, W, act, C8;
 };
 __global__ __launch_bounds__(256) void out_act_bwd_kernel(OutActBwdArgs a) {
-  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)a.N * a.H * a.W * a.C8;
-  if (u >= total) return;
-  const int c8 = (int)(u % a.C8);
-  long long r = u / a.C8;
-  const int x = (int)(r % a.W);
-  r /= a.W;
-  const int y = (int)(r % a.H), n = (int)(r / a.H);
+  const unsigned u = blockIdx.x * 256u + threadIdx.x;             // N * H * W * C8 < 2^31 (launcher): 32-bit index arithmetic
+  if (u >= (unsigned)a.N * a.H * a.W * a.C8) return;
+  const int c8 = (int)(u % (unsigned)a.C8);
+  unsigned r = u / (unsigned)a.C8;
+  const int x = (int)(r % (unsigned)a.W);
+  r /= (unsigned)a.W;
+  const int y = (int)(r % (unsigned)a.H), n = (int)(r / (unsigned)a.H);
   f32x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -915,13 +914,13 @@ struct GradEwArgs {
   int N, H, W, C8, mode, C;   // H, W: dst size; C: channels of the view
 };
 __global__ __launch_bounds__(256) void grad_ew_kernel(GradEwArgs a) {
-  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (u >= (long long)a.N * a.H * a.W * a.C8) return;
-  const int c8 = (int)(u % a.C8);
-  long long r = u / a.C8;
-  const int x = (int)(r % a.W);
-  r /= a.W;
-  const int y = (int)(r % a.H), n = (int)(r / a.H);
+  const unsigned u = blockIdx.x * 256u + threadIdx.x;             // N * H * W * C8 < 2^31 (launcher): 32-bit index arithmetic
+  if (u >= (unsigned)a.N * a.H * a.W * a.C8) return;
+  const int c8 = (int)(u % (unsigned)a.C8);
+  unsigned r = u / (unsigned)a.C8;
+  const int x = (int)(r % (unsigned)a.W);
+  r /= (unsigned)a.W;
+  const int y = (int)(r % (unsigned)a.H), n = (int)(r / (unsigned)a.H);
   auto ld = [&](const unsigned short* base, long long sn, int sh, int sw, int yy, int xx) {
     return __builtin_convertvector(
         __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + n * sn + (long long)yy * sh + (long long)xx * sw + c8 * 8)), f32x8);
@@ -1406,6 +1405,7 @@ extern "C" int fdgan_out_act_bwd(const float* dout, const float* out, int64_t n,
   OutActBwdArgs a{dout, out, static_cast<unsigned short*>(g->ptr), g->stride[0], (int)g->stride[1], (int)g->stride[2],
                   (int)n, (int)c, (int)h, (int)w, act, (int)((g->c + 7) / 8)};
   const long long total = n * h * w * a.C8;
+  FD_REQUIRE(total < (1ll << 31), "out_act_bwd: more than 2^31 pieces");
   return fd_launch(&out_act_bwd_kernel, "out_act_bwd", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
@@ -1431,6 +1431,7 @@ extern "C" int fdgan_grad_ew(int mode, const FdTensor* src, const FdTensor* ref,
   a.d_sn = dst->stride[0], a.d_sh = (int)dst->stride[1], a.d_sw = (int)dst->stride[2];
   a.N = (int)dst->n, a.H = (int)dst->h, a.W = (int)dst->w, a.C8 = (int)((dst->c + 7) / 8), a.mode = mode, a.C = (int)dst->c;
   const long long total = (long long)a.N * a.H * a.W * a.C8;
+  FD_REQUIRE(total < (1ll << 31), "grad_ew: more than 2^31 pieces");
   return fd_launch(&grad_ew_kernel, "grad_ew", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }

@@ -236,16 +236,16 @@ struct ToNhwcArgs {
 };
 
 __global__ void nchw_to_nhwc_kernel(ToNhwcArgs a) {
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= a.total) return;
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;        // total < 2^31 (launcher): 32-bit index arithmetic
+  if (u >= (unsigned)a.total) return;
   // pixel-fastest so the fp32 plane reads are coalesced
-  long long r = u;
-  const long long px = r % a.w;
-  r /= a.w;
-  const long long py = r % a.h;
-  r /= a.h;
-  const int g = (int)(r % a.groups);
-  const long long n = r / a.groups;
+  unsigned r = u;
+  const long long px = r % (unsigned)a.w;
+  r /= (unsigned)a.w;
+  const long long py = r % (unsigned)a.h;
+  r /= (unsigned)a.h;
+  const int g = (int)(r % (unsigned)a.groups);
+  const long long n = r / (unsigned)a.groups;
   f32x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -276,6 +276,7 @@ extern "C" int fdgan_nchw_f32_to_nhwc(const float* x, int64_t n, int64_t c, int6
   a.groups = (int)(y->c / 8);
   a.dtype = y->dtype;
   a.total = n * a.groups * h * w;
+  FD_REQUIRE(a.total < (1ll << 31), "nchw_f32_to_nhwc: more than 2^31 pieces");
   return fd_launch(&nchw_to_nhwc_kernel, "nchw_f32_to_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
                    0, a, static_cast<hipStream_t>(stream));
 }
@@ -292,15 +293,15 @@ struct ToNchwArgs {
 };
 
 __global__ void nhwc_to_nchw_kernel(ToNchwArgs a) {
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= a.total) return;
-  long long r = u;
-  const long long px = r % a.w;
-  r /= a.w;
-  const long long py = r % a.h;
-  r /= a.h;
-  const long long c = r % a.c;
-  const long long n = r / a.c;
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;        // total < 2^31 (launcher): 32-bit index arithmetic
+  if (u >= (unsigned)a.total) return;
+  unsigned r = u;
+  const long long px = r % (unsigned)a.w;
+  r /= (unsigned)a.w;
+  const long long py = r % (unsigned)a.h;
+  r /= (unsigned)a.h;
+  const long long c = r % (unsigned)a.c;
+  const long long n = r / (unsigned)a.c;
   const unsigned short b = a.x[n * a.x_sn + py * a.x_sh + px * a.x_sw + c];
   a.y[u] = a.dtype == FD_F16 ? fd_cvt1<FmtA>(b) : fd_cvt1<FmtG>(b);
 }
@@ -310,6 +311,7 @@ extern "C" int fdgan_nhwc_to_nchw_f32(const FdTensor* x, float* y, FdStream stre
   FD_REQUIRE((x->dtype == FD_F16 || x->dtype == FD_BF16) && x->stride[3] == 1, "nhwc_to_nchw_f32: x must be an NHWC fp16 / bf16 view");
   ToNchwArgs a{static_cast<const unsigned short*>(x->ptr), y, x->n, x->c, x->h, x->w,
                x->stride[0], x->stride[1], x->stride[2], x->n * x->c * x->h * x->w, x->dtype};
+  FD_REQUIRE(a.total < (1ll << 31), "nhwc_to_nchw_f32: more than 2^31 elements");
   return fd_launch(&nhwc_to_nchw_kernel, "nhwc_to_nchw_f32", dim3((unsigned)((a.total + 255) / 256)), dim3(256),
                    0, a, static_cast<hipStream_t>(stream));
 }

@@ -125,13 +125,13 @@ __global__ __launch_bounds__(256) void mse_nhwc_kernel(MseNhwcArgs a) {
   float acc = 0.f;
   float up = 0.f;
   if (BWD) up = a.upstream[0] * a.scale;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < a.units; u += (long long)gridDim.x * 256) {
-    const int c8 = (int)(u % a.C8);
-    long long p = u / a.C8;
-    const int x = (int)(p % a.W);
-    p /= a.W;
-    const int y = (int)(p % a.H);
-    const long long n = p / a.H;
+  for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < (unsigned)a.units; u += gridDim.x * 256u) {   // units < 2^31: 32-bit index arithmetic
+    const int c8 = (int)(u % (unsigned)a.C8);
+    unsigned p = u / (unsigned)a.C8;
+    const int x = (int)(p % (unsigned)a.W);
+    p /= (unsigned)a.W;
+    const int y = (int)(p % (unsigned)a.H);
+    const long long n = p / (unsigned)a.H;
     const u32x4 av = *reinterpret_cast<const u32x4*>(a.a + n * a.a_sn + (long long)y * a.a_sh + (long long)x * a.a_sw + c8 * 8);
     const u32x4 bv = *reinterpret_cast<const u32x4*>(a.b + n * a.b_sn + (long long)y * a.b_sh + (long long)x * a.b_sw + c8 * 8);
     const f32x8 d = fd_cvt8<FmtA>(av) - fd_cvt8<FmtA>(bv);      // feature maps: fp16
@@ -170,6 +170,7 @@ int mse_setup(const FdTensor* a, const FdTensor* b, const FdTensor* g, MseNhwcAr
   if (g) m.g = static_cast<unsigned short*>(g->ptr), m.g_sn = g->stride[0], m.g_sh = (int)g->stride[1], m.g_sw = (int)g->stride[2];
   m.H = (int)a->h, m.W = (int)a->w, m.C8 = (int)(a->c / 8);
   m.units = a->n * a->h * a->w * m.C8;
+  FD_REQUIRE(m.units < (1ll << 31), "mse_nhwc: more than 2^31 pieces");
   return FD_OK;
 }
 

@@ -12,15 +12,15 @@ struct PoolArgs {
 };
 
 __global__ void maxpool2_kernel(PoolArgs a) {
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= a.total) return;
-  long long r = u;
-  const int g = (int)(r % a.groups);
-  r /= a.groups;
-  const int ox = (int)(r % a.Wo);
-  r /= a.Wo;
-  const int oy = (int)(r % a.Ho);
-  const long long n = r / a.Ho;
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;      // total < 2^31 (launcher): 32-bit index arithmetic (a 64-bit
+  if (u >= (unsigned)a.total) return;                             // division is ~100 vector instructions; there were four per thread)
+  unsigned r = u;
+  const int g = (int)(r % (unsigned)a.groups);
+  r /= (unsigned)a.groups;
+  const int ox = (int)(r % (unsigned)a.Wo);
+  r /= (unsigned)a.Wo;
+  const int oy = (int)(r % (unsigned)a.Ho);
+  const long long n = r / (unsigned)a.Ho;
   const unsigned short* p = a.x + n * a.x_sn + (long long)(2 * oy) * a.x_sh + (long long)(2 * ox) * a.x_sw + g * 8;
   const f32x8 f0 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p)), f1 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sw));
   const f32x8 f2 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sh)), f3 = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(p + a.x_sh + a.x_sw));
@@ -40,15 +40,15 @@ struct PoolBwdArgs {
   long long total;
 };
 __global__ void maxpool2_bwd_kernel(PoolBwdArgs a) {
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= a.total) return;
-  long long r = u;
-  const int g = (int)(r % a.groups);
-  r /= a.groups;
-  const int ox = (int)(r % a.Wo);
-  r /= a.Wo;
-  const int oy = (int)(r % a.Ho);
-  const long long n = r / a.Ho;
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x;      // total < 2^31 (launcher): 32-bit index arithmetic (a 64-bit
+  if (u >= (unsigned)a.total) return;                             // division is ~100 vector instructions; there were four per thread)
+  unsigned r = u;
+  const int g = (int)(r % (unsigned)a.groups);
+  r /= (unsigned)a.groups;
+  const int ox = (int)(r % (unsigned)a.Wo);
+  r /= (unsigned)a.Wo;
+  const int oy = (int)(r % (unsigned)a.Ho);
+  const long long n = r / (unsigned)a.Ho;
   const unsigned short* p = a.x + n * a.x_sn + (long long)(2 * oy) * a.x_sh + (long long)(2 * ox) * a.x_sw + g * 8;
   const long long xo[4] = {0, a.x_sw, a.x_sh, a.x_sh + a.x_sw};
   f32x8 f[4];
@@ -96,7 +96,7 @@ extern "C" int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, co
                 static_cast<unsigned short*>(dx->ptr), x->stride[0], x->stride[1], x->stride[2], dy->stride[0], dy->stride[1],
                 dy->stride[2], dx->stride[0], dx->stride[1], dx->stride[2], (int)dy->h, (int)dy->w, (int)(x->c / 8),
                 dy->n * dy->h * dy->w * (x->c / 8)};
-  FD_REQUIRE(a.total > 0, "maxpool2_bwd_nhwc: empty");
+  FD_REQUIRE(a.total > 0 && a.total < (1ll << 31), "maxpool2_bwd_nhwc: empty, or more than 2^31 pieces");
   return fd_launch(&maxpool2_bwd_kernel, "maxpool2_bwd_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
@@ -113,7 +113,7 @@ extern "C" int fdgan_maxpool2_nhwc(const FdTensor* x, const FdTensor* y, FdStrea
   PoolArgs a{static_cast<const unsigned short*>(x->ptr), static_cast<unsigned short*>(y->ptr),
              x->stride[0], x->stride[1], x->stride[2], y->stride[0], y->stride[1], y->stride[2],
              (int)y->h, (int)y->w, (int)(x->c / 8), y->n * y->h * y->w * (x->c / 8)};
-  FD_REQUIRE(a.total > 0, "maxpool2_nhwc: empty output");
+  FD_REQUIRE(a.total > 0 && a.total < (1ll << 31), "maxpool2_nhwc: empty output, or more than 2^31 pieces");
   return fd_launch(&maxpool2_kernel, "maxpool2_nhwc", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
