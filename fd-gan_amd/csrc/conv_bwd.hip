@@ -618,6 +618,11 @@ struct SumFinArgs {
   float coef_inv_m;
   float *bsum, *csum;
 };
+// (An LDS-free form -- 256 threads, the row lanes summed with wave shuffles -- was measured in round 3 because rocprofv3 shows this
+// kernel at 24.6 us on average against 3.9 us alone: its workgroups wait for LDS while the side stream's weight-gradient kernels
+// hold all 160 KB of every CU.  Without LDS it starts at once -- and the NEXT kernel of the walk waits instead: the step stayed at
+// 28.3 ms and the fused bottleneck backward's bracketed time rose from 113 to 125 us.  The wait is the two streams sharing CUs,
+// not this kernel.)
 __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
   __shared__ double sh[2][32][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
