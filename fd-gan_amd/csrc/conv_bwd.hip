@@ -522,6 +522,12 @@ struct BnActBwdArgs {
   // pool != 0 (the transitions' pooled prologue): `da` is the gradient w.r.t. the 2x2-AVERAGED activation at half
   // resolution; pixel (y, x) takes da[y/2][x/2] / 4 (the un-pool), dpre is NOT written back -- only the sums leave
   int pool;
+  // pooled form, optional: G (the gradient of x, full resolution) += gamma * rstd * dpre in the same pass; what is left of
+  // BatchNorm's backward is then B * x + C per channel (fdgan_bn_bwd_coef), which the caller defers like everywhere else --
+  // the second full-resolution pass (fdgan_bn_bwd_apply) is not needed
+  unsigned short* dx;
+  long long dx_sn;
+  int dx_sh, dx_sw;
 };
 
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
@@ -550,8 +556,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long stride = (long long)gridDim.x * 32;
     for (long long p0 = (long long)blockIdx.x * 32 + slot; cok && p0 < a.P; p0 += 4 * stride) {   // 4 pixels in flight
-      u32x4 dvv[4], xvv[4];
+      u32x4 dvv[4], xvv[4], gvv[4];
       unsigned short* dp[4];
+      unsigned short* gp[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const long long p = p0 + k * stride;
@@ -562,6 +569,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
           dp[k] = a.da + n * a.da_sn + (long long)(a.pool ? y >> 1 : y) * a.da_sh + (long long)(a.pool ? xx >> 1 : xx) * a.da_sw + c8 * 8;
           dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
           xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+          if (a.dx != nullptr) {
+            gp[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+            gvv[k] = *reinterpret_cast<const u32x4*>(gp[k]);
+          }
         }
       }
 #pragma unroll
@@ -579,6 +590,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
           s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
         }
         if (!a.pool) *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+        if (a.dx != nullptr) {
+          f32x8 g = __builtin_convertvector(__builtin_bit_cast(bf16x8, gvv[k]), f32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = fmaf(sc[e], o[e], g[e]);
+          *reinterpret_cast<u32x4*>(gp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(g, bf16x8));
+        }
       }
     }
     if (a.partial != nullptr) {
@@ -1142,6 +1159,11 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
 
 extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
                                 int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
+  return fdgan_bn_act_bwd_acc(da, x, pro, nullptr, partial, capacity_floats, rows_out, cpad_out, stream);
+}
+
+extern "C" int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, float* partial,
+                                    int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
   if (int rc = check_view(da, "bn_act_bwd(da)")) return rc;
   if (int rc = check_view(x, "bn_act_bwd(x)", FD_F16)) return rc;
   const bool pooled = pro && pro->pool2;
@@ -1151,6 +1173,11 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
   FD_REQUIRE(!pooled || (pro->mean && partial), "bn_act_bwd: the pooled form only produces the BatchNorm sums");
   BnActBwdArgs a{};
   a.pool = pooled ? 1 : 0;
+  if (dx != nullptr) {
+    if (int rc = check_view(dx, "bn_act_bwd(dx)")) return rc;
+    FD_REQUIRE(pooled && dx->n == x->n && dx->h == x->h && dx->w == x->w && dx->c == x->c, "bn_act_bwd: dx goes with the pooled form and has x's shape");
+    a.dx = static_cast<unsigned short*>(dx->ptr), a.dx_sn = dx->stride[0], a.dx_sh = (int)dx->stride[1], a.dx_sw = (int)dx->stride[2];
+  }
   a.da = static_cast<unsigned short*>(da->ptr);
   a.da_sn = da->stride[0], a.da_sh = (int)da->stride[1], a.da_sw = (int)da->stride[2];
   a.x = static_cast<const unsigned short*>(x->ptr);

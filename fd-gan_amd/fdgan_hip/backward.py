@@ -142,6 +142,7 @@ class PlanBackward:
         self.defer_affine = os.environ.get("FDGAN_NO_DEFERRED_AFFINE") is None  # tuning aid: per-layer bn_bwd_apply pass
         self.fuse_wgrad = os.environ.get("FDGAN_NO_FUSED_WGRAD") is None        # tuning aid: separate 1x1 weight-gradient kernel
         self.fold_flush = os.environ.get("FDGAN_NO_FOLDED_FLUSH") is None       # tuning aid: separate affine_accumulate pass
+        self.pool_one_pass = os.environ.get("FDGAN_NO_POOL_ONEPASS") is None    # tuning aid: pooled prologues through bn_bwd_apply
         # Weight gradients off the critical path: dW only feeds the optimizer, while the data gradient is what the next
         # (earlier) layer waits for.  Every unfused weight gradient (kernel + its fixed-order reduction) whose operands are
         # persistent buffers runs on a second HIP stream with its own split-K workspace; the walk joins it at the end (and
@@ -512,12 +513,18 @@ class PlanBackward:
             dg = torch.empty(cin, dtype=torch.float32, device=p.device)
             dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
             train_bn = bn.weight is not None and bn.weight.requires_grad
-            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn)
+            one_pass = self.defer_affine and not check and self.pool_one_pass     # G += gamma * rstd * dpre rides in the pass that forms the sums
+            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn, dx_fd=gx.fd if one_pass else None)
             E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                               sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
             for lo, hi in _constant_entries(meta, cin):
                 dg[lo:hi].zero_()
                 dbt[lo:hi].zero_()
+            if one_pass:      # what is left, B * x + C per channel, waits in the buffer's coefficient pair like every other norm's
+                d = self._deferred(x)
+                E.bn_bwd_coef(dg, dbt, pool_pro, cin, n * 4 * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
+                d["dirty"].update(range(x.c0, x.c0 + cin))
+                return
             E.bn_bwd_apply(Tv.fd, x.fd, pool_pro, dg, dbt, gx.fd, accumulate=True)
             if check:
                 self._finish_check(rec, x, gx_before, dx_ref)

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 10
+#define FDGAN_ABI_VERSION 11
 
 enum FdStatus {
   FD_OK = 0,
@@ -326,6 +326,12 @@ int fdgan_conv2d_bwd_weight(const FdTensor* x, const FdPrologue* pro, const FdTe
                             FdStream stream);
 int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,
                      int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
+/* fdgan_bn_act_bwd for a POOLED prologue that also adds gamma * rstd * dpre into dx (the full-resolution gradient of x) in the same
+ * pass: with the sums reduced (fdgan_bn_bwd_finalize) and turned into the per-channel remainder B * x + C (fdgan_bn_bwd_coef), which a
+ * caller that defers such remainders (fdgan_affine_accumulate) already knows how to apply, the second pass over the full-resolution
+ * input -- fdgan_bn_bwd_apply -- is not needed (torchvision _Transition under autograd, dehaze1113.py:716-728). */
+int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, float* partial,
+                         int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
 int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                           float* dbeta, int accumulate, FdStream stream);
 /* Same, and the sums are ALSO added into sink_dgamma / sink_dbeta when non-NULL: the BatchNorm parameters' own
