@@ -149,6 +149,11 @@ struct C1BwdArgs {
 // (v_pk_fma_f32, the tap value broadcast); a filter fragment read from LDS serves both pixels; and the LDS image is
 // [tap][low / high half][piece][4 floats], so the lanes of a read touch consecutive 16-byte slots (the [tap][channel] image
 // made every ds_read_b128 a two-way conflict).
+// (Also measured in round 3: the same gradient on the matrix pipe -- K = 16 taps is one v_mfma_f32_16x16x16_bf16 per 16 pixels x 16
+// channels, the filter in registers, two row-permuted tiles giving every lane eight adjacent channels: identical results, 168 us
+// against this kernel's 128.  The MFMA result layout leaves a wave instruction with 16 pixels x 64 bytes, half a cache line per
+// pixel, and that access pattern costs more than the arithmetic it saves; a version that transposes through LDS to whole rows is
+// what it would take.)
 template <int KS>
 __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char c1_lds[];
