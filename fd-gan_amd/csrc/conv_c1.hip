@@ -156,9 +156,14 @@ struct C1BwdArgs {
 // what it would take.)
 template <int KS>
 __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
+  // Third form (round 3).  Unit = one 8-channel piece of FOUR vertically adjacent pixels; units are numbered piece-fastest, then
+  // pixel, so the 64 lanes of a wave instruction touch 1 KB of ONE contiguous run of the NHWC row (whole 128-byte lines -- the
+  // "pieces C32 apart" numbering of the second form gave 144-byte runs, the matrix-pipe form 64-byte ones, and on this memory
+  // system that is what decides: 177 / 129 / 168 us).  The four pixels share their dy window ((4 + KS - 1) x KS values instead
+  // of 4 KS^2) and every filter fragment read from LDS (2 ds_read_b128 per tap for 64 packed FMAs).
   extern __shared__ __attribute__((aligned(16))) char c1_lds[];
   float* wl = reinterpret_cast<float*>(c1_lds);            // [taps][2][C8][4] fp32, forward tap order
-  constexpr int KK = KS * KS;
+  constexpr int KK = KS * KS, R = 4;
   const int cp = a.C8 * 8;
   for (int i = threadIdx.x; i < KK * cp; i += 256) {
     const int t = i / cp, c = i - t * cp;
@@ -170,70 +175,60 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
     wl[((t * 2 + ((c >> 2) & 1)) * a.C8 + (c >> 3)) * 4 + (c & 3)] = v;
   }
   __syncthreads();
-  const int C32 = (a.C8 + 3) / 4, W2 = (a.W + 1) / 2;
-  const unsigned units = (unsigned)a.total;                 // N * H * ceil(W / 2) * C32 (launcher: < 2^31)
+  const unsigned units = (unsigned)a.total;                 // N * ceil(H / 4) * W * C8 (launcher: < 2^31)
+  const unsigned H4 = (unsigned)(a.H + R - 1) / R;
   for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < units; u += gridDim.x * 256u) {
-    const int c32 = (int)(u % (unsigned)C32);
-    unsigned r = u / (unsigned)C32;
-    const int x = 2 * (int)(r % (unsigned)W2);
-    r /= (unsigned)W2;
-    const int y = (int)(r % (unsigned)a.H), n = (int)(r / (unsigned)a.H);
-    const bool two = x + 1 < a.W;
+    const int c8 = (int)(u % (unsigned)a.C8);
+    unsigned r = u / (unsigned)a.C8;
+    const int x = (int)(r % (unsigned)a.W);
+    r /= (unsigned)a.W;
+    const int y0 = R * (int)(r % H4), n = (int)(r / H4);
     const unsigned short* dn = a.dy + (long long)n * a.dy_sn;
-    f32x2 da[2][4][4];
+    const long long xo = (long long)n * a.x_sn + (long long)y0 * a.x_sh + (long long)x * a.x_sw + c8 * 8;
+    const long long go = (long long)n * a.g_sn + (long long)y0 * a.g_sh + (long long)x * a.g_sw + c8 * 8;
+    u32x4 xv[R];                                            // the mask operand, requested now and used after the taps
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int i = 0; i < R; ++i) xv[i] = *reinterpret_cast<const u32x4*>(a.x + xo + (long long)(y0 + i < a.H ? i : 0) * a.x_sh);
+    f32x2 da[R][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) da[p][q][k] = f32x2{0.f, 0.f};
-    // the mask operand (the forward input of these 2 x 32 channels) is requested now and used after the taps
-    u32x4 xv[2][4];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c8 = c32 + q * C32 < a.C8 ? c32 + q * C32 : c32;
-        const int xp = p == 1 && !two ? x : x + p;
-        xv[p][q] = *reinterpret_cast<const u32x4*>(a.x + (long long)n * a.x_sn + (long long)y * a.x_sh + (long long)xp * a.x_sw + c8 * 8);
-      }
-    // (the tap loop stays rolled: unrolled, hipcc hoists all 128 filter reads and spills -- 256 registers and 584 bytes of scratch)
+      for (int k = 0; k < 4; ++k) da[i][k] = f32x2{0.f, 0.f};
+    // window row wr = 0 .. R + KS - 2 is dy row y0 + pad - (KS - 1) + wr; pixel i, filter row ky reads window row i + KS - 1 - ky
 #pragma unroll 1
-    for (int t = 0; t < KK; ++t) {
-      const int ky = t / KS, kx = t - ky * KS;
-      const int oy = y + a.pad - ky, ox = x + a.pad - kx;
-      const bool rok = oy >= 0 && oy < a.Ho;
-      const int off = oy * a.dy_sh + ox * a.dy_sw;
-      const float e0 = rok && ox >= 0 && ox < a.Wo ? fd_cvt1<FmtG>(dn[off]) : 0.f;                     // zeros outside the image:
-      const float e1 = rok && ox + 1 >= 0 && ox + 1 < a.Wo ? fd_cvt1<FmtG>(dn[off + a.dy_sw]) : 0.f;   // no branch around the FMAs
-      const f32x2 d0 = {e0, e0}, d1 = {e1, e1};
-      const float* wt = wl + (t * 2 * a.C8 + c32) * 4;
+    for (int kx = 0; kx < KS; ++kx) {
+      const int ox = x + a.pad - kx;
+      const bool cok = ox >= 0 && ox < a.Wo;
+      float dv[R + KS - 1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c8 = c32 + q * C32 < a.C8 ? c32 + q * C32 : c32;      // past the last piece: piece c32 again (result unused)
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + (c8 - c32) * 4), w1 = *reinterpret_cast<const f32x4*>(wt + (a.C8 + c8 - c32) * 4);
+      for (int wr = 0; wr < R + KS - 1; ++wr) {
+        const int oy = y0 + a.pad - (KS - 1) + wr;
+        dv[wr] = cok && oy >= 0 && oy < a.Ho ? fd_cvt1<FmtG>(dn[oy * a.dy_sh + ox * a.dy_sw]) : 0.f;
+      }
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const float* wt = wl + (((ky * KS + kx) * 2) * a.C8 + c8) * 4;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + a.C8 * 4);
         const f32x2 wa = {w0[0], w0[1]}, wb = {w0[2], w0[3]}, wc = {w1[0], w1[1]}, wd = {w1[2], w1[3]};
-        da[0][q][0] = __builtin_elementwise_fma(d0, wa, da[0][q][0]), da[0][q][1] = __builtin_elementwise_fma(d0, wb, da[0][q][1]);
-        da[0][q][2] = __builtin_elementwise_fma(d0, wc, da[0][q][2]), da[0][q][3] = __builtin_elementwise_fma(d0, wd, da[0][q][3]);
-        da[1][q][0] = __builtin_elementwise_fma(d1, wa, da[1][q][0]), da[1][q][1] = __builtin_elementwise_fma(d1, wb, da[1][q][1]);
-        da[1][q][2] = __builtin_elementwise_fma(d1, wc, da[1][q][2]), da[1][q][3] = __builtin_elementwise_fma(d1, wd, da[1][q][3]);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const float e = dv[i + KS - 1 - ky];
+          const f32x2 d2 = {e, e};
+          da[i][0] = __builtin_elementwise_fma(d2, wa, da[i][0]), da[i][1] = __builtin_elementwise_fma(d2, wb, da[i][1]);
+          da[i][2] = __builtin_elementwise_fma(d2, wc, da[i][2]), da[i][3] = __builtin_elementwise_fma(d2, wd, da[i][3]);
+        }
       }
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (p == 1 && !two) break;
+    for (int i = 0; i < R; ++i) {
+      if (y0 + i >= a.H) break;
+      const f32x8 fx = fd_cvt8<FmtA>(xv[i]);
+      unsigned short* gp = a.g + go + (long long)i * a.g_sh;
+      f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c8 = c32 + q * C32;
-        if (c8 >= a.C8) break;
-        const f32x8 fx = fd_cvt8<FmtA>(xv[p][q]);
-        unsigned short* gp = a.g + (long long)n * a.g_sn + (long long)y * a.g_sh + (long long)(x + p) * a.g_sw + c8 * 8;
-        f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[p][q][e >> 1][e & 1] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
-        *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
-      }
+      for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[i][e >> 1][e & 1] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
+      *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
     }
   }
 }
@@ -287,7 +282,7 @@ int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const F
   c.g = static_cast<unsigned short*>(dpre->ptr), c.g_sn = dpre->stride[0], c.g_sh = (int)dpre->stride[1], c.g_sw = (int)dpre->stride[2];
   c.H = (int)dpre->h, c.W = (int)dpre->w, c.C = (int)dpre->c, c.C8 = (int)((dpre->c + 7) / 8), c.ks = d->ksize, c.pad = pad_fwd, c.acc = accumulate;
   c.slope = act == FD_ACT_RELU ? 0.f : (act == FD_ACT_LEAKY02 ? 0.2f : 1.f);
-  c.total = dpre->n * dpre->h * ((dpre->w + 1) / 2) * ((c.C8 + 3) / 4);      // units: (image, row, pixel pair, piece group)
+  c.total = dpre->n * ((dpre->h + 3) / 4) * dpre->w * c.C8;                    // units: (image, four rows, pixel, 8-channel piece)
   c.ntile = (int)((dpre->c + 15) / 16);
   const unsigned lds = (unsigned)(d->ksize * d->ksize * c.C8 * 8 * 4);
   if (lds > 64 * 1024 || c.total >= (1ll << 31) || dy->n * dy->stride[0] >= (1ll << 31)) return 1;
