@@ -13,7 +13,7 @@ def t_us(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (n, h, w, cin) in ((1, 8, 8, 32), (2, 31, 31, 288), (1, 40, 70, 64), (16, 127, 127, 288)):
+for (n, h, w, cin) in (((16, 127, 127, 288),) if os.environ.get("BIG") else ((1, 8, 8, 32), (2, 31, 31, 288), (1, 40, 70, 64), (16, 127, 127, 288))):
     x = torch.randn(n, h, w, cin, device=dev).half()
     wt = torch.randn(1, cin, 4, 4, device=dev) * 0.05
     pw = E.PackedWeight(wt, 1, cin, 4); pw.pack()
