@@ -143,3 +143,49 @@ def test_demo_checkpoint_key_handling(tmp_path):
                          "dense_block1.denselayer1.conv2.weight", "trans_block1.norm.weight"]
     opt = demo.build_parser().parse_args(["--valDataroot", "d", "--netG", "w.pth"])
     assert (opt.valBatchSize, opt.imageSize, opt.lrG, opt.beta1, opt.dataset) == (1, 1024, 0.0002, 0.5, 'pix2pix')
+
+
+def test_transposed_conv_parity_filters_and_their_adjoint():
+    """models/dehaze22.py: ConvTranspose2d(4, 2, 1) as four stride-1 3x3 convolutions, one per output parity (`_phase_filters`), and
+    the map that gathers the four filter gradients back into the (cin, cout, 4, 4) parameter (`_phase_filter_grads`): the parity
+    convolutions reproduce F.conv_transpose2d exactly, and the gather is the exact adjoint of the scatter (host logic, no GPU)."""
+    import torch.nn.functional as F
+    from models.dehaze22 import _phase_filter_grads, _phase_filters
+    g = torch.Generator().manual_seed(3)
+    cin, cout = 5, 7
+    w = torch.randn(cin, cout, 4, 4, generator=g)
+    x = torch.randn(2, cin, 6, 9, generator=g)
+    filt = _phase_filters(w, [torch.zeros(cout, cin, 3, 3) for _ in range(4)])
+    want = F.conv_transpose2d(x, w, None, 2, 1)
+    got = torch.zeros_like(want)
+    for a in range(2):
+        for b in range(2):
+            got[:, :, a::2, b::2] = F.conv2d(x, filt[a * 2 + b], None, 1, 1)
+    assert float((got - want).abs().max()) < 1e-5
+    d = [torch.randn(cout, cin, 3, 3, generator=g) for _ in range(4)]
+    lhs = sum(float((f * dd).sum()) for f, dd in zip(filt, d))
+    rhs = float((w * _phase_filter_grads(d, w)).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    d[2] = None                                   # a parity that received no gradient counts as zero
+    assert _phase_filter_grads(d, w).shape == w.shape
+
+
+def test_stem_filter_and_its_gradient_map():
+    """models/dehaze1113.py: DenseNet's 7x7 stride-2 stem as a 4x4 stride-1 convolution on the 2x2 space-to-depth image (`_stem_filter`),
+    and `_DenseBase._derived_grads`' inverse map for its gradient: same outputs as F.conv2d(x, w7, stride 2, pad 3), and the gradient
+    map is the adjoint."""
+    import torch.nn.functional as F
+    from models.dehaze1113 import _stem_filter
+    g = torch.Generator().manual_seed(4)
+    w7 = torch.randn(8, 3, 7, 7, generator=g)
+    x = torch.randn(2, 3, 16, 24, generator=g)
+    w4 = _stem_filter(w7, torch.zeros(8, 16, 4, 4))
+    xs = F.pad(F.pixel_unshuffle(x, 2), (2, 1, 2, 1))           # two zero block columns / rows in front, one behind
+    xs = torch.cat([xs, torch.zeros(2, 4, xs.shape[2], xs.shape[3])], 1)
+    assert float((F.conv2d(xs, w4) - F.conv2d(x, w7, None, 2, 3)).abs().max()) < 1e-4
+    d4 = torch.randn(8, 16, 4, 4, generator=g)
+    g8 = torch.zeros(8, 3, 8, 8)
+    for dy in range(2):
+        for dx in range(2):
+            g8[:, :, dy::2, dx::2] = d4[:, dy * 2 + dx:12:4]
+    assert abs(float((w4 * d4).sum()) - float((w7 * g8[:, :, 1:, 1:]).sum())) < 1e-4 * max(1.0, abs(float((w4 * d4).sum())))
