@@ -207,7 +207,12 @@ __global__ __launch_bounds__(512) void conv3x3_bwd_kernel(Bwd3Args a) {
 //   * dy rows two steps, x rows one step ahead in registers; a 4-slot dy ring, one raw barrier per row.
 // Four steps unrolled: every register set and LDS slot is a compile-time constant.
 template <int V> struct IC3 { static constexpr int value = V; };
-constexpr int B4_DROW = 66 * 64;                 // a staged dy row: 66 pixels x 32 channels
+constexpr int B4_DPP = 80;                       // bytes per staged dy pixel: 32 channels x 2 B + 16 of padding.  With the natural
+                                                 // 64-byte pitch the 16 lanes of a B-fragment ds_read_b128 (pixels m = 0..15, one 16-byte
+                                                 // piece each) fall on (4 m + piece) mod 16 = four 16-byte bank groups, a 4-way conflict on
+                                                 // every one of the 18 fragment reads of a row (rocprofv3: 1.64 conflict cycles per LDS
+                                                 // instruction); 80 = 5 x 16 makes them (5 m + piece) mod 16: all sixteen, once
+constexpr int B4_DROW = 66 * B4_DPP;             // a staged dy row: 66 pixels x 32 channels
 constexpr int B4_TBP = 64;                       // transposition tile: 32 channels x 2 B per pixel, no padding: the 16-byte unit u
                                                  // of pixel p sits at u ^ ((p >> 1) & 3), which makes the ds_read_b128 lane groups
                                                  // (pixels {0,3,5,6} / {1,2,4,7} of eight) cover all 64 banks once and the
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   const bool dcol = d_thr && dpx >= 0 && dpx < a.W;
   const unsigned short* dimg = a.dy + (long long)n * a.dy_sn;
   const unsigned dvo = dcol ? 2u * (unsigned)(dpx * a.dy_sw + dpiece * 8) : 0u;   // bytes
-  char* dwp = ring + (d_thr ? dpix * 64 + dpiece * 16 : 0);
+  char* dwp = ring + (d_thr ? dpix * B4_DPP + dpiece * 16 : 0);
   u32x4 dyr[2];
   unsigned dym[2];
   auto request_dy = [&](int rr, auto S) __attribute__((always_inline)) {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
     }
   };
   // B fragment (pixel tile t, shift kx) of a staged row = 16 pixels x 64 B starting at pixel 32 pxh + 16 t + kx
-  const char* bptr = ring + (pxh * 32 + m) * 64 + kgl * 16;
+  const char* bptr = ring + (pxh * 32 + m) * B4_DPP + kgl * 16;
   f32x4 acc[2][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(rowp + (16 * t + kx) * 64));
+          const bf16x8 bfr = __builtin_bit_cast(bf16x8, lds_read16(rowp + (16 * t + kx) * B4_DPP));
 #pragma unroll
           for (int c2 = 0; c2 < 2; ++c2) {
             const bf16x8 afr = ky < 2 ? A[ky * 3 + kx][c2] : __builtin_bit_cast(bf16x8, lds_read16(wf + (kx * 2 + c2) * 1024));
