@@ -392,8 +392,26 @@ def forward_1024(g, dev, batch=4, size=1024, warm=2, steps=5):
             "GB/s": round(by / dt / 1e9, 1), "frac_hbm": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "finite": ok}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves, one process
+    per GPU, exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` would, and
+    pass rank 0's JSON line through.  The reference's multi-GPU mechanism is nn.DataParallel(netG) inside ONE process
+    (/root/reference/demo.py:89); one process per GPU over RCCL is this build's form of it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     from fdgan_hip.dp import DpContext

@@ -6,7 +6,10 @@
 // dependency on it and loads on a box without RCCL), the caller distributes the 128-byte unique id out of band, and the sum runs
 // in place on the caller's stream.  One process per GPU, one communicator per process.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "common.h"
 
@@ -32,13 +35,16 @@ struct Rccl {
 
 int rccl_load(Rccl** out) {
   static Rccl lib;
-  static int state = 0;   // 0 not tried, 1 ok, -1 failed
-  if (state == 0) {
+  static int state = 0;   // 1 ok, -1 failed
+  static char why[256] = "symbols missing";
+  static std::once_flag once;
+  std::call_once(once, [] {
     // a process that already runs torch has its RCCL loaded: the soname resolves to that copy
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
       lib.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (lib.handle) break;
+      if (const char* e = dlerror()) snprintf(why, sizeof(why), "%s", e);   // dlerror() clears itself: read it once, right here
     }
     if (lib.handle) {
       lib.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(lib.handle, "ncclGetUniqueId"));
@@ -47,9 +53,11 @@ int rccl_load(Rccl** out) {
       lib.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(lib.handle, "ncclCommDestroy"));
       lib.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(lib.handle, "ncclGetErrorString"));
     }
+    if (lib.handle && !(lib.get_unique_id && lib.comm_init_rank && lib.all_reduce && lib.comm_destroy))
+      snprintf(why, sizeof(why), "symbols missing");
     state = (lib.handle && lib.get_unique_id && lib.comm_init_rank && lib.all_reduce && lib.comm_destroy) ? 1 : -1;
-  }
-  if (state != 1) FD_FAIL(FD_EUNSUPPORTED, "allreduce: RCCL (librccl.so) is not available in this process: %s", dlerror() ? dlerror() : "symbols missing");
+  });
+  if (state != 1) FD_FAIL(FD_EUNSUPPORTED, "allreduce: RCCL (librccl.so) is not available in this process: %s", why);
   *out = &lib;
   return FD_OK;
 }

@@ -432,12 +432,17 @@ class PlanBackward:
             if bn is not None:
                 train_bn = bn.weight is not None and bn.weight.requires_grad
                 d = self._deferred(x)
+                # table entries that are constants, not batch statistics (eval-mode BatchNorm, finished values behind a BatchNorm +
+                # Dropout2d pass) get no correction terms.  finalize_coef ADDS into the buffer's shared pair, so their columns are
+                # set aside and put back: zeroing them afterwards would also erase the terms other consumers of the same channels
+                # (a train-mode transition behind eval-mode dense layers) added earlier in the walk and have not flushed
+                keep = [(lo, hi, d["coef"][:, x.c0 + lo:x.c0 + hi].clone()) for lo, hi in _constant_entries(meta, cin)]
                 E.bn_bwd_finalize_coef(self.ws_bn, rows, cpad, cin, act_pro, n * hin * win, d["coef"][0, x.c0:x.c0 + cin],
                                        d["coef"][1, x.c0:x.c0 + cin],
                                        sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                                        sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
-                for lo, hi in _constant_entries(meta, cin):  # table entries that are constants, not batch statistics: no
-                    d["coef"][:, x.c0 + lo:x.c0 + hi].zero_()  # correction terms (finished values behind a BatchNorm + Dropout2d pass)
+                for lo, hi, saved in keep:
+                    d["coef"][:, x.c0 + lo:x.c0 + hi].copy_(saved)
                 d["dirty"].update(range(x.c0, x.c0 + cin))
             if check:
                 self.flush(x)

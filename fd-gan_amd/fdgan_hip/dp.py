@@ -110,6 +110,40 @@ class DpContext:
             self._owns = False
 
 
+class RankBatches:
+    """`batch_sampler` for a DataLoader under data parallelism: every rank runs the SAME number of equally sized steps.
+
+    Each epoch is one permutation of the dataset drawn from an explicit generator seeded `seed + epoch` (identical on all
+    ranks by construction, not by the global RNG staying in sync), cut into global batches of `world * batch` items; rank r
+    takes items [r*batch, (r+1)*batch) of each -- the partitioning of DpContext.batch_slice.  The ragged tail (fewer than
+    world * batch items) is DROPPED: a step that only some ranks run would issue gradient all-reduces no peer matches and
+    hang the job, and a short batch on one rank would be averaged with weight 1/world.  Each rank reads only
+    its own items.  The reference trains in one process (nn.DataParallel, demo.py:89) and has no such rule to mirror."""
+
+    def __init__(self, n_items, batch, world=1, rank=0, seed=0, shuffle=True):
+        if not 0 <= rank < world:
+            raise ValueError("rank %d outside world %d" % (rank, world))
+        self.n, self.batch, self.world, self.rank, self.seed, self.shuffle, self.epoch = n_items, batch, world, rank, seed, shuffle, 0
+        if len(self) == 0:
+            raise ValueError("%d items cannot fill one global batch of %d ranks x %d" % (n_items, world, batch))
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.n // (self.batch * self.world)
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator(device="cpu").manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        gb = self.batch * self.world
+        for s in range(0, len(self) * gb, gb):
+            yield order[s + self.rank * self.batch: s + (self.rank + 1) * self.batch]
+
+
 class GradBuckets:
     """Data-parallel gradient averaging for the training path: RCCL all-reduce (backend "nccl" on the GPU
     box, "gloo" in the CPU tests) of flat fp32 buckets, launched in REVERSE parameter order so the first

@@ -115,11 +115,27 @@ def _wants_grad(module, x):
 
 def _param_list(module):
     """module.parameters() as a list found once per module (the generator has 786 of them; the recursive walk cost 0.4 ms per
-    call); rebuilt when a child is added or removed, or a parameter object is replaced."""
+    call).  Validated on every call against the module tree it was built from: every submodule's child and parameter COUNT, and
+    the identity of every Parameter object in its owner's `_parameters` dict -- so `m.sub.weight = nn.Parameter(...)`,
+    pruning / spectral-norm reparametrisation, or a parameter added to a nested child all rebuild it (the first four
+    parameters and the top-level child count alone missed those)."""
     c = module.__dict__.get("_fd_param_list")
-    if c is None or c[0] != len(module._modules) or any(p is not q for p, q in zip(c[1][:4], module.parameters())):
-        c = module.__dict__["_fd_param_list"] = (len(module._modules), list(module.parameters()))
-    return c[1]
+    if c is not None:
+        for m, n_par, n_mod in c[0]:
+            if len(m._parameters) != n_par or len(m._modules) != n_mod:
+                c = None
+                break
+    if c is not None:
+        for d, name, p in c[1]:
+            if d.get(name) is not p:
+                c = None
+                break
+    if c is None:
+        mods = list(module.modules())
+        owners = [(m._parameters, name, p) for m in mods for name, p in m._parameters.items() if p is not None]
+        c = module.__dict__["_fd_param_list"] = ([(m, len(m._parameters), len(m._modules)) for m in mods], owners,
+                                                 list(module.parameters()))
+    return c[2]
 
 
 def _apply_plan_function(module, x):
@@ -654,6 +670,7 @@ class _DenseBase(_PlannedModule):
     def _forward_plan(self, x):
         P = self._plan_for(x)
         w7 = self.conv0.weight
+        P.w0.requires_grad_(w7.requires_grad)             # a derived leaf follows its source: freezing / unfreezing after the plan exists
         with torch.no_grad():
             if getattr(P.w0, "_src_version", None) != (w7._version, w7.data_ptr()):
                 _stem_filter(w7, P.w0)
@@ -727,6 +744,7 @@ class _DensePyramid(_DenseBase):
 
     def _refresh_tail(self, P):
         wf = self.refine3.weight
+        P.wfinal.requires_grad_(wf.requires_grad)
         if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
             P.wfinal[:, :20].copy_(wf.detach()[:, 4:])       # reference order: [pyramid 0-3 | x9 4-23]
             P.wfinal[:, 20:].copy_(wf.detach()[:, :4])

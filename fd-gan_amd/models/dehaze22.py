@@ -398,6 +398,8 @@ class _UNet(_PlannedModule):
         with torch.no_grad():
             for w_t, filt in P.derived:
                 ver = w_t._version
+                for f in filt:
+                    f.requires_grad_(w_t.requires_grad)
                 if getattr(filt[0], "_src_version", None) != (ver, w_t.data_ptr()):
                     _phase_filters(w_t, filt)
                     filt[0]._src_version = (ver, w_t.data_ptr())
@@ -485,6 +487,7 @@ class G(_UNet):
     def _run(self, x):
         P = self._plan_for(x)
         wf = self.dlayerfinal.dlayer1.conv.weight
+        P.wfinal.requires_grad_(wf.requires_grad)
         with torch.no_grad():                        # reference channel order [pyramid 0-3 | dout1 4-23] -> buffer order
             if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
                 P.wfinal[:, :20].copy_(wf.detach()[:, 4:])
@@ -613,6 +616,7 @@ class dehaze(_PlannedModule):
                 P.pw[i].copy_(conv.weight.detach().view(20))
                 P.pb[i:i + 1].copy_(conv.bias.detach())
             wf = self.refine3.weight
+            P.wfinal.requires_grad_(wf.requires_grad)
             if getattr(P.wfinal, "_src_version", None) != (wf._version, wf.data_ptr()):
                 P.wfinal[:, :20].copy_(wf.detach()[:, 4:])       # reference order: [pyramid 0-3 | features 4-23]
                 P.wfinal[:, 20:].copy_(wf.detach()[:, :4])

@@ -209,7 +209,7 @@ def build_parser():
 
 def run(opt):
     """Trains and returns (checkpoint paths written, last loss dict).  With --dataroot: epochs over the .h5 pairs through
-    misc.getLoader (rank r takes every world-th batch); without: --niter steps on synthetic images."""
+    misc.getLoader (N ranks: fdgan_hip.dp.RankBatches, equal step counts, ragged tail dropped); without: --niter steps on synthetic images."""
     dp = DpContext.from_env()
     dev = dp.device or torch.device("cuda", 0)
     synthetic = not opt.dataroot
@@ -246,14 +246,21 @@ def run(opt):
     else:
         loader = misc.getLoader(opt.dataset, opt.dataroot, opt.originalSize, opt.imageSize, opt.batchSize, opt.workers,
                                 split="train", shuffle=True, seed=1234)
+        sampler = None
+        if dp.world > 1:
+            # one process: the reference's loader as it is (shuffled, ragged last batch).  N ranks: equal step counts on every
+            # rank or the all-reduces of the odd step out have no peer (fdgan_hip.dp.RankBatches)
+            from fdgan_hip.dp import RankBatches
+            sampler = RankBatches(len(loader.dataset), opt.batchSize, dp.world, dp.rank, seed=1234)
+            loader = torch.utils.data.DataLoader(loader.dataset, batch_sampler=sampler, num_workers=int(opt.workers))
         for epoch in range(opt.niter):
             if epoch > opt.annealStart:                  # linear decay, as misc.adjust_learning_rate is written to be used
                 misc.adjust_learning_rate(ts.optG, opt.lrG, epoch, None, opt.annealEvery)
                 misc.adjust_learning_rate(ts.optD, opt.lrD, epoch, None, opt.annealEvery)
             vals = None
-            for i, (haze, gt) in enumerate(loader):
-                if i % dp.world != dp.rank:
-                    continue
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            for haze, gt in loader:
                 vals = one(haze.float().to(dev, non_blocking=True), gt.float().to(dev, non_blocking=True))
             if vals is not None:
                 last = ts.losses_dict(vals)

@@ -96,14 +96,14 @@ def main():
     # gradients are comparable.)  Stored: per parameter 64 signed strided sums + the norm of the REFERENCE's gradient,
     # and the oracle-vs-bf16-emulating-oracle disagreement of that parameter (the noise floor a bf16 path can reach).
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from hiputil import emulate_bf16_operands, rel_rms
+    from hiputil import emulate_kernel_operands, rel_rms
     from oracle.detweights import grad_projection, shift_bn_bias
     ogw, rgw, oew = o1113.FDGAN(), r1113.FDGAN(), o1113.FDGAN()
     fill_state_dict(ogw, seed=0)
     shift_bn_bias(ogw, 3.0)
     _copy_weights(rgw, ogw)
     oew.load_state_dict(ogw.state_dict())
-    emulate_bf16_operands(oew)
+    emulate_kernel_operands(oew)
     xw = det_input((8, 3, 64, 64), seed=1234)
     tw = det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
     yrw = rgw(xw.clone())

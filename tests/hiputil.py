@@ -78,8 +78,8 @@ def seeded(shape, seed, lo=-1.0, hi=1.0):
     return torch.from_numpy(a.astype(np.float32))
 
 
-def emulate_bf16_operands(module, round_grads=False):
-    """(Name kept from the all-bf16 rounds.)  Turns an fp32 oracle network into a statement of what the HIP path computes:
+def emulate_kernel_operands(module, round_grads=False):
+    """Turns an fp32 oracle network into a statement of what the HIP path computes:
     every conv sees its filter, its (activated) input and its stored output rounded to fp16 -- the forward element format;
     activation gradients are rounded to bf16 with round_grads -- straight-through for autograd -- and in-place
     activations are made out-of-place so conv outputs can be inspected.  Accumulation stays fp32/fp64.

@@ -166,3 +166,55 @@ def test_two_rank_overlapped_allreduce_of_the_flat_gradient(tmp_path):
         assert torch.allclose(r[0]["grad"][off:off + n], torch.full((n,), want)), k
         off += (n + 3) // 4 * 4
     assert r[0]["early"] >= 1            # at least one slice left before the walk ended
+
+
+def _loader_worker(rank, world, port, out_dir, root):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from datasets.pix2pix import pix2pix
+    from fdgan_hip.dp import DpContext, RankBatches
+    dp = DpContext.from_env(backend="gloo", device=torch.device("cpu"))
+    ds = pix2pix(root)
+    sampler = RankBatches(len(ds), 2, dp.world, dp.rank, seed=1234)
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=sampler, num_workers=0)
+    seen, steps = [], 0
+    for epoch in range(2):
+        sampler.set_epoch(epoch)
+        ids = []
+        for haze, gt in loader:
+            assert haze.shape == (2, 3, 8, 8)
+            # what TrainStep.step does once per step: a collective every rank must match (the job hangs here if step counts differ)
+            t = torch.tensor([float(haze[:, 0, 0, 0].sum())], dtype=torch.float64)
+            dist.all_reduce(t)
+            ids += [int(round(float(v) * 100)) for v in haze[:, 0, 0, 0]]
+            steps += 1
+        seen.append(ids)
+    torch.save(dict(seen=seen, steps=steps, n=len(sampler)), os.path.join(out_dir, "l%d.pt" % rank))
+    dp.close()
+
+
+def test_two_rank_epoch_loader_equal_steps_with_odd_batch_count(tmp_path):
+    """train.py sharded `if i % world != rank: continue` over a loader without drop_last, so with an odd number of
+    batches one rank ran a step (and its all-reduces) no peer matched.  11 items, batch 2, 2 ranks = 5.5 batches: both ranks must
+    run exactly 2 steps per epoch on disjoint items, the same permutation on both, a different one per epoch, tail dropped."""
+    import numpy as np
+    from datasets.pix2pix import write_pair
+    root = str(tmp_path / "data")
+    for i in range(11):
+        img = np.full((8, 8, 3), i / 100.0, np.float32)
+        write_pair(root, i, img, img)
+    world = 2
+    mp.spawn(_loader_worker, args=(world, _free_port(), str(tmp_path), root), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "l%d.pt" % i)) for i in range(world)]
+    assert r[0]["n"] == r[1]["n"] == 2 and r[0]["steps"] == r[1]["steps"] == 4
+    for e in range(2):
+        a, b = r[0]["seen"][e], r[1]["seen"][e]
+        assert len(a) == len(b) == 4 and not set(a) & set(b) and set(a) | set(b) <= set(range(11))
+    assert r[0]["seen"][0] != r[0]["seen"][1]                        # reshuffled per epoch
+    import pytest
+    from fdgan_hip.dp import RankBatches
+    with pytest.raises(ValueError):
+        RankBatches(3, 2, 2, 0)                                      # cannot fill one global batch
+    one = RankBatches(5, 2, 1, 0, shuffle=False)
+    assert list(one) == [[0, 1], [2, 3]]

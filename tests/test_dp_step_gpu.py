@@ -143,6 +143,32 @@ def test_bench_py_single_rank_through_rccl(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_py_plain_python_launches_its_own_ranks(gpus):
+    """The driver's command shape with NO launcher around it: `python bench.py --gpus N --steps K --warmup W` and WORLD_SIZE
+    unset.  N = 1 runs in-process; N = 2 must start its own two ranks (bench.self_launch -> torch.distributed.run on
+    127.0.0.1; both on cuda:0 over gloo through the FDGAN_BENCH_SHARED_GPU hook on this one-GPU box) instead of dying on an
+    argument check (VERDICT r3, next #1a).  The reference's only multi-GPU mechanism is /root/reference/demo.py:89."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FDGAN_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--size", "64", "--no-forward-leg", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["config"]["parallelism"] == "dp%d" % gpus and d["config"]["global_batch"] == 2 * gpus
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    if gpus > 1:
+        assert d["config"]["gradient_exchange"]["rccl_ranks"] == gpus
+
+
+@pytest.mark.gpu
 def test_c_abi_allreduce_one_rank_communicator():
     """include/fdgan_hip.h fdgan_allreduce_*: the RCCL wrapper a non-PyTorch host would use for the gradient exchange,
     as far as ONE GPU lets it be exercised: unique id, a world-size-1 communicator, an in-place fp32 sum on a side stream (the

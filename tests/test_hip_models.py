@@ -39,6 +39,12 @@ def nets():
     return net, ref
 
 
+# Floors at measured - 6 dB; the measurements are in profiles/r4_parity_*.json
+RAGGED_FLOOR_DB = 55.0
+WELLCOND_FWD_FLOOR_DB = 55.0
+TRAIN_B16_FLOOR_DB = 55.0
+
+
 def test_fdgan_train_mode_matches_oracle_and_golden(nets, golden_dir):
     net, ref = nets
     from oracle.detweights import det_input, fill_state_dict
@@ -64,9 +70,9 @@ def test_fdgan_train_mode_matches_oracle_and_golden(nets, golden_dir):
         rep["taps"][k] = rel_rms(P.taps[k].torch_nchw().cpu(), v)
     _report("fdgan_train", rep)
     for k, e in rep["taps"].items():
-        assert e < 0.05, (k, e)
-    assert rep["psnr_vs_oracle"] > 38.0, rep
-    assert rep["psnr_vs_golden"] > 38.0, rep
+        assert e < 0.011, (k, e)                     # measured <= 0.0053 (fp16 forward); floors = measured - 6 dB
+    assert rep["psnr_vs_oracle"] > 59.0, rep         # measured 65.06 dB
+    assert rep["psnr_vs_golden"] > 59.0, rep
     # train-mode BatchNorm side effects
     sd, osd = g.state_dict(), og.state_dict()
     for name in ("dense_block1.denselayer1.norm1", "dense_block2.denselayer12.norm2", "trans_block3.norm",
@@ -99,7 +105,7 @@ def test_fdgan_eval_mode_matches_golden(nets, golden_dir):
     gold = torch.from_numpy(np.load(os.path.join(golden_dir, "fdgan_2x64_eval.npz"))["y"])
     rep = {"psnr_vs_golden": psnr(y, gold), "max_abs": float((y - gold).abs().max())}
     _report("fdgan_eval", rep)
-    assert rep["psnr_vs_golden"] > 38.0, rep
+    assert rep["psnr_vs_golden"] > 65.5, rep         # measured 71.75 dB
     assert int(g.state_dict()["trans_block3.norm.num_batches_tracked"]) == 0
 
 
@@ -116,7 +122,8 @@ def test_fdgan_other_shapes_and_errors(nets):
         y_ref = og(x.clone())
         y = g(x.to(DEV)).cpu()
     assert y.shape == (1, 3, 40, 72)
-    assert psnr(y, y_ref) > 36.0
+    _report("fdgan_ragged_40x72", {"psnr_vs_oracle": psnr(y, y_ref)})
+    assert psnr(y, y_ref) > RAGGED_FLOOR_DB, psnr(y, y_ref)
     with pytest.raises(ValueError):
         g(torch.zeros(1, 3, 36, 64, device=DEV))
     with pytest.raises(RuntimeError):
@@ -358,8 +365,18 @@ def test_fdgan_full_size_properties(nets):
     with torch.no_grad():
         y_ref = og(x[:1].cpu())
     rep = {"psnr_eval_256": psnr(y16[:1].cpu(), y_ref)}
+    # configs[1] in the REFERENCE's mode: train-mode BatchNorm over the whole batch of 16 @ 256^2 (one ~40 s oracle forward on
+    # the host): the batch statistics couple all sixteen images, so this is the comparison eval mode cannot stand in for
+    og.train()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        t_ref = og(x.cpu())
+    rep["psnr_train_256_b16"] = psnr(t16.cpu(), t_ref)
+    rep["train_256_b16_max_abs"] = float((t16.cpu() - t_ref).abs().max())
+    rep["psnr_train_256_b16_worst_image"] = min(psnr(t16[i:i + 1].cpu(), t_ref[i:i + 1]) for i in range(16))
     _report("fdgan_full_size", rep)
-    assert rep["psnr_eval_256"] > 38.0, rep
+    assert rep["psnr_eval_256"] > 64.0, rep          # measured 70.28 dB
+    assert rep["psnr_train_256_b16"] > TRAIN_B16_FLOOR_DB and rep["psnr_train_256_b16_worst_image"] > TRAIN_B16_FLOOR_DB - 3.0, rep
 
 
 def test_fdgan_high_res_1024(nets):
@@ -391,7 +408,7 @@ def test_fdgan_high_res_1024(nets):
         y_ref = og(x[:1].cpu())
     rep = {"psnr_eval_1024": psnr(y4[:1].cpu(), y_ref), "max_abs": float((y4[:1].cpu() - y_ref).abs().max())}
     _report("fdgan_1024", rep)
-    assert rep["psnr_eval_1024"] > 38.0, rep
+    assert rep["psnr_eval_1024"] > 64.0, rep         # measured 70.03 dB
 
 
 def test_frequency_split_1024():
@@ -448,7 +465,8 @@ def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
     y = g(x)
     ((y - tgt) ** 2).mean().backward()
     torch.cuda.synchronize()
-    assert psnr(y.detach().cpu()[:, :, ::4, ::4], torch.from_numpy(gold["y"])) > 38.0
+    fwd_db = psnr(y.detach().cpu()[:, :, ::4, ::4], torch.from_numpy(gold["y"]))
+    assert fwd_db > WELLCOND_FWD_FLOOR_DB, fwd_db
     rep, bad, zero_grad = {}, [], []
     for name, p in g.named_parameters():
         key = name.replace(".", "__")
@@ -488,21 +506,21 @@ def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
 def test_fusion_d_backward_matches_oracle_and_golden(nets, golden_dir):
     """Training-path slice: D(9,36) forward + backward through the HIP plan under torch autograd.
 
-    Three references, because LeakyReLU's derivative is discontinuous (tests/hiputil.emulate_bf16_operands):
+    Three references, because LeakyReLU's derivative is discontinuous (tests/hiputil.emulate_kernel_operands):
       * the oracle with conv operands rounded to bf16 where the kernels round them, random cotangent:
         same masks up to ~0.05 % of the elements -> 5e-2 (measured 2-3 %);
       * the plain fp32 oracle, random cotangent: 0.15 (measured 4-8 %: ~0.3 % of the masks differ);
       * the golden file (`out.mean()` through the REAL reference): every element of dL/dout is identical, so
         BatchNorm's backward cancels most of the incoming gradient and amplifies the above: 0.15 (measured
         10 % at the network input); the oracle reproduces the golden gradient to 1e-4."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     net, ref = nets
     from oracle.detweights import det_input, fill_state_dict
     od = ref.D(9, 36)
     fill_state_dict(od, seed=1)
     oe = ref.D(9, 36)
     oe.load_state_dict(od.state_dict())
-    emulate_bf16_operands(oe)
+    emulate_kernel_operands(oe)
     d = net.D(9, 36)
     d.load_state_dict(od.state_dict())
     d = d.to(DEV)
@@ -556,7 +574,7 @@ def _grad_report(hip_module, oracle_module):
 
 def test_dy_blocks_backward(nets):
     """BottleneckBlockdy / TransitionBlockdy under autograd vs the bf16-emulating oracle (random cotangent)."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     net, ref = nets
     from oracle.detweights import det_input, fill_state_dict
     rep = {}
@@ -567,7 +585,7 @@ def test_dy_blocks_backward(nets):
         b = ctor(net)
         b.load_state_dict(ob.state_dict())
         b = b.to(DEV)
-        emulate_bf16_operands(ob)
+        emulate_kernel_operands(ob)
         x = det_input(shape, seed=41, lo=-1.0, hi=1.0)
         cot = det_input(oshape, seed=42, lo=-1.0, hi=1.0)
         xo = x.clone().requires_grad_(True)
@@ -589,7 +607,7 @@ def test_dense_block_backward_small(nets):
     """Three dense layers + a pooled transition on a shared concat buffer (recomputed bottleneck, accumulated
     prefix gradients, BatchNorm statistics of a growing concat) vs the bf16-emulating oracle: shallow enough
     for a network-level comparison to be well conditioned."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     import models.dehaze1113 as net
     import models.tv_densenet121 as tv
     from fdgan_hip import engine as E
@@ -606,7 +624,7 @@ def test_dense_block_backward_small(nets):
     hmod = nn.Sequential(block, trans)
     hmod.load_state_dict(omod.state_dict())
     hmod = hmod.to(DEV)
-    emulate_bf16_operands(omod)
+    emulate_kernel_operands(omod)
     x = det_input((n, c0, h, w), seed=51, lo=-1.0, hi=1.0)
     cot = det_input((n, 64, h // 2, w // 2), seed=52, lo=-1.0, hi=1.0)
     xo = x.clone().requires_grad_(True)
@@ -660,14 +678,14 @@ def test_fdgan_backward_matches_oracle_and_golden(nets, golden_dir):
         gradient < 2e-2);
       * decoder / transition / refine parameters are compared with the bf16-emulating oracle (< 0.12);
       * everything is compared with the reference's golden gradients at the oracle-vs-oracle noise level."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     net, ref = nets
     from oracle.detweights import det_input, fill_state_dict
     og = ref.FDGAN()
     fill_state_dict(og, seed=0)
     oe = ref.FDGAN()
     oe.load_state_dict(og.state_dict())
-    emulate_bf16_operands(oe)
+    emulate_kernel_operands(oe)
     g = net.FDGAN()
     g.load_state_dict(og.state_dict())
     g = g.to(DEV)
@@ -713,7 +731,7 @@ def test_vgg16_backward_perceptual_path(golden_dir):
     """Perceptual-loss path: gradients of the four VGG16 feature maps back to the image (frozen filters) and
     to the filters (unfrozen), through 10 conv+ReLU epilogues and 3 max-pools; every op verified in place, the
     image gradient compared with the bf16-emulating oracle."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     from myutils.vgg16 import Vgg16
     from oracle.vgg16_ref import Vgg16 as OVgg
     from oracle.detweights import det_input, fill_state_dict
@@ -722,7 +740,7 @@ def test_vgg16_backward_perceptual_path(golden_dir):
     v = Vgg16()
     v.load_state_dict(ov.state_dict())
     v = v.to(DEV)
-    emulate_bf16_operands(ov)
+    emulate_kernel_operands(ov)
     x = det_input((2, 3, 32, 48), seed=61, lo=0.0, hi=1.0)
     shapes = [(2, 64, 32, 48), (2, 128, 16, 24), (2, 256, 8, 12), (2, 512, 4, 6)]
     cots = [det_input(s, seed=70 + i, lo=-1.0, hi=1.0) for i, s in enumerate(shapes)]
@@ -1058,7 +1076,7 @@ def test_flat_gradient_sink_equals_autograd_accumulation():
 
 def test_dehaze22_d_backward():
     """PatchGAN D (4x4 stride-2 convs: any-stride direct data gradient) under autograd vs the bf16-emulating oracle."""
-    from hiputil import emulate_bf16_operands
+    from hiputil import emulate_kernel_operands
     import models.dehaze22 as net22
     from oracle import dehaze22_ref as o22
     from oracle.detweights import det_input, fill_state_dict
@@ -1067,7 +1085,7 @@ def test_dehaze22_d_backward():
     d = net22.D(9, 36)
     d.load_state_dict(od.state_dict())
     d = d.to(DEV)
-    emulate_bf16_operands(od)
+    emulate_kernel_operands(od)
     x = det_input((2, 9, 64, 64), seed=77, lo=-1.0, hi=1.0)
     cot = det_input((2, 1, 6, 6), seed=5, lo=-1.0, hi=1.0)
     xo = x.clone().requires_grad_(True)
@@ -1572,3 +1590,39 @@ def test_backward_through_eval_mode_batchnorm(nets):
         # against the PLAIN fp32 oracle (no rounding emulation): the generator's 282 gradients sit at 6 % median / 8 % p90 / 16 % worst
         # (an un-normalised random-weight network in eval mode: running statistics are the defaults), D's nine at 2-3 %
         assert rep[name]["median"] < 0.10 and rep[name]["p90"] < 0.15 and rep[name]["worst"] < 0.30, rep
+
+
+def test_backward_mixed_train_eval_batchnorm_in_one_dense_block(nets):
+    """`dense_block1.eval()` with `trans_block1` left in train mode.  The transition's one-pass BatchNorm backward
+    parks its B * x + C correction for channels [0, 256) in the concat buffer's SHARED coefficient pair; the eval-mode dense layers
+    that read the same channels afterwards in the reverse walk have no correction terms of their own and used to ZERO those
+    columns -- wiping the transition's pending ones, so every dense layer's weights (and everything upstream) got silently wrong
+    gradients.  Well-conditioned weights (BatchNorm biases + 3, batch 8 @ 64x64: the emulated-vs-fp32 oracle distance is 0.8 % there)
+    against torch.autograd over the oracle in the same mixed mode."""
+    from hiputil import emulate_kernel_operands
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict, shift_bn_bias
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    shift_bn_bias(og, 3.0)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    emulate_kernel_operands(og)
+    g.train(), og.train()
+    g.dense_block1.eval(), og.dense_block1.eval()
+    x = det_input((8, 3, 64, 64), seed=1234)
+    tgt = det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
+    ((og(x.clone()) - tgt) ** 2).mean().backward()
+    ((g(x.to(DEV)) - tgt.to(DEV)) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    r = _grad_report(g, og)
+    b1 = {k: v for k, v in r.items() if k.startswith("dense_block1.") and k.endswith("weight")}
+    rest = sorted(v for k, v in r.items() if not k.startswith("dense_block1.") and not k.endswith("conv_refine4.bias"))
+    rep = {"dense_block1_worst": max(b1.values()), "dense_block1_median": sorted(b1.values())[len(b1) // 2],
+           "rest_median": rest[len(rest) // 2], "rest_p90": rest[int(0.9 * len(rest))], "n_block1": len(b1),
+           "rm_untouched": float((g.dense_block1.denselayer3.norm1.running_mean.cpu() - og.dense_block1.denselayer3.norm1.running_mean).abs().max()),
+           "trans_nbt": int(g.trans_block1.norm.num_batches_tracked)}
+    _report("backward_mixed_mode_bn", rep)
+    assert rep["n_block1"] == 6 * 4 and rep["rm_untouched"] == 0.0 and rep["trans_nbt"] == 1, rep
+    assert rep["dense_block1_worst"] < 0.08 and rep["dense_block1_median"] < 0.03 and rep["rest_median"] < 0.03, rep

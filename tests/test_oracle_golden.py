@@ -184,6 +184,44 @@ def test_oracle_reproduces_wellconditioned_reference_gradients(golden_dir):
     assert n == 282
 
 
+def test_wellconditioned_tolerance_rows_match_the_committed_emulation(golden_dir):
+    """The per-parameter tolerance rows `o2o__*` of fdgan_8x64_wellcond.npz (and MANIFEST's oracle_vs_emulated_median) are the
+    distance between the fp32 oracle and tests/hiputil.emulate_kernel_operands AS COMMITTED.  VERDICT r3 weak #1: the helper
+    moved from bf16 to fp16 rounding while the fixture kept the bf16-era rows (median 3.2 % where the recipe gives 0.8 %), so the
+    GPU test's bound was 4x looser than its docstring.  This re-runs the emulation here and fails when the fixture is stale."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hiputil import emulate_kernel_operands, rel_rms
+    from oracle import dehaze1113_ref as ref
+    from oracle.detweights import det_input, fill_state_dict, shift_bn_bias
+    gold = _load(golden_dir, "fdgan_8x64_wellcond.npz")
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["fdgan_wellcond"]
+    og, oe = ref.FDGAN(), ref.FDGAN()
+    fill_state_dict(og, seed=0)
+    shift_bn_bias(og, man["bn_bias_shift"])
+    oe.load_state_dict(og.state_dict())
+    emulate_kernel_operands(oe)
+    x, tgt = det_input((8, 3, 64, 64), seed=1234), det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
+    ((og(x.clone()) - tgt) ** 2).mean().backward()
+    ((oe(x.clone()) - tgt) ** 2).mean().backward()
+    pe = dict(oe.named_parameters())
+    now, then = [], []
+    for name, p in og.named_parameters():
+        key = "o2o__" + name.replace(".", "__")
+        if key not in gold.files:
+            continue
+        now.append(rel_rms(pe[name].grad, p.grad))
+        then.append(float(gold[key]))
+    now, then = np.array(now), np.array(then)
+    assert len(now) == 282
+    # rounding decisions are deterministic; only fp32 reduction order (thread count) moves a row, by far less than this
+    assert abs(np.median(now) - man["oracle_vs_emulated_median"]) < 0.1 * man["oracle_vs_emulated_median"], (np.median(now), man)
+    assert abs(np.median(then) - man["oracle_vs_emulated_median"]) < 1e-9
+    ok = np.abs(now - then) <= 0.25 * then + 1e-4
+    assert ok.mean() > 0.97, (float(ok.mean()), float(np.median(now)), float(np.median(then)))
+
+
 def test_loss_module_restatements_are_pinned_to_the_reference_bytecode(golden_dir):
     """tests/golden/loss_pyc_constants.json = names / constants / line numbers extracted from the reference's
     __pycache__/loss.cpython-36.pyc (oracle/pin_loss_pyc.py); the Blur / Laplacian / ContextualLoss restatements must

@@ -5,10 +5,10 @@ import torch
 import models.dehaze1113 as net
 from oracle import dehaze1113_ref as ref
 from oracle.detweights import det_input, fill_state_dict
-from hiputil import rel_rms, emulate_bf16_operands
+from hiputil import rel_rms, emulate_kernel_operands
 og = ref.FDGAN(); fill_state_dict(og, seed=0)
 g = net.FDGAN(); g.load_state_dict(og.state_dict()); g = g.to("cuda:0")
-emulate_bf16_operands(og)
+emulate_kernel_operands(og)
 x = det_input((2, 3, 64, 64), seed=1234); tgt = det_input((2, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
 ((og(x.clone()) - tgt) ** 2).mean().backward()
 y = g(x.to("cuda:0")); ((y - tgt.to("cuda:0")) ** 2).mean().backward(); torch.cuda.synchronize()
