@@ -103,7 +103,7 @@ def main():
     shift_bn_bias(ogw, 3.0)
     _copy_weights(rgw, ogw)
     oew.load_state_dict(ogw.state_dict())
-    emulate_kernel_operands(oew)
+    emulate_kernel_operands(oew, round_grads=True)      # fp16 forward operands AND bf16-stored activation gradients: what the HIP path does
     xw = det_input((8, 3, 64, 64), seed=1234)
     tw = det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
     yrw = rgw(xw.clone())

@@ -437,9 +437,14 @@ def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
 
     Conditioning: batch 8 @ 64x64 with every BatchNorm bias shifted by +3 (oracle/detweights.shift_bn_bias), which
     takes almost all pre-activations off the ReLU kink; two CPU statements of the network (fp32 oracle vs the
-    bf16-operand-emulating oracle) then agree to 3 % in the median (MANIFEST: oracle_vs_emulated_median) instead of 54 %
-    with the plain weights.  Bound per parameter: 2 x max(that parameter's own oracle-vs-emulated disagreement, the
-    median) -- a bf16 path cannot be expected closer to the fp32 reference than a bf16-emulating CPU statement is.
+    CPU statement of what the HIP path computes: fp16 forward operands and bf16-stored activation gradients,
+    tests/hiputil.emulate_kernel_operands(round_grads=True)) then agree to 0.8 % in the median (MANIFEST:
+    oracle_vs_emulated_median; p90 1.5 %) instead of 54 % with the plain weights.  Bounds (round 4, after the fixture was
+    regenerated with the fp16 emulation -- the committed rows used to be the bf16-era 3.2 %): the DISTRIBUTION must match the
+    emulation's -- median and p90 of the 281 distances below 1.5 x the emulation's own median / p90 -- and every single parameter
+    must stay below 3 x max(its own oracle-vs-emulated distance, the median): one parameter's distance is a single noisy draw
+    (measured: dense_block1.denselayer1.conv2.weight 2.25 % against its emulated 1.08 %), the distribution is not.  Measured
+    on the HIP path: median 0.82 %, p90 1.25 %, worst 4.7 % (conv_refin1.bias, emulated 3.7 %).
     The fixture holds 64 signed strided sums + the norm per parameter (oracle/detweights.grad_projection).
 
     BatchNorm biases are measured on the scale of their (weight, bias) PAIR: d beta = sum dpre and d gamma = sum dpre * xhat
@@ -487,7 +492,7 @@ def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
             if pscale > gn:                               # BatchNorm bias: the (weight, bias) pair's scale (docstring)
                 scale, nscale = scale * pscale / gn, pscale
         rel = float(np.sqrt(((proj - gp) ** 2).sum()) / scale)
-        tol = 2.0 * max(o2o, man["oracle_vs_emulated_median"])
+        tol = 3.0 * max(o2o, man["oracle_vs_emulated_median"])
         rep[name] = [rel, tol, abs(norm - gn) / nscale]
         if rel > tol or abs(norm - gn) / nscale > tol:
             bad.append((name, rel, tol, norm / gn))
@@ -500,7 +505,7 @@ def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
     w = dict(g.named_parameters())["conv_refine4.weight"].grad
     assert zero_grad[0][1] < 1e-3 * float(w.norm()), zero_grad      # conv_refine4.bias feeds BatchNorm only: d/db == 0
     assert not bad, (bad[:10], summary)
-    assert summary["median"] < 2.0 * man["oracle_vs_emulated_median"], summary
+    assert summary["median"] < 1.5 * man["oracle_vs_emulated_median"] and summary["p90"] < 1.5 * man["oracle_vs_emulated_p90"], summary
 
 
 def test_fusion_d_backward_matches_oracle_and_golden(nets, golden_dir):

@@ -201,7 +201,7 @@ def test_wellconditioned_tolerance_rows_match_the_committed_emulation(golden_dir
     fill_state_dict(og, seed=0)
     shift_bn_bias(og, man["bn_bias_shift"])
     oe.load_state_dict(og.state_dict())
-    emulate_kernel_operands(oe)
+    emulate_kernel_operands(oe, round_grads=True)
     x, tgt = det_input((8, 3, 64, 64), seed=1234), det_input((8, 3, 64, 64), seed=4321, lo=-1.0, hi=1.0)
     ((og(x.clone()) - tgt) ** 2).mean().backward()
     ((oe(x.clone()) - tgt) ** 2).mean().backward()
