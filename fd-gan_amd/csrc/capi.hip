@@ -118,6 +118,7 @@ int fd_enqueue(const void* fn, const char* name, dim3 grid, dim3 block, unsigned
   L.shmem = shmem;
   L.arg.assign(static_cast<const char*>(arg), static_cast<const char*>(arg) + arg_bytes);
   if (g_recording != nullptr) {
+    L.slot = g_recording->cur_slot;
     g_recording->launches.push_back(std::move(L));
     return FD_OK;
   }
@@ -135,6 +136,7 @@ extern "C" void fdgan_plan_destroy(FdPlan* p) {
     hipEventDestroy(pr.first);
     hipEventDestroy(pr.second);
   }
+  for (hipEvent_t e : p->wait_events) hipEventDestroy(e);
   delete p;
 }
 
@@ -143,6 +145,7 @@ extern "C" int fdgan_plan_begin(FdPlan* p) {
   if (g_recording != nullptr) FD_FAIL(FD_ESTATE, "plan_begin: another plan is recording on this thread");
   if (p->exec) FD_FAIL(FD_ESTATE, "plan_begin: plan already instantiated as a graph");
   p->recording = true;
+  p->cur_slot = 0;
   g_recording = p;
   return FD_OK;
 }
@@ -152,6 +155,54 @@ extern "C" int fdgan_plan_end(FdPlan* p) {
   if (g_recording != p) FD_FAIL(FD_ESTATE, "plan_end: this plan is not recording");
   p->recording = false;
   g_recording = nullptr;
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_set_slot(FdPlan* p, int slot) {
+  FD_REQUIRE(p && g_recording == p, "plan_set_slot: this plan is not recording");
+  FD_REQUIRE(slot >= 0 && slot < 8, "plan_set_slot: slot %d outside [0, 8)", slot);
+  p->cur_slot = slot;
+  if (slot > p->max_slot) p->max_slot = slot;
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_record_wait(FdPlan* p, int waiter_slot, int signaler_slot) {
+  FD_REQUIRE(p && g_recording == p, "plan_record_wait: this plan is not recording");
+  FD_REQUIRE(waiter_slot >= 0 && waiter_slot < 8 && signaler_slot >= 0 && signaler_slot < 8 && waiter_slot != signaler_slot,
+             "plan_record_wait: slots %d <- %d", waiter_slot, signaler_slot);
+  FdLaunch L;
+  L.fn = nullptr;
+  L.name = "stream_wait";
+  L.shmem = 0;
+  L.slot = waiter_slot;
+  L.other = signaler_slot;
+  if (waiter_slot > p->max_slot) p->max_slot = waiter_slot;
+  if (signaler_slot > p->max_slot) p->max_slot = signaler_slot;
+  p->launches.push_back(std::move(L));
+  return FD_OK;
+}
+
+extern "C" int fdgan_plan_launch_multi(FdPlan* p, const FdStream* streams, int nstreams) {
+  FD_REQUIRE(p && streams, "plan_launch_multi: NULL argument");
+  if (p->recording) FD_FAIL(FD_ESTATE, "plan_launch_multi: plan is still recording");
+  FD_REQUIRE(nstreams > p->max_slot, "plan_launch_multi: the plan uses stream slots 0..%d, %d streams given", p->max_slot, nstreams);
+  size_t w = 0;
+  for (const FdLaunch& L : p->launches) {
+    if (L.fn != nullptr) {
+      int rc = do_launch(L, static_cast<hipStream_t>(streams[L.slot]));
+      if (rc != FD_OK) return rc;
+      continue;
+    }
+    if (w == p->wait_events.size()) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) FD_FAIL(FD_ELAUNCH, "plan_launch_multi: hipEventCreate failed");
+      p->wait_events.push_back(ev);
+    }
+    hipEvent_t ev = p->wait_events[w++];
+    hipError_t e = hipEventRecord(ev, static_cast<hipStream_t>(streams[L.other]));
+    if (e == hipSuccess) e = hipStreamWaitEvent(static_cast<hipStream_t>(streams[L.slot]), ev, 0);
+    if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "plan_launch_multi: stream dependency %d <- %d: %s", L.slot, L.other, hipGetErrorString(e));
+  }
   return FD_OK;
 }
 
@@ -189,6 +240,7 @@ extern "C" int fdgan_plan_launch(FdPlan* p, FdStream stream) {
   FD_REQUIRE(p, "plan_launch: NULL plan");
   if (p->recording) FD_FAIL(FD_ESTATE, "plan_launch: plan is still recording");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p->max_slot > 0) FD_FAIL(FD_ESTATE, "plan_launch: the plan records %d stream slots: use fdgan_plan_launch_multi", p->max_slot + 1);
   if (!p->marked.empty()) return timed_launch(p, s);
   if (p->exec) {
     hipError_t e = hipGraphLaunch(p->exec, s);
@@ -206,6 +258,7 @@ extern "C" int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream) {
   FD_REQUIRE(p, "plan_instantiate_graph: NULL plan");
   if (p->recording) FD_FAIL(FD_ESTATE, "plan_instantiate_graph: plan is still recording");
   if (p->exec) return FD_OK;
+  if (p->max_slot > 0) FD_FAIL(FD_ESTATE, "plan_instantiate_graph: multi-stream plans replay through fdgan_plan_launch_multi");
   // Capture never executes anything, so it runs on a private stream: the caller's stream may be
   // the legacy NULL stream, which cannot be captured.
   (void)stream;
@@ -282,6 +335,7 @@ extern "C" int fdgan_plan_read_timing(FdPlan* p, double* total_ms, int64_t* laun
 extern "C" int fdgan_plan_profile(FdPlan* p, FdStream stream, float* ms_out, int64_t n) {
   FD_REQUIRE(p && ms_out, "plan_profile: NULL argument");
   if (p->recording) FD_FAIL(FD_ESTATE, "plan_profile: plan is still recording");
+  if (p->max_slot > 0) FD_FAIL(FD_ESTATE, "plan_profile: single-stream plans only");
   FD_REQUIRE(n == (int64_t)p->launches.size(), "plan_profile: ms_out holds %lld entries, plan has %zu launches",
              (long long)n, p->launches.size());
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -108,16 +108,21 @@ void fd_set_error(const char* fmt, ...);
 // Every kernel takes ONE by-value POD argument struct, so a launch is fully
 // described by (function, grid, block, dynamic LDS, bytes of the struct).
 struct FdLaunch {
-  const void* fn;
+  const void* fn;      // nullptr: not a kernel but a stream dependency -- stream `slot` waits for everything enqueued so far on stream `other`
   const char* name;
   dim3 grid, block;
   unsigned shmem;
   std::vector<char> arg;
+  int slot = 0;        // which of the streams handed to fdgan_plan_launch_multi this launch goes to (0: the launch stream)
+  int other = 0;
 };
 
 struct FdPlan {
   std::vector<FdLaunch> launches;
   bool recording = false;
+  int cur_slot = 0;                                       // stream slot of the launches being recorded (fdgan_plan_set_slot)
+  int max_slot = 0;
+  std::vector<hipEvent_t> wait_events;                    // one per recorded dependency, created by the first multi-stream launch
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   std::vector<int64_t> marked;                            // launch indices bracketed by events

@@ -449,3 +449,86 @@ extern "C" int fdgan_adam_step(float* p, const float* g, float* m, float* v, int
              (float)(1.0 - pow((double)beta2, (double)step))};
   return fd_launch(&adam_kernel, "adam_step", dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
 }
+
+// ---- zero fills and the transposed accumulate of the reverse walk --------------------------------------------------
+// The reverse walk of fdgan_hip/backward.py is RECORDED into an FdPlan and replayed (round 4); whatever it did with torch
+// tensor methods between two launches (`buf.zero_()`, `coef[:, lo:hi].zero_()`, `grad.add_(tmp.permute(1, 0, 2, 3))`) has to
+// be a launch of this library to be part of the recording.
+namespace {
+struct FillArgs {
+  char* p;
+  long long row_bytes, row_stride, rows;
+};
+// one thread: 64 bytes of one row (16-byte stores when the row allows it)
+__global__ __launch_bounds__(256) void fill_zero_kernel(FillArgs a) {
+  const long long per_row = (a.row_bytes + 63) / 64;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= per_row * a.rows) return;
+  const long long r = t / per_row, o = (t - r * per_row) * 64;
+  char* d = a.p + r * a.row_stride + o;
+  const long long left = a.row_bytes - o;
+  if (left >= 64 && (((uintptr_t)d) & 15) == 0) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<u32x4*>(d)[k] = z;
+  } else {
+    for (long long k = 0; k < (left < 64 ? left : 64); k += 4) *reinterpret_cast<unsigned*>(d + k) = 0u;
+  }
+}
+
+struct FillManyArgs {
+  const FdZeroJob* jobs;
+  long long njobs;
+};
+// one workgroup: 16 KiB of one job (binary search over the jobs' first groups)
+__global__ __launch_bounds__(256) void fill_zero_many_kernel(FillManyArgs a) {
+  const long long grp = blockIdx.x;
+  long long lo = 0, hi = a.njobs - 1;
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (a.jobs[mid].first_group <= grp) lo = mid; else hi = mid - 1;
+  }
+  const FdZeroJob j = a.jobs[lo];
+  const long long o = (grp - j.first_group) * 16384 + (long long)threadIdx.x * 16;
+  char* d = static_cast<char*>(j.ptr) + o;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (o + k * 4096 + 16 <= j.bytes) *reinterpret_cast<u32x4*>(d + k * 4096) = z;
+}
+
+struct AddTArgs {
+  float* dst;
+  const float* src;
+  long long rows, cols;
+};
+// dst[c][r] += src[r][c]   (dst: cols x rows)
+__global__ __launch_bounds__(256) void add_transposed_kernel(AddTArgs a) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.rows * a.cols) return;
+  const long long c = t / a.rows, r = t - c * a.rows;      // consecutive threads: consecutive dst elements
+  a.dst[t] += a.src[r * a.cols + c];
+}
+}  // namespace
+
+extern "C" int fdgan_fill_zero(void* p, int64_t row_bytes, int64_t rows, int64_t row_stride_bytes, FdStream stream) {
+  FD_REQUIRE(p && row_bytes > 0 && rows > 0 && (row_bytes & 3) == 0 && (((uintptr_t)p) & 3) == 0 && (row_stride_bytes & 3) == 0,
+             "fill_zero: %lld rows of %lld bytes (4-byte granularity)", (long long)rows, (long long)row_bytes);
+  FillArgs a{static_cast<char*>(p), row_bytes, row_stride_bytes, rows};
+  const long long threads = (row_bytes + 63) / 64 * rows;
+  return fd_launch(&fill_zero_kernel, "fill_zero", dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_fill_zero_many(const FdZeroJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream) {
+  FD_REQUIRE(jobs_device && njobs > 0 && total_groups > 0 && total_groups < (1ll << 31), "fill_zero_many: %lld jobs, %lld groups",
+             (long long)njobs, (long long)total_groups);
+  FillManyArgs a{jobs_device, njobs};
+  return fd_launch(&fill_zero_many_kernel, "fill_zero_many", dim3((unsigned)total_groups), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fdgan_add_transposed_f32(float* dst, const float* src, int64_t rows, int64_t cols, FdStream stream) {
+  FD_REQUIRE(dst && src && rows > 0 && cols > 0, "add_transposed_f32: bad arguments");
+  AddTArgs a{dst, src, rows, cols};
+  return fd_launch(&add_transposed_kernel, "add_transposed_f32", dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, a,
+                   static_cast<hipStream_t>(stream));
+}

@@ -19,12 +19,70 @@ consumer's backward needs them: one extra 1x1 forward per dense layer instead of
 Reference semantics: torch.autograd over /root/reference/models/dehaze1113.py:703-801 (FDGAN), :256-275,
 :358-370 (dy blocks).
 """
+import contextlib
+import ctypes as C
 import os
 
 import torch
 
 from . import engine as E
 from . import lib as L
+
+
+class _Tape:
+    """One reverse walk as it was RECORDED (round 4): multi-stream FdPlans -- every launch of the walk with its stream slot (0: the
+    walk's stream, 1: the weight-gradient side stream) and the fork / join dependencies between the two -- interleaved with the few
+    host callables a walk still needs (the optimizer's all-reduce hook under data parallelism, eval-mode coefficient save / restore).
+    Replaying it costs one library call per plan segment instead of ~30 Python calls per record."""
+
+    def __init__(self):
+        self.lib = L.load()
+        self.steps = []          # E.Plan | callable
+        self.keep = []           # temporaries the recorded launches point into
+        self.cur = None
+        self.inplace = []        # parameters whose gradient the walk adds straight into their optimizer sink
+        self.sinks = []          # (parameter, data_ptr of the sink) the recorded launches write to
+        self.side_used = False
+        self.launches = 0
+
+    def _plan(self):
+        if self.cur is None:
+            self.cur = E.Plan()
+            L.check(self.lib.fdgan_plan_begin(self.cur.h), "plan_begin")
+        return self.cur
+
+    def _close(self):
+        if self.cur is not None:
+            L.check(self.lib.fdgan_plan_end(self.cur.h), "plan_end")
+            if len(self.cur):
+                self.launches += len(self.cur)
+                self.steps.append(self.cur)
+            self.cur = None
+
+    def set_slot(self, slot):
+        L.check(self.lib.fdgan_plan_set_slot(self._plan().h, slot), "plan_set_slot")
+        if slot:
+            self.side_used = True
+
+    def wait(self, waiter, signaler):
+        L.check(self.lib.fdgan_plan_record_wait(self._plan().h, waiter, signaler), "plan_record_wait")
+
+    def add_py(self, fn):
+        self._close()
+        self.steps.append(fn)
+
+    def abort(self):
+        if self.cur is not None:
+            self.lib.fdgan_plan_end(self.cur.h)
+            self.cur = None
+
+    def replay(self, streams):
+        lib = self.lib
+        for st in self.steps:
+            if isinstance(st, E.Plan):
+                L.check(lib.fdgan_plan_launch_multi(st.h, streams, 2), "plan_launch_multi")
+            else:
+                st()
 
 
 
@@ -172,6 +230,18 @@ class PlanBackward:
         self.tr_jobs = []
         self.tr_table = None
         self.walks_done = 0
+        # Recording (the host needed 23.6 ms to enqueue a 28 ms step, most of it these walks).  The first two walks
+        # run eagerly (they learn which records defer their reductions and allocate those buffers); the third is a DRY run that
+        # records every launch into a _Tape and is followed by its first replay; from then on a walk is `tape.replay()`.  A tape
+        # is keyed by everything that changes what a walk does (which parameters want gradients, whose input gradient is
+        # skipped, whether an all-reduce hook rides along) and is only made when every gradient goes straight into an
+        # optimizer's flat buffer (FlatAdam sinks: stable addresses) and the plan holds no legacy op with host-side arithmetic.
+        self.tape_enabled = (os.environ.get("FDGAN_NO_BACKWARD_TAPE") is None and dev.type == "cuda" and not self.recompute and
+                             all(r["kind"] in ("conv", "copy", "maxpool") for r in self.recs))
+        self.tapes = {}
+        self._rec = None
+        self._persist = {}
+        self._zero_tables = {}
         self.deferred = {}      # activation buffer data_ptr -> pending per-channel (Bsum, Csum) of BatchNorm's backward
         # Sole consumers: a conv whose input region no other op reads between its producer and its next overwrite (the
         # dense layers' bottlenecks) STORES its data gradient instead of accumulating it; gradient buffers fed only by such
@@ -263,8 +333,59 @@ class PlanBackward:
         """The walk's stream waits for the weight gradients issued on the side stream so far (end of a walk; before a slice
         of the flat gradient is handed to the all-reduce)."""
         if self._w_pending:
-            torch.cuda.current_stream(self.wstream.device).wait_stream(self.wstream)
+            if self._rec is not None:
+                self._rec.wait(0, 1)
+            else:
+                torch.cuda.current_stream(self.wstream.device).wait_stream(self.wstream)
             self._w_pending = False
+
+    # ---- eager / recorded execution of everything that is not a plain library launch --------------------------------
+    def _py(self, fn):
+        """A host-side step of the walk: run now, or (recording) become a step of the tape."""
+        if self._rec is None:
+            fn()
+        else:
+            self._rec.add_py(fn)
+
+    def _tmp(self, shape, dtype):
+        """A temporary of this walk; a recorded walk keeps it (the launches point into it)."""
+        t = torch.empty(shape, dtype=dtype, device=self.plan.device)
+        if self._rec is not None:
+            self._rec.keep.append(t)
+        return t
+
+    def _new_grad(self, n, h, w, c, zero=False):
+        t = self._tmp((n, h, w, c), E.GRAD_DTYPE)
+        if zero:
+            E.fill_zero(t)
+        return t
+
+    @contextlib.contextmanager
+    def _side(self):
+        """Launches inside go to the weight-gradient side stream (recording: to stream slot 1)."""
+        if self._rec is None:
+            with torch.cuda.stream(self.wstream):
+                yield
+        else:
+            self._rec.set_slot(1)
+            try:
+                yield
+            finally:
+                self._rec.set_slot(0)
+
+    def _fork(self):
+        """The side stream waits for what the walk's stream has enqueued so far."""
+        if self._rec is None:
+            self.wstream.wait_stream(torch.cuda.current_stream(self.plan.device))
+        else:
+            self._rec.wait(1, 0)
+
+    def persistent(self, name, make):
+        """A buffer that lives as long as this object (the seed gradient of a network's last conv: recorded launches read it)."""
+        t = self._persist.get(name)
+        if t is None:
+            t = self._persist[name] = make()
+        return t
 
     def G(self, view):
         g = self.gbuf[view.buf.data_ptr()]
@@ -273,13 +394,24 @@ class PlanBackward:
         return E.View(g, view.c0, view.c)
 
     def zero_(self):
+        """Every gradient buffer that is accumulated into: ONE launch over a device table (they were ~25 torch fills per walk)."""
         skip = self.nozero if self.checks is None else ()
-        for g in {id(g): g for g in self.gbuf.values()}.values():      # aliased gradient buffers once
-            if id(g) not in skip:
+        tab = self._zero_tables.get(self.checks is None)
+        if tab is None:
+            bufs = [g for g in {id(g): g for g in self.gbuf.values()}.values() if id(g) not in skip]      # aliased buffers once
+            if all((g.numel() * g.element_size()) % 16 == 0 and g.data_ptr() % 16 == 0 for g in bufs):
+                tab = E.ZeroTable(bufs) if bufs else False
+            else:
+                tab = bufs
+            self._zero_tables[self.checks is None] = tab
+        if isinstance(tab, list):
+            for g in tab:
                 g.zero_()
+        elif tab:
+            tab.launch()
         for d in self.deferred.values():                                # nothing pending from an interrupted walk
             if d["dirty"]:
-                d["coef"].zero_()
+                E.fill_zero(d["coef"])
                 d["dirty"].clear()
 
     # ---- one fused convolution ---------------------------------------------------------------
@@ -316,9 +448,13 @@ class PlanBackward:
         assert dy_pending is None or fuse_w
         if p.requires_grad and not fuse_w:
             if w.transposed:                      # ConvTranspose2d 1x1: weight is (cin, cout, 1, 1)
-                tmp = torch.empty((w.cout, w.cin, k, k), dtype=torch.float32, device=p.device)
+                tmp = self._tmp((w.cout, w.cin, k, k), torch.float32)
                 E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, tmp, None, self.ws, False)
-                grad_target(grads, p).add_(tmp.permute(1, 0, 2, 3))
+                tgt = grad_target(grads, p)
+                if k == 1 and tgt.is_contiguous():
+                    E.add_transposed(tgt, tmp)
+                else:
+                    self._py(lambda: tgt.add_(tmp.permute(1, 0, 2, 3)))
             else:
                 db = None
                 if r["bias"] is not None and r["bias"].requires_grad:
@@ -329,10 +465,9 @@ class PlanBackward:
                 side = (self.offload_wgrad and self.checks is None and r.get("y") is not None and dy_view.buf is self.gbuf.get(r["y"].buf.data_ptr())
                         and r["y"].buf.data_ptr() not in self.multi_version)
                 if side:
-                    main = torch.cuda.current_stream(p.device)
-                    self.wstream.wait_stream(main)            # dy is final (flushed) on the walk's stream
+                    self._fork()                              # dy is final (flushed) on the walk's stream
                     idx = r.get("_idx")
-                    with torch.cuda.stream(self.wstream):
+                    with self._side():
                         if db is not None or idx is None or not self.defer_reduce:
                             E.conv_bwd_weight(x.fd, pro, dy_view.fd, desc, dw_t, db, self.ws_w, True)
                         elif idx in self._tr_deferred:      # partial sums stay in the record's own buffer until the batched launch
@@ -374,7 +509,7 @@ class PlanBackward:
         cin = w.cin
         if r["stride"] != 1:     # any-stride direct kernel (one thread per input element): the discriminators' 4x4 s2 convs
             hin, win = x.shape[1], x.shape[2]
-            T = E.new_grad(n, hin, win, _r8(cin), p.device, zero=True)
+            T = self._new_grad(n, hin, win, _r8(cin), zero=True)
             E.conv_bwd_data_direct_nhwc(dy_view.fd, p.detach().contiguous(), desc, E.View(T, 0, cin), cin)
             return self._prologue_backward(r, T, meta, grads, check_state=(rec, gx_before, dx_ref) if check else None)
         hin, win = hy + k - 1 - 2 * pad, wy + k - 1 - 2 * pad
@@ -419,7 +554,7 @@ class PlanBackward:
                     if res is not None and idx is not None:
                         self._fused_seen.add(idx)
                 if res is not None and dy_pending is not None:
-                    dy_pending["coef"].zero_()
+                    E.fill_zero(dy_pending["coef"])
                     dy_pending["dirty"].clear()
                 if res is None:     # outside the fused kernel's shapes: the two separate kernels
                     if dy_pending is not None:
@@ -436,19 +571,26 @@ class PlanBackward:
                 # Dropout2d pass) get no correction terms.  finalize_coef ADDS into the buffer's shared pair, so their columns are
                 # set aside and put back: zeroing them afterwards would also erase the terms other consumers of the same channels
                 # (a train-mode transition behind eval-mode dense layers) added earlier in the walk and have not flushed
-                keep = [(lo, hi, d["coef"][:, x.c0 + lo:x.c0 + hi].clone()) for lo, hi in _constant_entries(meta, cin)]
+                keep = []
+                const = [(x.c0 + lo, x.c0 + hi) for lo, hi in _constant_entries(meta, cin)]
+                if const:
+                    self._py(lambda: keep.extend(d["coef"][:, lo:hi].clone() for lo, hi in const))
                 E.bn_bwd_finalize_coef(self.ws_bn, rows, cpad, cin, act_pro, n * hin * win, d["coef"][0, x.c0:x.c0 + cin],
                                        d["coef"][1, x.c0:x.c0 + cin],
                                        sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                                        sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
-                for lo, hi, saved in keep:
-                    d["coef"][:, x.c0 + lo:x.c0 + hi].copy_(saved)
+                if const:
+                    def restore():
+                        for (lo, hi), saved in zip(const, keep):
+                            d["coef"][:, lo:hi].copy_(saved)
+                        del keep[:]
+                    self._py(restore)
                 d["dirty"].update(range(x.c0, x.c0 + cin))
             if check:
                 self.flush(x)
                 self._finish_check(rec, x, gx_before, dx_ref)
             return
-        T = E.new_grad(n, hin, win, _r8(cin), p.device)
+        T = self._new_grad(n, hin, win, _r8(cin))
         masked = None
         if fusable:     # the activation mask and the BatchNorm sums ride in the data-gradient kernel's epilogue
             masked = E.conv_bwd_data(dy_view.fd, pw, x.fd, act_pro, E.View(T, 0, cin).fd, ddesc, self.ws_bn if bn is not None else None)
@@ -485,7 +627,7 @@ class PlanBackward:
         lo, hi = c0 - c0 % 8, min(d["buf"].shape[-1], (c1 + 7) // 8 * 8)      # whole 8-channel groups (clean ones add zero)
         xv = E.View(d["buf"], lo, hi - lo)
         E.affine_accumulate(xv.fd, d["coef"][0, lo:hi], d["coef"][1, lo:hi], self.G(xv).fd)
-        d["coef"][:, lo:hi].zero_()
+        E.fill_zero(d["coef"][:, lo:hi])
         d["dirty"].difference_update(range(lo, hi))
 
     def flush_all(self):
@@ -515,16 +657,16 @@ class PlanBackward:
             # full-resolution dpre tensor (it was written, masked in place and re-read: four more passes)
             pool_pro = E.make_prologue(act=meta["act"], pool=True, mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
                                        beta=meta["beta"], eps=meta["eps"])
-            dg = torch.empty(cin, dtype=torch.float32, device=p.device)
-            dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
+            dg = self._tmp((cin,), torch.float32)
+            dbt = self._tmp((cin,), torch.float32)
             train_bn = bn.weight is not None and bn.weight.requires_grad
             one_pass = self.defer_affine and not check and self.pool_one_pass     # G += gamma * rstd * dpre rides in the pass that forms the sums
             rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn, dx_fd=gx.fd if one_pass else None)
             E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                               sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
             for lo, hi in _constant_entries(meta, cin):
-                dg[lo:hi].zero_()
-                dbt[lo:hi].zero_()
+                E.fill_zero(dg[lo:hi])
+                E.fill_zero(dbt[lo:hi])
             if one_pass:      # what is left, B * x + C per channel, waits in the buffer's coefficient pair like every other norm's
                 d = self._deferred(x)
                 E.bn_bwd_coef(dg, dbt, pool_pro, cin, n * 4 * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
@@ -535,14 +677,14 @@ class PlanBackward:
                 self._finish_check(rec, x, gx_before, dx_ref)
             return
         if meta["pool"]:
-            T2 = E.new_grad(n, 2 * hin, 2 * win, _r8(cin), p.device)
+            T2 = self._new_grad(n, 2 * hin, 2 * win, _r8(cin))
             E.grad_ew(E.GRAD_UNPOOL, Tv, E.View(T2, 0, cin))
             T, Tv = T2, E.View(T2, 0, cin)
         if bn is not None:
             act_pro = E.make_prologue(act=meta["act"], mean=meta["mean"], var=meta["var"], gamma=meta["gamma"],
                                       beta=meta["beta"], eps=meta["eps"])
-            dg = torch.empty(cin, dtype=torch.float32, device=p.device)
-            dbt = torch.empty(cin, dtype=torch.float32, device=p.device)
+            dg = self._tmp((cin,), torch.float32)
+            dbt = self._tmp((cin,), torch.float32)
             train_bn = bn.weight is not None and bn.weight.requires_grad
             sinks = dict(sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                          sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
@@ -553,8 +695,8 @@ class PlanBackward:
                 rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, act_pro, self.ws_bn)
                 E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, **sinks)
             for lo, hi in _constant_entries(meta, cin):  # constants, not batch statistics (see conv_backward): dx = A * dpre there
-                dg[lo:hi].zero_()
-                dbt[lo:hi].zero_()
+                E.fill_zero(dg[lo:hi])
+                E.fill_zero(dbt[lo:hi])
             E.bn_bwd_apply(Tv.fd, x.fd, act_pro, dg, dbt, gx.fd, accumulate=True)
         else:
             if meta["act"] != L.ACT_NONE and masked is None:
@@ -591,11 +733,104 @@ class PlanBackward:
             E.bn_bwd_apply(gs.fd, src.fd, pro, dg, dbt, gs.fd, accumulate=False)
 
     # ---- the whole plan ------------------------------------------------------------------------
-    def run(self, grads, skip_dx_of=()):
-        """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's
-        outputs.  `grads`: dict parameter -> fp32 gradient, filled / accumulated."""
+    def _hook(self, i):
+        if PROGRESS_HOOK is not None:
+            self._py(lambda: PROGRESS_HOOK(self, i))      # the hook installed when the step RUNS (a new _Overlap object per step)
+
+    # ---- recording ---------------------------------------------------------------------------------
+    def _walk_params(self):
+        """Every parameter a walk may add a gradient to, in a fixed order (conv weights, biases, the prologues' BatchNorm pairs)."""
+        ps = self.__dict__.get("_walk_param_list")
+        if ps is None:
+            seen, ps = set(), []
+            for i in range(len(self.recs)):
+                r = self.recs[i]
+                if r["kind"] != "conv":
+                    continue
+                cand = [r["w"].param, r.get("bias")]
+                bn = r["pro"]._meta.get("bn") if r.get("pro") is not None else None
+                if bn is not None:
+                    cand += [bn.weight, bn.bias]
+                for q in cand:
+                    if q is not None and id(q) not in seen:
+                        seen.add(id(q))
+                        ps.append(q)
+            self._walk_param_list = ps
+        return ps
+
+    def _tape_key(self, skip_dx_of, head):
+        ps = self._walk_params() + ([q for q in (head[0]["w"].param, head[0].get("bias")) if q is not None] if head is not None else [])
+        return (tuple(q.requires_grad for q in ps), frozenset(skip_dx_of), PROGRESS_HOOK is not None, head is not None,
+                self.relu_premask)
+
+    def _sinks_attached(self, params):
+        for q in params:
+            if q.requires_grad and grad_sink(q) is None:
+                return False
+        return True
+
+    def run(self, grads, skip_dx_of=(), head=None):
+        """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's outputs.  `grads`: dict
+        parameter -> fp32 gradient, filled / accumulated.  head = (record, dy_view): a conv outside the plan whose backward
+        comes first (a network's last conv, launched per call because its output is a fresh tensor); dy_view must live in a
+        `persistent` buffer.  From the third walk on (same key) the walk is a recorded tape."""
+        key = None
+        if self.tape_enabled and self.checks is None and self.walks_done >= 2:
+            key = self._tape_key(skip_dx_of, head)
+            tape = self.tapes.get(key)
+            if tape is None and key not in self.tapes:
+                params = self._walk_params() + ([q for q in (head[0]["w"].param, head[0].get("bias")) if q is not None] if head is not None else [])
+                if self._sinks_attached(params):
+                    tape = self._record(grads, skip_dx_of, head)
+                self.tapes[key] = tape            # None: this configuration stays eager (a gradient without an optimizer sink)
+            if tape is not None:
+                for q, ptr in tape.sinks:         # the recorded launches write here: the optimizer must still own these views
+                    g = q.grad
+                    if g is None or g.data_ptr() != ptr:
+                        tape = None
+                        break
+            if tape is not None:
+                return self._replay(tape, grads)
+        return self._walk(grads, skip_dx_of, head)
+
+    def _record(self, grads, skip_dx_of, head):
+        """A dry walk: every launch lands in the tape's plans instead of on the GPU; host state ends as after a real walk."""
+        tape = self._rec = _Tape()
+        probe = {}
+        ok = False
+        try:
+            self._walk(probe, skip_dx_of, head)
+            tape._close()
+            ok = all(v is IN_PLACE for v in probe.values())
+        finally:
+            self._rec = None
+            if not ok:
+                tape.abort()
+                for d in self.deferred.values():
+                    d["dirty"].clear()
+                self._w_pending = False
+        if not ok:
+            return None
+        self.walks_done -= 1                      # the dry walk computed nothing
+        tape.inplace = list(probe.keys())
+        tape.sinks = [(q, q._fd_grad_sink.data_ptr()) for q in probe]
+        return tape
+
+    def _replay(self, tape, grads):
+        cur = torch.cuda.current_stream(self.plan.device).cuda_stream
+        streams = (C.c_void_p * 2)(cur, self.wstream.cuda_stream if self.wstream is not None else cur)
+        self._w_pending = tape.side_used        # a hook that hands a slice to the all-reduce joins the side stream itself
+        tape.replay(streams)
+        self._w_pending = False                 # the tape ends with the join
+        for q in tape.inplace:
+            grads[q] = IN_PLACE
+        self.walks_done += 1
+
+    def _walk(self, grads, skip_dx_of=(), head=None):
         self.reduce_jobs = []
         self.tr_jobs = []
+        if head is not None:
+            self.conv_backward(head[0], head[1], grads)
         for i in range(len(self.recs) - 1, -1, -1):
             r = self.recs[i]
             r["_idx"] = i
@@ -610,8 +845,7 @@ class PlanBackward:
             if r["kind"] in ("pyramid", "bn_dropout", "maxpool3"):      # the legacy DCPDN networks' own ops (csrc/legacy_bwd.hip)
                 self.flush(r["dst"])
                 self._legacy_backward(r, grads)
-                if PROGRESS_HOOK is not None:
-                    PROGRESS_HOOK(self, i)
+                self._hook(i)
                 continue
             if i in self.recompute:
                 self.recs[self.recompute[i]]["rerun"]()
@@ -619,8 +853,7 @@ class PlanBackward:
             need_dx = id(r["x"].buf) not in skip_dx_of and r["x"].buf.data_ptr() not in skip_dx_of
             if y is None:      # a conv that stores a network output (NCHW fp32): the caller seeded its gradient (`_dy`, already
                 self.conv_backward(r, r["_dy"], grads, need_dx=need_dx)      # through the output activation's derivative)
-                if PROGRESS_HOOK is not None:
-                    PROGRESS_HOOK(self, i)
+                self._hook(i)
                 continue
             pending = self._pending_for_fused(r, need_dx)
             if pending is None:
@@ -629,7 +862,7 @@ class PlanBackward:
             dyv = gy
             if r["upsample"]:
                 n, h2, w2, _ = y.shape
-                t = E.new_grad(n, h2 // 2, w2 // 2, _r8(y.c), y.buf.device)
+                t = self._new_grad(n, h2 // 2, w2 // 2, _r8(y.c))
                 dyv = E.View(t, 0, y.c)
                 E.grad_ew(E.GRAD_SUMPOOL, gy, dyv)
             r["_post_relu"] = self.x_post_relu.get(i, False)
@@ -642,9 +875,8 @@ class PlanBackward:
                 raise NotImplementedError("epilogue activation %d inside a plan" % r["e_act"])
             self.conv_backward(r, dyv, grads, need_dx=need_dx, dy_pending=pending)
             if y.buf.data_ptr() in self.multi_version and (self.checks is not None or id(self.gbuf[y.buf.data_ptr()]) not in self.nozero):
-                self.gbuf[y.buf.data_ptr()].zero_()      # the next (earlier) layer accumulates a fresh gradient here
-            if PROGRESS_HOOK is not None:
-                PROGRESS_HOOK(self, i)
+                E.fill_zero(self.gbuf[y.buf.data_ptr()])      # the next (earlier) layer accumulates a fresh gradient here
+            self._hook(i)
         self.flush_all()      # plan inputs: their gradients are read by the caller
         if self.reduce_jobs:  # the fused bottlenecks' weight gradients: one launch for all of them
             key = tuple((pt.data_ptr(), o.data_ptr(), n, s_, a) for pt, o, n, s_, a in self.reduce_jobs)
@@ -655,7 +887,7 @@ class PlanBackward:
             key = tuple((j.part, j.out, j.item_stride, j.items, j.accumulate) for j in self.tr_jobs)
             if self.tr_table is None or self.tr_table.key != key:
                 self.tr_table = E.TrReduceTable(self.tr_jobs, list(self.tr_parts.values()), self.plan.device)
-            with torch.cuda.stream(self.wstream):
+            with self._side():
                 self.tr_table.launch()
             self._w_pending = True
         if self._deferred_idx is None and self.checks is None:
@@ -665,6 +897,5 @@ class PlanBackward:
                 for i in self._tr_deferred:
                     self.tr_parts[i] = torch.empty(self._tr_seen[i], dtype=torch.float32, device=self.plan.device)
         self.walks_done += 1
-        if PROGRESS_HOOK is not None:
-            PROGRESS_HOOK(self, len(self.recs))
+        self._hook(len(self.recs))
         self.join_side()      # parameter gradients written on the side stream are complete for whatever follows on this one

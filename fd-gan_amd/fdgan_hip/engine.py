@@ -607,6 +607,46 @@ def out_act_bwd(dout, out, act, g_view):
             "out_act_bwd")
 
 
+def fill_zero(t):
+    """t.zero_() as a launch of the library (recordable into a plan).  t: a contiguous tensor, or a 2-D row-slice view
+    (`coef[:, lo:hi]`) of 4-byte elements."""
+    if t.dim() == 2 and not t.is_contiguous():
+        assert t.stride(1) == 1 and t.element_size() == 4
+        rows, rb, rs = t.shape[0], t.shape[1] * 4, t.stride(0) * 4
+    else:
+        assert t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0
+        rows, rb, rs = 1, t.numel() * t.element_size(), 0
+    if rb:
+        L.check(L.load().fdgan_fill_zero(t.data_ptr(), rb, rows, rs, stream_ptr()), "fill_zero")
+
+
+class ZeroTable:
+    """Several whole buffers zeroed by ONE launch (fdgan_fill_zero_many); the device table stays valid while they keep their addresses."""
+
+    def __init__(self, tensors):
+        self.keep = list(tensors)
+        tab = (L.FdZeroJob * len(self.keep))()
+        first = 0
+        for j, t in zip(tab, self.keep):
+            nb = t.numel() * t.element_size()
+            assert t.is_contiguous() and nb % 16 == 0 and t.data_ptr() % 16 == 0
+            j.ptr, j.bytes, j.first_group = t.data_ptr(), nb, first
+            first += (nb + 16383) // 16384
+        self.groups = first
+        self.table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.keep[0].device)
+
+    def launch(self):
+        L.check(L.load().fdgan_fill_zero_many(self.table.data_ptr(), len(self.keep), self.groups, stream_ptr()), "fill_zero_many")
+
+
+def add_transposed(dst, src):
+    """dst (cols, rows) += src (rows, cols) transposed; fp32, contiguous."""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    rows, cols = src.shape[0], src.numel() // src.shape[0]
+    assert dst.numel() == src.numel()
+    L.check(L.load().fdgan_add_transposed_f32(dst.data_ptr(), src.data_ptr(), rows, cols, stream_ptr()), "add_transposed_f32")
+
+
 GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK, GRAD_LEAKY_MASK = 0, 1, 2, 3, 4
 
 

@@ -15,7 +15,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class FdganLibraryError(RuntimeError):
@@ -38,6 +38,10 @@ class FdPackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
                 ("transposed", C.c_int32), ("flip", C.c_int32), ("layout", C.c_int32), ("dtype", C.c_int32), ("_pad", C.c_int32),
                 ("first_unit", C.c_int64)]
+
+
+class FdZeroJob(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_int64), ("first_group", C.c_int64)]
 
 
 class FdReduceJob(C.Structure):
@@ -111,6 +115,12 @@ SIGNATURES = {
     "fdgan_plan_end": (C.c_int, [C.c_void_p]),
     "fdgan_plan_num_launches": (C.c_int64, [C.c_void_p]),
     "fdgan_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fdgan_plan_set_slot": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdgan_plan_record_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "fdgan_plan_launch_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
+    "fdgan_fill_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_fill_zero_many": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "fdgan_add_transposed_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "fdgan_plan_instantiate_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fdgan_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "fdgan_plan_time_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]),

@@ -447,12 +447,11 @@ class FDGAN(_PlannedModule):
         B = _plan_backward(P)
         B.zero_()
         n, _, h, w = out.shape
-        g8 = E.new_grad(n, h, w, 8, out.device)
+        g8 = B.persistent("g8", lambda: E.new_grad(n, h, w, 8, out.device))      # read by the (recorded) walk's first launches
         E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))                          # dehaze = tanh(conv_refin3(x6)) (:799)
         grads = {}
-        last = dict(x=E.View(P.x6), w=P.w_last, k=3, pad=1, stride=1, bias=self.conv_refin3.bias, pro=None)
-        B.conv_backward(last, E.View(g8, 0, 3), grads)
-        B.run(grads, skip_dx_of={P.in8.data_ptr()})
+        last = B.persistent("last", lambda: dict(x=E.View(P.x6), w=P.w_last, k=3, pad=1, stride=1, bias=self.conv_refin3.bias, pro=None))
+        B.run(grads, skip_dx_of={P.in8.data_ptr()}, head=(last, E.View(g8, 0, 3)))
         return None, grads
 
     def _forward_plan(self, P, x):
@@ -888,13 +887,12 @@ class D(_PlannedModule):
         B = _plan_backward(P)
         B.zero_()
         n, _, h5, w5 = out.shape
-        g8 = E.new_grad(n, h5, w5, 8, out.device)
+        g8 = B.persistent("g8", lambda: E.new_grad(n, h5, w5, 8, out.device))    # read by the (recorded) walk's first launches
         E.out_act_bwd(dout, out, L.ACT_SIGMOID, E.View(g8))
         grads = {}
-        last = dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,
-                    pro=E.make_prologue(act=L.ACT_LEAKY02))
-        B.conv_backward(last, E.View(g8, 0, 1), grads)
-        B.run(grads, skip_dx_of={P.xin.data_ptr()})
+        last = B.persistent("last", lambda: dict(x=E.View(P.a4, 0, 8 * self.nf), w=P.w_last, k=4, pad=1, stride=1, bias=None,
+                                                 pro=E.make_prologue(act=L.ACT_LEAKY02)))
+        B.run(grads, skip_dx_of={P.xin.data_ptr()}, head=(last, E.View(g8, 0, 1)))
         dx = None
         if need_dx:
             dx = torch.empty((n, self.nc, P.xin.shape[1], P.xin.shape[2]), dtype=torch.float32, device=out.device)

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 11
+#define FDGAN_ABI_VERSION 12
 
 enum FdStatus {
   FD_OK = 0,
@@ -284,7 +284,17 @@ int fdgan_plan_end(FdPlan* p);
 int64_t fdgan_plan_num_launches(const FdPlan* p);
 int fdgan_plan_launch(FdPlan* p, FdStream stream);
 int fdgan_plan_instantiate_graph(FdPlan* p, FdStream stream);
-/* Name of the k-th recorded kernel (for profiles/tests); NULL if out of range. */
+/* Multi-stream recording (round 4: the REVERSE walk of a network is recorded too, and it runs its unfused weight gradients on a
+ * second stream beside the chain of data gradients -- the reference's counterpart is torch.autograd's engine walking
+ * /root/reference/models/dehaze1113.py:758-801 backwards).  While a plan records, fdgan_plan_set_slot names the stream slot
+ * (0 .. 7; 0 = the launch stream) the following launches belong to, and fdgan_plan_record_wait records a dependency: everything
+ * recorded afterwards for `waiter_slot` runs after everything recorded so far for `signaler_slot` (an event recorded on one
+ * stream and waited for on the other at replay).  fdgan_plan_launch_multi replays such a plan on the caller's streams
+ * (streams[slot]); fdgan_plan_launch / _instantiate_graph / _profile refuse plans that use more than slot 0. */
+int fdgan_plan_set_slot(FdPlan* p, int slot);
+int fdgan_plan_record_wait(FdPlan* p, int waiter_slot, int signaler_slot);
+int fdgan_plan_launch_multi(FdPlan* p, const FdStream* streams, int nstreams);
+/* Name of the k-th recorded kernel (for profiles/tests; "stream_wait" for a recorded dependency); NULL if out of range. */
 const char* fdgan_plan_kernel_name(const FdPlan* p, int64_t k);
 /* Measurement (bench.py): mark launches (strictly increasing indices; n == 0 clears).
  * While marks exist fdgan_plan_launch replays eagerly and brackets every marked launch
@@ -392,6 +402,21 @@ int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const FdPrologue*
 /* Sums [nsplit][numel] fp32 partial blocks into out[numel] (+= when accumulate) for a whole table of jobs in one launch, in
  * the fixed order of the per-conv reduction (bitwise the same sums).  `jobs` lives in DEVICE memory; first_group = running
  * sum of ceil(numel / 64) over the preceding jobs, total_groups = that sum over all jobs. */
+/* Zero fills as launches of this library, so that they can be recorded into a plan (torch's `t.zero_()` cannot): `rows` rows of
+ * `row_bytes` bytes, `row_stride_bytes` apart (4-byte granularity); and a whole device table of buffers in one launch
+ * (16-byte-aligned pointers and sizes; first_group = running sum of ceil(bytes / 16384) over the preceding jobs) -- the gradient
+ * buffers a reverse walk accumulates into.  fdgan_add_transposed_f32: dst[c][r] += src[r][c] (dst is cols x rows): the
+ * gradient of a ConvTranspose2d 1x1 filter, stored (cin, cout), from the (cout, cin) matrix the weight-gradient kernels write
+ * (/root/reference/models/dehaze1113.py:362-364). */
+typedef struct FdZeroJob {
+  void* ptr;
+  int64_t bytes;
+  int64_t first_group;
+} FdZeroJob;
+int fdgan_fill_zero(void* p, int64_t row_bytes, int64_t rows, int64_t row_stride_bytes, FdStream stream);
+int fdgan_fill_zero_many(const FdZeroJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream);
+int fdgan_add_transposed_f32(float* dst, const float* src, int64_t rows, int64_t cols, FdStream stream);
+
 typedef struct FdReduceJob {
   const float* part;
   float* out;
