@@ -62,6 +62,14 @@ __device__ __forceinline__ void ds_wait_vm() {
 // barrier that leaves LDS-DMA in flight (see conv3x3_rs.hip)
 __device__ __forceinline__ void ds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Phase skips (tuning builds only, FDGAN_DEBUG_PHASES; results wrong): 1 no filter DMA after the pipeline fill, 2 no MFMAs, 4 no
+// prologue transform, 8 no output stores, 16 no activation DMA after the pipeline fill, 32 no statistics
+#ifdef FDGAN_TUNING
+#define DS_SKIP(bit) ((a.dbg_skip & (bit)) != 0)
+#else
+#define DS_SKIP(bit) false
+#endif
+
 struct DsTimer {   // measurement aid (tools/conv_bench.py FDGAN_TIMING=1): s_memtime per phase, workgroup 0
   bool on;
   unsigned long long t[6], last;
@@ -107,6 +115,13 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
   const int my_tiles = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * a.nks;
   const int cmax = a.Cin8 * 8;
+  // Channel chunks past Cin are masked by the consumer, but what their DMA reads is not free: pointing them all at chunk 0 of the
+  // pixel (the first version) makes a prefix of 64 k + 32 channels -- every second dense layer -- end in a half-used 128-byte
+  // line plus 32 lanes hammering one 16-byte address, and a 96-channel prefix took LONGER than a 128-channel one (135.6 vs
+  // 124.5 us at 256^2, tools/ds_sweep.py).  When pixel rows are 128-byte aligned the masked chunks of the LAST line read their
+  // own addresses instead: the line is fetched whole, the bytes (later channels of the concat buffer, or the next pixel's)
+  // belong to the same allocation, and the select below still zeroes them.
+  const int clim = (((unsigned long long)a.x & 127ull) == 0 && (a.x_sw & 63) == 0 && !DS_SKIP(64)) ? ((cmax + 63) & ~63) : cmax;
 
   // ---- DMA maps.  Activation instruction i of this wave covers LDS positions [(4 wave + i) KiB, +1 KiB):
   // local pixel 32 wave + 8 i + lane / 8, slot lane % 8, holding channel chunk slot ^ ((px >> 1) & 5).
@@ -125,14 +140,19 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
     }
   };
   int f_tile = (int)blockIdx.x, f_ks = 0;   // stage to be fetched next
+  int issued = 0;
   auto issue = [&](int buf) __attribute__((always_inline)) {
     char* dst = stage0 + buf * DS_STAGE_B;
     if (f_ks == 0) retarget(f_tile);
+    const bool fill = issued < 2;
+    ++issued;
+    if (fill || !DS_SKIP(16))
 #pragma unroll
     for (int i = 0; i < C::AI; ++i) {
       const int ch = f_ks * 64 + dch[i];
-      ds_dma16(a.x + dsrc[i] + (ch < cmax ? ch : 0), dst + (wave * C::AI + i) * 1024);   // past Cin: chunk 0 (masked)
+      ds_dma16(a.x + dsrc[i] + (ch < clim ? ch : 0), dst + (wave * C::AI + i) * 1024);   // past the last line: chunk 0 (masked)
     }
+    if (fill || !DS_SKIP(1))
 #pragma unroll
     for (int f = 0; f < C::FI; ++f) {
       // fragment (j = fi >> 3, cout tile fi & 7) of k-step f_ks; with fewer than 16 fragment slots left a
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
       u32x4 raw[DS_PT];
 #pragma unroll
       for (int p = 0; p < DS_PT; ++p) raw[p] = lds_read16(act + boff[p][j]);
-      if (XMODE != 0) {
+      if (XMODE != 0 && !DS_SKIP(4)) {
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + cb), s1 = *reinterpret_cast<const f32x4*>(sc_lds + cb + 4);
         const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_lds + cb), h1 = *reinterpret_cast<const f32x4*>(sh_lds + cb + 4);
 #pragma unroll
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
         for (int p = 0; p < DS_PT; ++p)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            acc[p][c0 + c] = fd_mfma_a(wf[c], xf[p], acc[p][c0 + c]);
+            if (!DS_SKIP(2)) acc[p][c0 + c] = fd_mfma_a(wf[c], xf[p], acc[p][c0 + c]);
       }
     }
 
@@ -238,8 +258,10 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = pok ? acc[p][c][r] : 0.f;
-            st1[c][r] += v;
-            st2[c][r] = fmaf(v, v, st2[c][r]);
+            if (!DS_SKIP(32)) {
+              st1[c][r] += v;
+              st2[c][r] = fmaf(v, v, st2[c][r]);
+            }
           }
         unsigned short* yrow = reinterpret_cast<unsigned short*>(a.y) + (unsigned long long)pxt * (unsigned)a.y_sw;
         const int npix = full ? 16 : (pxt < a.P ? (int)min(16u, a.P - pxt) : 0);
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
           for (int c = 0; c < C::SC; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[c][r] = acc[p][c0 + c][r];
-          fd_store_row16_ptr<C::SC>(yrow + c0 * 16, a.y_sw, tb, v, lane, npix);
+          if (!DS_SKIP(8)) fd_store_row16_ptr<C::SC>(yrow + c0 * 16, a.y_sw, tb, v, lane, npix);
         }
 #pragma unroll
         for (int c = 0; c < DS_CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};

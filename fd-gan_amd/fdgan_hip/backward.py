@@ -70,6 +70,7 @@ class _Tape:
     def add_py(self, fn):
         self._close()
         self.steps.append(fn)
+        self._plan()             # whatever the walk launches next is recorded again (launches only record while a plan is open)
 
     def abort(self):
         if self.cur is not None:
@@ -110,6 +111,7 @@ IN_PLACE = _InPlace()
 
 # Called as PROGRESS_HOOK(plan_backward, record_index) after each record of a reverse walk is done: the optimizer's
 # gradient all-reduce rides on it (optim.FlatAdam.overlap), so RCCL runs while the rest of the backward computes.
+FORCE_EAGER = False         # measurement aid (bench.py): walk eagerly even where a tape exists, so that wrapped engine entry points see every call
 TR_DEFER_MAX = 1 << 24      # floats (64 MiB) of partial sums a record may keep private for the batched reduce
 PROGRESS_HOOK = None
 
@@ -775,7 +777,7 @@ class PlanBackward:
         comes first (a network's last conv, launched per call because its output is a fresh tensor); dy_view must live in a
         `persistent` buffer.  From the third walk on (same key) the walk is a recorded tape."""
         key = None
-        if self.tape_enabled and self.checks is None and self.walks_done >= 2:
+        if self.tape_enabled and not FORCE_EAGER and self.checks is None and self.walks_done >= 2:
             key = self._tape_key(skip_dx_of, head)
             tape = self.tapes.get(key)
             if tape is None and key not in self.tapes:
@@ -799,6 +801,7 @@ class PlanBackward:
         probe = {}
         ok = False
         try:
+            tape._plan()
             self._walk(probe, skip_dx_of, head)
             tape._close()
             ok = all(v is IN_PLACE for v in probe.values())

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdgan_hip.so")
+# FDGAN_LIB: tuning aid -- an experiment build of the same ABI (`FDGAN_BUILD_TAG=x python __graft_entry__.py` writes
+# variants/libfdgan_hip_x.so); unset everywhere outside tools/
+LIB_PATH = os.environ.get("FDGAN_LIB") or os.path.join(_HERE, "libfdgan_hip.so")
 
 FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)

@@ -980,7 +980,7 @@ def test_recorded_backward_walk_is_bitwise_the_eager_walk(monkeypatch):
     eager = run(False, False)
     taped = run(True, False)
     assert not eager[3] and len(taped[3]) >= 3, (len(eager[3]), len(taped[3]))      # G, D (training), D (adversarial, frozen)
-    assert any(t.side_used for t in taped[3]) and all(t.launches > 5 for t in taped[3])
+    assert any(t.side_used for t in taped[3]) and all(t.launches >= 3 for t in taped[3]), [(t.launches, len(t.steps), t.side_used) for t in taped[3]]
     assert all(len(t.steps) <= 3 for t in taped[3]), [len(t.steps) for t in taped[3]]   # one plan per walk: no host step left
     assert eager[0] == taped[0], (eager[0], taped[0])
     assert torch.equal(eager[1], taped[1]) and torch.equal(eager[2], taped[2])
