@@ -288,13 +288,11 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
   const int piece = lane & 7, ql0 = lane >> 3;
   const int cg = c0 + chh * 64 + piece * 8;
   const bool ch_ok = cg < a.C;
-  // lanes past the last channel: their G store is skipped, their sums and weight-gradient columns are never read (C % 8 == 0).
-  // What they LOAD matters all the same: parked on channels 0-7 (the first version) a prefix of 64 k + 32 channels ends in a
-  // half-used 128-byte line with 32 lanes on one address, and those shapes streamed at 4.0-4.5 TB/s against 4.9-6.0 for
-  // C = 64 k.  With 128-byte-aligned pixel rows they read their own addresses up to the end of the last line instead (later
-  // channels of the concat buffer: same allocation, finite or not -- nothing computed from them is stored).
-  const bool line_al = (((unsigned long long)a.x | (unsigned long long)a.g) & 127ull) == 0 && ((a.x_pitch | a.g_pitch) & 63) == 0;
-  const int cg_ld = (ch_ok || (line_al && !(a.dbg & 128) && cg < ((a.C + 63) & ~63))) ? cg : 0;      // dbg: tuning builds only (A/B)
+  const int cg_ld = ch_ok ? cg : 0;                           // lanes past the last channel work on channels 0-7 (their G store is skipped,
+                                                              // their sums and weight-gradient columns are never read; C % 8 == 0).
+  // (Round 4: neither letting them read their own address up to the end of the last 128-byte line, nor parking them all on ONE
+  // address per wave instruction, changed anything -- C = 96 takes 270-275 us at 256^2 whatever they fetch, the time of C = 128
+  // (270 us): a channel tile costs its step count, not its bytes; tools/bwdw_one.py.)
   f32x2 s1[4], s2[4];                                         // BatchNorm's two sums of the lane's 8 channels, as 4 pairs (fd_row8)
 #pragma unroll
   for (int k = 0; k < 4; ++k) s1[k] = s2[k] = f32x2{0.f, 0.f};

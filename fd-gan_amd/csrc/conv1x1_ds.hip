@@ -115,13 +115,9 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
   const int my_tiles = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * a.nks;
   const int cmax = a.Cin8 * 8;
-  // Channel chunks past Cin are masked by the consumer, but what their DMA reads is not free: pointing them all at chunk 0 of the
-  // pixel (the first version) makes a prefix of 64 k + 32 channels -- every second dense layer -- end in a half-used 128-byte
-  // line plus 32 lanes hammering one 16-byte address, and a 96-channel prefix took LONGER than a 128-channel one (135.6 vs
-  // 124.5 us at 256^2, tools/ds_sweep.py).  When pixel rows are 128-byte aligned the masked chunks of the LAST line read their
-  // own addresses instead: the line is fetched whole, the bytes (later channels of the concat buffer, or the next pixel's)
-  // belong to the same allocation, and the select below still zeroes them.
-  const int clim = (((unsigned long long)a.x & 127ull) == 0 && (a.x_sw & 63) == 0 && !DS_SKIP(64)) ? ((cmax + 63) & ~63) : cmax;
+  // (Tried in round 4: masked channel chunks reading their OWN address up to the end of the last 128-byte line instead of all
+  // parking on chunk 0 -- a 96-channel prefix takes longer than a 128-channel one, 135.6 vs 124.5 us at 256^2 -- made no
+  // difference (133.1 vs 136.2 us, inside the run-to-run drift), and neither did one shared address for all of them.  tools/ds_sweep.py has the per-phase table.)
 
   // ---- DMA maps.  Activation instruction i of this wave covers LDS positions [(4 wave + i) KiB, +1 KiB):
   // local pixel 32 wave + 8 i + lane / 8, slot lane % 8, holding channel chunk slot ^ ((px >> 1) & 5).
@@ -150,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < C::AI; ++i) {
       const int ch = f_ks * 64 + dch[i];
-      ds_dma16(a.x + dsrc[i] + (ch < clim ? ch : 0), dst + (wave * C::AI + i) * 1024);   // past the last line: chunk 0 (masked)
+      ds_dma16(a.x + dsrc[i] + (ch < cmax ? ch : 0), dst + (wave * C::AI + i) * 1024);   // past Cin: chunk 0 (masked)
     }
     if (fill || !DS_SKIP(1))
 #pragma unroll
