@@ -782,10 +782,13 @@ __device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const c
     // phase A of the cycle starting at step t (set `cur`), phase B (set `nxt`)
     auto phase_a = [&](int t, u32x4 (&cur)[5], auto epi) __attribute__((always_inline)) {
       write_row(4 * (t + 2) + 2 + h, cur);
+      tm.stamp(4);   // (waits for the five writes to COMPLETE: with the transform pinned into phase B this is pure LDS queueing behind the
+                     // compute waves' fragment reads -- 51 of 170 k ticks: the kernel's limit is LDS traffic, 162 KB per step)
       const int qf = 4 * (t + 6) + 2 + h;
       const char* rowp = img + (unsigned long long)min(max(y0 + (t + 6 < n ? qf : 0), 0), a.Hs - 1) * row_pitch_b;
 #pragma unroll
       for (int it = 0; it < 5; ++it) cur[it] = *reinterpret_cast<const u32x4*>(rowp + src_off[it]);
+      tm.stamp(5);
       if (decltype(epi)::value) {
         rbuf = red_lane + ((t - 1) & 1) * RS_RED_B;
         epilogue();
@@ -797,6 +800,11 @@ __device__ __forceinline__ void r2_helper(const ConvArgs& a, char* ring, const c
     auto phase_b = [&](int t, u32x4 (&nxt)[5], auto epi) __attribute__((always_inline)) {   // step t + 1
       if (decltype(epi)::value) flush_staged();
       transform_row(4 * (t + 4) + 2 + h, nxt, nxt);
+      // The transformed row must EXIST before this step's barrier: the barrier asm only clobbers memory, so hipcc was free to sink
+      // the whole transform (and the vmcnt wait for the row it works on) below it -- into the next step, in front of the five
+      // ring writes, the one place every other wave of the workgroup waits for (round 4, phase timers: 84 of the 96 k ticks of
+      // phase A sat before the first ring write).  An empty asm that reads and writes the five registers pins them here.
+      asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]));
       tm.stamp(2);
       r2_barrier<0>();
       tm.stamp(3);
