@@ -70,6 +70,49 @@ template <class F> __device__ __forceinline__ unsigned fd_pk2(f32x2 f) {
 template <class F> __device__ __forceinline__ unsigned short fd_pk1(float f) {
   return __builtin_bit_cast(unsigned short, (typename F::T)f);
 }
+// ---- stochastic rounding for ACCUMULATIONS into bf16 gradient buffers ---------------------------------------------------------
+// A gradient buffer holds bf16 values, i.e. numbers ON the bf16 grid.  Adding a small term d to such a value g and rounding to
+// nearest returns g whenever |d| < ulp(g) / 2: the term is not rounded, it is ABSORBED -- every time, for every pixel, with the
+// same sign.  BatchNorm's backward adds exactly such terms: dx = A dpre + (B x + C), where B x + C (the subtraction of the
+// batch mean of the gradient) is ~1 / sqrt(N H W) of A dpre and is added in a second pass (the deferred affine of
+// fdgan_hip/backward.py).  Round 4 measured what that does (tools/dbg_dc.py): the gradient a BatchNorm backward leaves sums to
+// 3e-4 .. 8e-4 of its absolute sum per channel instead of zero (round-to-nearest noise would be 1e-5), and a weight gradient
+// taken against activations with a large mean -- the well-conditioned fixtures, BatchNorm biases + 3 -- is 5-20 % off, as a
+// rank-1 error (DC offset x sum of the input).  Rounding the SUM stochastically (v_cvt_sr_bf16_f32: up with probability = the
+// discarded fraction) is unbiased whatever the sizes of the two terms, costs the same 16 bits, and stays reproducible: the
+// random bits are a hash of the element's position, not of time.
+__device__ __forceinline__ unsigned fd_mix32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// 8 fp32 -> 8 bf16 (4 dwords), each rounded stochastically; `seed`: any number unique to this 8-element group in the launch
+__device__ __forceinline__ u32x4 fd_pk8_sr(f32x8 f, unsigned seed) {
+  const unsigned h = fd_mix32(seed);
+  u32x4 out;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {   // a fresh 16 random bits per element: rotations of one well-mixed word (v_alignbit_b32)
+    bf16x2 t = {0, 0};
+    t = __builtin_amdgcn_cvt_sr_bf16_f32(t, f[2 * k], __builtin_amdgcn_alignbit(h, h, 8 * k + 3), false);
+    t = __builtin_amdgcn_cvt_sr_bf16_f32(t, f[2 * k + 1], __builtin_amdgcn_alignbit(h, h, 8 * k + 19), true);
+    out[k] = __builtin_bit_cast(unsigned, t);
+  }
+  return out;
+}
+__device__ __forceinline__ unsigned short fd_pk1_sr(float f, unsigned seed) {
+  bf16x2 t = {0, 0};
+  t = __builtin_amdgcn_cvt_sr_bf16_f32(t, f, fd_mix32(seed), false);
+  return (unsigned short)(__builtin_bit_cast(unsigned, t) & 0xffffu);
+}
+// Where it is used, and where NOT (measured, round 4): only where the added term is small AND coherent -- fdgan_affine_accumulate and
+// the dy staging of the fused bottleneck backward (both add B x + C), the four-scale head's input gradient (constants over
+// k x k windows).  In the data-gradient kernels' own `G += gamma * rstd * dpre` the two terms are of one size, nearest rounding has
+// no bias to remove, and stochastic rounding only doubles the variance: all 282 generator gradients moved from a median 0.80 % /
+// p90 1.20 % to 0.89 % / 1.45 % from the reference's with it there (and the dominant kernel lost 5 %), so those stores round to nearest.
+
 // D = A x B + C on one 16 x 16 x 32 tile; operands as raw 16-byte fragments
 template <class F> __device__ __forceinline__ f32x4 fd_mfma(u32x4 a, u32x4 b, f32x4 c);
 template <> __device__ __forceinline__ f32x4 fd_mfma<FmtA>(u32x4 a, u32x4 b, f32x4 c) {

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
         f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, v), f32x8);
         const f32x8 y8 = fd_cvt8<FmtA>(ybr[i]);               // the bottleneck activation: fp16
         f = __builtin_elementwise_fma(cb8, y8, f + cc8);        // packed fp32: 8 instructions
-        v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, bf16x8));
+        v = fd_pk8_sr(f, (unsigned)p0 * 16u + (unsigned)(tid + i * 512));   // dy is on the bf16 grid already: stochastic rounding (common.h)
       }
       lds_write16(dyt + dyl[i], v);
     }

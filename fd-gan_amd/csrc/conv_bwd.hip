@@ -1326,7 +1326,8 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += fmaf(B[e], xf[e], Cc[e]);
-      *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+      // a small coherent term on top of a value already on the bf16 grid: stochastic rounding (csrc/common.h: fd_pk8_sr)
+      *reinterpret_cast<u32x4*>(op[k]) = fd_pk8_sr(o, (unsigned)((p0 + k * stride) * (long long)a.C8) + (unsigned)c8);
     }
   }
 }

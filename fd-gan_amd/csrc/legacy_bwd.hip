@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void pyramid_pool4_bwd_kernel(PyrBwdArgs a) {
     unsigned short* dp = db_ + py * a.d_sh + px * a.d_sw;
     for (int c = 0; c < a.C; ++c) {
       const float v = fd_cvt1<FmtG>(dp[c]) + c0 * wl[c] + c1 * wl[a.C + c] + c2 * wl[2 * a.C + c] + c3 * wl[3 * a.C + c];
-      dp[c] = fd_pk1<FmtG>(v);
+      dp[c] = fd_pk1_sr(v, (unsigned)(dp - a.dx) + (unsigned)c);   // constants over k x k windows on top of a bf16 value: stochastic rounding (common.h)
     }
   }
   __syncthreads();

@@ -76,8 +76,9 @@ def unet_forward(sd, x, training, kind, masks=None):
 # transitions; decoder: BottleneckBlock (BN-ReLU-1x1, BN-ReLU-3x3, concat) / TransitionBlock (BN-ReLU-ConvTranspose 1x1, nearest x2)
 # with the skip concatenations x42 = [x4, x2], x52 = [x5, x1], x8 = [x8, x] (dehaze22.py:491-529, :604-632).
 # ------------------------------------------------------------------------------------------------------------------
-def dense_forward(sd, x, training, tail):
-    """sd: state_dict (running statistics updated in place in training mode).  tail: "bn" (dehaze1113.Dense) or "pyramid"."""
+def dense_forward(sd, x, training, tail, taps=None):
+    """sd: state_dict (running statistics updated in place in training mode).  tail: "bn" (dehaze1113.Dense) or "pyramid".
+    taps: optional dict that receives conv_refin's raw output (`x9pre`, gradient retained) for gradient debugging."""
     sd = dict(sd)
     bn = lambda t, p: _bn(t, sd, p, training)
 
@@ -111,6 +112,10 @@ def dense_forward(sd, x, training, tail):
     x7 = transup(bottleneck(x6, "dense_block7"), "trans_block7")
     x8 = transup(bottleneck(x7, "dense_block8"), "trans_block8")
     x9 = F.conv2d(torch.cat([x8, x], 1), sd["conv_refin.weight"], sd["conv_refin.bias"], 1, 1)
+    if taps is not None:
+        if x9.requires_grad:
+            x9.retain_grad()
+        taps["x9pre"] = x9
     if tail == "bn":
         x9 = F.leaky_relu(bn(x9, "batchnorm20"), 0.2)
         return torch.tanh(F.conv2d(x9, sd["refine3.weight"], sd["refine3.bias"], 1, 1))

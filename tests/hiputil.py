@@ -135,3 +135,31 @@ def op_reference(r, dy_view, meta):
         y = F.conv2d(a, wt, None, r["stride"], pad)
         y.backward(dy_view.torch_nchw()[:, :w.cout])
     return wt.grad, xr.grad
+
+
+class emulated_functional_convs:
+    """Context manager for the FUNCTIONAL oracles (oracle/legacy_ref.py): while active, `module.F.conv2d / conv_transpose2d` see their
+    input, their filter and their result rounded to fp16 (straight-through for autograd) and hand bf16-rounded gradients back --
+    the functional twin of emulate_kernel_operands(round_grads=True): a CPU statement of what the HIP path computes."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        import types
+        realF = self.module.F
+
+        def st(t):
+            r = t + (t.to(torch.float16).float() - t).detach()
+            if r.requires_grad:
+                r.register_hook(lambda g: g.to(torch.bfloat16).float())
+            return r
+        proxy = types.SimpleNamespace(**{k: getattr(realF, k) for k in dir(realF) if not k.startswith("__")})
+        proxy.conv2d = lambda x, w, *a, **k: st(realF.conv2d(st(x), st(w), *a, **k))
+        proxy.conv_transpose2d = lambda x, w, *a, **k: st(realF.conv_transpose2d(st(x), st(w), *a, **k))
+        self._real, self.module.F = realF, proxy
+        return self
+
+    def __exit__(self, *exc):
+        self.module.F = self._real
+        return False
