@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU call that regenerates the round's profile set under gpurun_out/ (copy the summaries to profiles/):
 #   tools/refresh_profiles.sh r3_v1
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 tools/prof_bench.sh $TAG --no-forward-1024 > gpurun_out/${TAG}_prof.log 2>&1
