@@ -634,6 +634,7 @@ struct SumFinArgs {
   const float* coef_gamma;
   float coef_inv_m;
   float *bsum, *csum;
+  int coef_store;   // bsum / csum = instead of +=
 };
 // (An LDS-free form -- 256 threads, the row lanes summed with wave shuffles -- was measured in round 3 because rocprofv3 shows this
 // kernel at 24.6 us on average against 3.9 us alone: its workgroups wait for LDS while the side stream's weight-gradient kernels
@@ -694,8 +695,14 @@ __global__ __launch_bounds__(1024) void sum_finalize_kernel(SumFinArgs a) {
     if (a.bsum != nullptr) {   // same arithmetic as bn_bwd_coef_kernel, on the fp32-rounded sums it would have read
       const float rs = 1.f / sqrtf(a.raw_var[c] + a.raw_eps), gmm = a.coef_gamma ? a.coef_gamma[c] : 1.f;
       const float A = gmm * rs, B = -gmm * rs * rs * (float)t2 * a.coef_inv_m;
-      a.bsum[c] += B;
-      a.csum[c] += -A * (float)t1 * a.coef_inv_m - B * a.raw_mean[c];
+      const float Cc = -A * (float)t1 * a.coef_inv_m - B * a.raw_mean[c];
+      if (a.coef_store) {
+        a.bsum[c] = B;
+        a.csum[c] = Cc;
+      } else {
+        a.bsum[c] += B;
+        a.csum[c] += Cc;
+      }
     }
   }
 }
@@ -1240,11 +1247,11 @@ extern "C" int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int
  * sinks (optional) and straight into the buffer's deferred coefficient pair; they are not stored anywhere else. */
 extern "C" int fdgan_bn_bwd_finalize_coef(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const FdPrologue* pro,
                                           int64_t count, float* sink_dgamma, float* sink_dbeta, float* bsum, float* csum,
-                                          float* scratch, int64_t scratch_floats, FdStream stream) {
+                                          float* scratch, int64_t scratch_floats, int coef_store, FdStream stream) {
   FD_REQUIRE(partial && pro && pro->mean && pro->var && bsum && csum && rows > 0 && channels > 0 && cpad >= channels && count > 0,
              "bn_bwd_finalize_coef: bad arguments");
   SumFinArgs a{partial, rows, cpad, channels, nullptr, nullptr, 0, sink_dbeta, sink_dgamma, pro->mean, pro->var, pro->eps, nullptr,
-               pro->gamma, 1.f / (float)count, bsum, csum};
+               pro->gamma, 1.f / (float)count, bsum, csum, coef_store};
   return launch_sum_finalize(a, scratch, scratch_floats, stream);
 }
 

@@ -401,6 +401,7 @@ class PlanBackward:
         tab = self._zero_tables.get(self.checks is None)
         if tab is None:
             bufs = [g for g in {id(g): g for g in self.gbuf.values()}.values() if id(g) not in skip]      # aliased buffers once
+            bufs += [d["coef"] for d in self.deferred.values()]      # the pending BatchNorm coefficient pairs: clean at the start of every walk
             if all((g.numel() * g.element_size()) % 16 == 0 and g.data_ptr() % 16 == 0 for g in bufs):
                 tab = E.ZeroTable(bufs) if bufs else False
             else:
@@ -411,10 +412,9 @@ class PlanBackward:
                 g.zero_()
         elif tab:
             tab.launch()
-        for d in self.deferred.values():                                # nothing pending from an interrupted walk
-            if d["dirty"]:
-                E.fill_zero(d["coef"])
-                d["dirty"].clear()
+        for d in self.deferred.values():                                # the launch above cleared every pair
+            d["dirty"].clear()
+            d["stale"].clear()
 
     # ---- one fused convolution ---------------------------------------------------------------
     def _fuse_w(self, r, need_dx):
@@ -556,7 +556,8 @@ class PlanBackward:
                     if res is not None and idx is not None:
                         self._fused_seen.add(idx)
                 if res is not None and dy_pending is not None:
-                    E.fill_zero(dy_pending["coef"])
+                    if not dy_pending.get("store"):
+                        E.fill_zero(dy_pending["coef"])
                     dy_pending["dirty"].clear()
                 if res is None:     # outside the fused kernel's shapes: the two separate kernels
                     if dy_pending is not None:
@@ -577,10 +578,15 @@ class PlanBackward:
                 const = [(x.c0 + lo, x.c0 + hi) for lo, hi in _constant_entries(meta, cin)]
                 if const:
                     self._py(lambda: keep.extend(d["coef"][:, lo:hi].clone() for lo, hi in const))
+                # a tensor this norm alone normalises, whole (a dense layer's bottleneck): its pair is WRITTEN, so nothing ever has
+                # to zero it (43 fills per generator walk); everybody else's pair collects several norms and is added to
+                d["store"] = store_coef = bool(r.get("_sole", False) and x.c0 == 0 and cin == d["buf"].shape[-1] and not const and self.checks is None)
+                if not store_coef:
+                    self._unstale(d, x.c0, x.c0 + cin)
                 E.bn_bwd_finalize_coef(self.ws_bn, rows, cpad, cin, act_pro, n * hin * win, d["coef"][0, x.c0:x.c0 + cin],
                                        d["coef"][1, x.c0:x.c0 + cin],
                                        sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
-                                       sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin)
+                                       sink_dbeta=grad_target(grads, bn.bias) if train_bn else None, scratch=self.ws_fin, store=store_coef)
                 if const:
                     def restore():
                         for (lo, hi), saved in zip(const, keep):
@@ -615,8 +621,23 @@ class PlanBackward:
         d = self.deferred.get(view.buf.data_ptr())
         if d is None:
             d = self.deferred[view.buf.data_ptr()] = dict(
-                buf=view.buf, coef=torch.zeros((2, view.buf.shape[-1]), dtype=torch.float32, device=view.buf.device), dirty=set())
+                buf=view.buf, coef=torch.zeros((2, view.buf.shape[-1]), dtype=torch.float32, device=view.buf.device), dirty=set(), stale=set(),
+                store=False)
+            self._zero_tables.clear()         # the pair joins the buffers zero_() clears
         return d
+
+    def _unstale(self, d, c0, c1):
+        """Channels whose pair was applied (flush) but not zeroed yet -- they are only zeroed at the start of the next walk, in
+        zero_()'s one launch -- must be zero before anything is ADDED to them again in this walk (never inside a dense block:
+        the slice a layer flushes lies above every prefix that is normalised afterwards)."""
+        hit = sorted(c for c in d["stale"] if c0 <= c < c1)
+        while hit:
+            lo = hi = hit[0]
+            while hit and hit[0] == hi:
+                hit.pop(0)
+                hi += 1
+            E.fill_zero(d["coef"][:, lo:hi])
+            d["stale"].difference_update(range(lo, hi))
 
     def flush(self, view):
         """Before G[view] is read: add the pending Bsum * x + Csum of its channels."""
@@ -627,9 +648,14 @@ class PlanBackward:
         if d["dirty"].isdisjoint(range(c0, c1)):
             return
         lo, hi = c0 - c0 % 8, min(d["buf"].shape[-1], (c1 + 7) // 8 * 8)      # whole 8-channel groups (clean ones add zero)
+        for c in [c for c in range(lo, hi) if c in d["stale"] and c not in d["dirty"]]:      # applied earlier in this walk, not zeroed yet
+            self._unstale(d, c, c + 1)
         xv = E.View(d["buf"], lo, hi - lo)
         E.affine_accumulate(xv.fd, d["coef"][0, lo:hi], d["coef"][1, lo:hi], self.G(xv).fd)
-        E.fill_zero(d["coef"][:, lo:hi])
+        if d.get("store") or self.checks is not None:
+            E.fill_zero(d["coef"][:, lo:hi])          # (a written pair is never in zero_()'s table; verification walks flush out of order)
+        else:
+            d["stale"].update(range(lo, hi))          # zeroed by zero_() at the start of the next walk, or by _unstale before a += in this one
         d["dirty"].difference_update(range(lo, hi))
 
     def flush_all(self):
@@ -671,6 +697,7 @@ class PlanBackward:
                 E.fill_zero(dbt[lo:hi])
             if one_pass:      # what is left, B * x + C per channel, waits in the buffer's coefficient pair like every other norm's
                 d = self._deferred(x)
+                self._unstale(d, x.c0, x.c0 + cin)
                 E.bn_bwd_coef(dg, dbt, pool_pro, cin, n * 4 * hin * win, d["coef"][0, x.c0:x.c0 + cin], d["coef"][1, x.c0:x.c0 + cin])
                 d["dirty"].update(range(x.c0, x.c0 + cin))
                 return

@@ -504,14 +504,14 @@ def bn_bwd_finalize_raw(ws, rows, cpad, channels, mean, var, eps, dgamma, dbeta,
             "bn_bwd_finalize_raw")
 
 
-def bn_bwd_finalize_coef(ws, rows, cpad, channels, pro, count, bsum, csum, sink_dgamma=None, sink_dbeta=None, scratch=None):
-    """bn_bwd_finalize_raw + bn_bwd_coef in one launch (no dgamma / dbeta temporaries)."""
+def bn_bwd_finalize_coef(ws, rows, cpad, channels, pro, count, bsum, csum, sink_dgamma=None, sink_dbeta=None, scratch=None, store=False):
+    """bn_bwd_finalize_raw + bn_bwd_coef in one launch (no dgamma / dbeta temporaries).  store: bsum / csum are written, not added to."""
     L.check(L.load().fdgan_bn_bwd_finalize_coef(ws.data_ptr(), rows, cpad, channels, C.byref(pro), count,
                                                 sink_dgamma.data_ptr() if sink_dgamma is not None else None,
                                                 sink_dbeta.data_ptr() if sink_dbeta is not None else None,
                                                 bsum.data_ptr(), csum.data_ptr(),
                                                 scratch.data_ptr() if scratch is not None else None,
-                                                scratch.numel() if scratch is not None else 0, stream_ptr()),
+                                                scratch.numel() if scratch is not None else 0, int(bool(store)), stream_ptr()),
             "bn_bwd_finalize_coef")
 
 

@@ -170,7 +170,7 @@ SIGNATURES = {
     "fdgan_bn_bwd_finalize_raw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "fdgan_bn_bwd_finalize_coef": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(FdPrologue), C.c_int64,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "fdgan_conv2d_bwd_data": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdPrologue),
                                         C.POINTER(FdTensor), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int64), C.POINTER(FdConvDesc), C.c_void_p]),

@@ -356,10 +356,11 @@ int fdgan_bn_bwd_finalize_raw(const float* partial, int64_t rows, int64_t cpad, 
                               float* sink_dbeta, float* scratch, int64_t scratch_floats, FdStream stream);
 /* fdgan_bn_bwd_finalize_raw followed by fdgan_bn_bwd_coef (below) in ONE launch: the sums go to the parameters' gradient
  * sinks (optional) and into the coefficient pair (bsum, csum) of the deferred affine; pro: the forward prologue (mean, var,
- * gamma, eps), count = N*H*W of the normalised tensor. */
+ * gamma, eps), count = N*H*W of the normalised tensor.  coef_store != 0 (ABI v12): bsum / csum are WRITTEN instead of added to --
+ * for a tensor with a single normalising consumer (a dense layer's bottleneck) the pair then never needs zeroing. */
 int fdgan_bn_bwd_finalize_coef(const float* partial, int64_t rows, int64_t cpad, int64_t channels, const FdPrologue* pro,
                                int64_t count, float* sink_dgamma, float* sink_dbeta, float* bsum, float* csum, float* scratch,
-                               int64_t scratch_floats, FdStream stream);
+                               int64_t scratch_floats, int coef_store, FdStream stream);
 /* Data gradient of a stride-1 conv (reference: autograd of nn.Conv2d as composed in models/dehaze1113.py:188-230,
  * :703-801) fused with the first backward pass of the conv's input-side prologue: runs the FORWARD kernel on dy with
  * the flipped filter (fdgan_pack_conv_weight(..., flip = 1), d->pad = k - 1 - pad) and stores
