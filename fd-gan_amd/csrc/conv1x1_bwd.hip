@@ -425,6 +425,9 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q = pq * 16 + m;
+    // raised priority from the data-gradient MFMAs to the weight-gradient block: the co-resident wave's loads and row-phase VALU
+    // yield to the MFMA issue (round 4, tools/bwdw_one.py over the 42 shapes: 4.92 / 4.99 ms without, 4.85 / 4.86 ms with)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
       const int c16 = kc * 4 + kgl;
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(512) void conv1x1_bwdw_kernel(Bwdw1Args aa) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (tl > 0 && !(a.dbg & 32)) wgrad_tile(dyp, atp);        // its MFMAs execute while the row phase below issues
+    __builtin_amdgcn_s_setprio(0);
     unsigned short* gst = a.g + p0 * a.g_pitch;                 // wave-uniform
     f32x2 sc2[4], sh2[4];
     {
