@@ -258,14 +258,19 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
   }
 }
 
-void gaussian15(float* g, double sigma) {   // 1-D factor of isotropic_gaussian_kernel(15, sigma), loss.py:153-159
+// 1-D factor of isotropic_gaussian_kernel(l, sigma), loss.py:153-159, centred in 15 taps (zeros outside the l-tap window: a
+// reflection pad of 7 with zero outer taps reads exactly what a reflection pad of l / 2 would; l odd, 1 <= l <= 15)
+void gaussian15(float* g, double sigma, int l = 15) {
   double v[15], s = 0.0;
   for (int i = 0; i < 15; ++i) {
-    v[i] = exp(-((i - 7) * (i - 7)) / (2.0 * sigma * sigma));
+    const int d = i - 7;
+    v[i] = (d >= -(l / 2) && d <= l / 2) ? exp(-(d * d) / (2.0 * sigma * sigma)) : 0.0;
     s += v[i];
   }
   for (int i = 0; i < 15; ++i) g[i] = (float)(v[i] / s);
 }
+thread_local int g_blur_l = 15;           // set by the _g entry points around their call into the shared launchers
+thread_local double g_blur_sigma = 3.0;
 
 // Adjoint of Blur along ONE axis (the 2-D adjoint is the x pass followed by the y pass; the Gaussian is
 // symmetric).  Forward, 1-D: out[i] = sum_t g[t] x[refl(i + t - 7)].  Its transpose is the zero-padded
@@ -309,7 +314,7 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
   a.tiles_y = (a.H + FS_T - 1) / FS_T;
   FD_REQUIRE(a.H >= 8 && a.W >= 8, "%s: reflection pad 7 needs H, W >= 8", name);
   FD_REQUIRE(planes > 0 && planes < 65536, "%s: plane count %lld", name, planes);
-  gaussian15(a.g, 3.0);
+  gaussian15(a.g, g_blur_sigma, g_blur_l);
   const float m[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
   for (int i = 0; i < 3; ++i) {
     a.mean[i] = m[i];
@@ -416,7 +421,7 @@ extern "C" int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t 
   FD_REQUIRE(!use_input_norm || c == 3, "blur15_bwd: use_input_norm needs 3 channels");
   BlurAdjArgs a{};
   a.H = (int)h, a.W = (int)w, a.C = (int)c;
-  gaussian15(a.g, 3.0);
+  gaussian15(a.g, g_blur_sigma, g_blur_l);
   a.total = n * c * h * w;
   const float sd[3] = {0.229f, 0.224f, 0.225f};
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -427,4 +432,24 @@ extern "C" int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t 
   a.d = tmp, a.out = dx, a.axis = 1;
   for (int i = 0; i < 3; ++i) a.scale[i] = use_input_norm ? 1.f / sd[i] : 1.f;
   return fd_launch(&blur_adj_kernel, "blur15_adj_y", dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, a, st);
+}
+
+/* Blur(l, isotropic_gaussian_kernel(l, sigma)) for any odd l <= 15 and sigma > 0 (loss.py:122-159 builds the module from both;
+ * the reference instantiates l = 15, sigma = 3, which is what fdgan_blur15_* are): the same kernels on zero-extended taps. */
+extern "C" int fdgan_blur_gauss_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int l, float sigma,
+                                    int use_input_norm, FdStream stream) {
+  FD_REQUIRE(l >= 1 && l <= 15 && (l & 1) && sigma > 0.f, "blur_gauss_fwd: l = %d (odd, <= 15), sigma = %g", l, (double)sigma);
+  g_blur_l = l, g_blur_sigma = sigma;
+  const int rc = fdgan_blur15_fwd(x, y, n, c, h, w, use_input_norm, stream);
+  g_blur_l = 15, g_blur_sigma = 3.0;
+  return rc;
+}
+
+extern "C" int fdgan_blur_gauss_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, int l,
+                                    float sigma, int use_input_norm, FdStream stream) {
+  FD_REQUIRE(l >= 1 && l <= 15 && (l & 1) && sigma > 0.f, "blur_gauss_bwd: l = %d (odd, <= 15), sigma = %g", l, (double)sigma);
+  g_blur_l = l, g_blur_sigma = sigma;
+  const int rc = fdgan_blur15_bwd(dy, tmp, dx, n, c, h, w, use_input_norm, stream);
+  g_blur_l = 15, g_blur_sigma = 3.0;
+  return rc;
 }

@@ -136,10 +136,14 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(SsimArgs a) {
   }
 }
 
-void ss_window(float* g) {   // pytorch_ssim/__init__.py:8-10
+thread_local int g_ssim_window = 11;   // set by the _w entry points around their call into the 11-tap ones
+// pytorch_ssim/__init__.py:8-10 gaussian(window_size, 1.5), centred in 11 taps: a window of w < 11 taps with zero padding w / 2
+// IS the zero-extended 11-tap window with zero padding 5
+void ss_window(float* g) {
   double v[11], s = 0.0;
+  const int r = g_ssim_window / 2;
   for (int i = 0; i < 11; ++i) {
-    v[i] = exp(-((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+    v[i] = (i - 5 >= -r && i - 5 <= r) ? exp(-((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)) : 0.0;
     s += v[i];
   }
   for (int i = 0; i < 11; ++i) g[i] = (float)(v[i] / s);
@@ -175,4 +179,24 @@ extern "C" int fdgan_ssim_bwd(const float* x, const float* y, const float* da, c
   ss_window(a.g);
   return fd_launch(&ssim_bwd_kernel, "ssim_bwd", dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)planes), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
+}
+
+/* The same with SSIM(window_size) for odd window sizes <= 11 (pytorch_ssim/__init__.py:39-73 takes the argument; the reference
+ * and fdgan_ssim_fwd / _bwd use 11). */
+extern "C" int fdgan_ssim_fwd_w(const float* x, const float* y, int64_t planes, int64_t h, int64_t w, int window_size, float* partial,
+                                int64_t partial_floats, float* da, float* db, float* dc, FdStream stream) {
+  FD_REQUIRE(window_size >= 1 && window_size <= 11 && (window_size & 1), "ssim_fwd_w: window_size %d (odd, <= 11)", window_size);
+  g_ssim_window = window_size;
+  const int rc = fdgan_ssim_fwd(x, y, planes, h, w, partial, partial_floats, da, db, dc, stream);
+  g_ssim_window = 11;
+  return rc;
+}
+
+extern "C" int fdgan_ssim_bwd_w(const float* x, const float* y, const float* da, const float* db, const float* dc, int64_t planes,
+                                int64_t h, int64_t w, int window_size, float weight, float* dx, FdStream stream) {
+  FD_REQUIRE(window_size >= 1 && window_size <= 11 && (window_size & 1), "ssim_bwd_w: window_size %d (odd, <= 11)", window_size);
+  g_ssim_window = window_size;
+  const int rc = fdgan_ssim_bwd(x, y, da, db, dc, planes, h, w, weight, dx, stream);
+  g_ssim_window = 11;
+  return rc;
 }

@@ -239,6 +239,23 @@ def blur15_bwd(dy, use_input_norm=True):
     return dx
 
 
+def blur_gauss(x, l, sigma, use_input_norm=True):
+    """Blur(l, isotropic_gaussian_kernel(l, sigma))(x): odd l <= 15."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().fdgan_blur_gauss_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, int(l), float(sigma), int(bool(use_input_norm)), stream_ptr()),
+            "blur_gauss_fwd")
+    return y
+
+
+def blur_gauss_bwd(dy, l, sigma, use_input_norm=True):
+    n, c, h, w = dy.shape
+    tmp, dx = torch.empty_like(dy), torch.empty_like(dy)
+    L.check(L.load().fdgan_blur_gauss_bwd(dy.data_ptr(), tmp.data_ptr(), dx.data_ptr(), n, c, h, w, int(l), float(sigma),
+                                          int(bool(use_input_norm)), stream_ptr()), "blur_gauss_bwd")
+    return dx
+
+
 def laplacian3(x):
     n, c, h, w = x.shape
     y = torch.empty_like(x)

@@ -117,6 +117,13 @@ SIGNATURES = {
     "fdgan_plan_end": (C.c_int, [C.c_void_p]),
     "fdgan_plan_num_launches": (C.c_int64, [C.c_void_p]),
     "fdgan_plan_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fdgan_ssim_fwd_w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdgan_ssim_bwd_w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                   C.c_float, C.c_void_p, C.c_void_p]),
+    "fdgan_blur_gauss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "fdgan_blur_gauss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int,
+                                       C.c_void_p]),
     "fdgan_plan_set_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "fdgan_plan_record_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "fdgan_plan_launch_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),

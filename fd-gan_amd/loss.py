@@ -117,17 +117,27 @@ def _gpu_f32(x, what):
 
 
 class Blur(nn.Module):
-    """loss.py:122-151.  The HIP kernel implements the instance the reference builds (l = 15, the
-    sigma = 3 isotropic Gaussian, :161-162); other kernels are rejected rather than approximated."""
+    """loss.py:122-151.  The HIP kernel is separable and 15 taps wide: it takes what `isotropic_gaussian_kernel(l, sigma)` builds for
+    any odd l <= 15 and any sigma (the reference's instance is l = 15, sigma = 3, :161-162); a kernel that is not such a Gaussian is
+    rejected rather than approximated."""
 
     def __init__(self, l=15, kernel=None, use_input_norm=True):
         super().__init__()
         self.l = l
         self.use_input_norm = use_input_norm
-        ref = isotropic_gaussian_kernel(15, 3.0)
-        kernel = ref if kernel is None else torch.as_tensor(kernel, dtype=torch.float32)
-        if l != 15 or tuple(kernel.shape[-2:]) != (15, 15) or (kernel.reshape(15, 15) - ref).abs().max() > 1e-7:
-            raise NotImplementedError("the HIP Blur implements l=15, isotropic_gaussian_kernel(15, 3.0) (loss.py:161)")
+        if kernel is None:
+            kernel = isotropic_gaussian_kernel(l, 3.0)
+        kernel = torch.as_tensor(kernel, dtype=torch.float32)
+        if l < 1 or l > 15 or l % 2 == 0 or tuple(kernel.shape[-2:]) != (l, l):
+            raise NotImplementedError("the HIP Blur takes odd kernel sizes l <= 15 with an l x l kernel (got l = %r, kernel %s)"
+                                      % (l, tuple(kernel.shape)))
+        k2 = kernel.reshape(l, l).double()
+        c = l // 2
+        # sigma from the ratio of the centre tap to its neighbour, then the kernel must BE that Gaussian
+        ratio = float(k2[c, c] / k2[c, c + 1]) if l > 1 else 2.0
+        self.sigma = float((1.0 / (2.0 * np.log(ratio))) ** 0.5) if ratio > 1.0 + 1e-12 else 1e6      # a box filter is the sigma -> inf Gaussian
+        if not (self.sigma > 0 and (k2 - isotropic_gaussian_kernel(l, self.sigma).double()).abs().max() < 1e-7):
+            raise NotImplementedError("the HIP Blur implements isotropic_gaussian_kernel(l, sigma) kernels (loss.py:153-159); this one is not")
         self.register_buffer("kernel", kernel.view(1, 1, l, l))
         if use_input_norm:
             self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
@@ -135,8 +145,8 @@ class Blur(nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
-            return _BlurFn.apply(x, self.use_input_norm)
-        return E.blur15(_gpu_f32(x, "Blur.forward"), self.use_input_norm)
+            return _BlurFn.apply(x, self.use_input_norm, self.l, self.sigma)
+        return E.blur_gauss(_gpu_f32(x, "Blur.forward"), self.l, self.sigma, self.use_input_norm)
 
 
 class Laplacian(nn.Module):
@@ -163,13 +173,13 @@ laplace_filter = Laplacian(kernel_size=3)                       # loss.py:304
 
 class _BlurFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, use_input_norm):
-        ctx.norm = use_input_norm
-        return E.blur15(_gpu_f32(x, "Blur.forward"), use_input_norm)
+    def forward(ctx, x, use_input_norm, l=15, sigma=3.0):
+        ctx.norm, ctx.l, ctx.sigma = use_input_norm, l, sigma
+        return E.blur_gauss(_gpu_f32(x, "Blur.forward"), l, sigma, use_input_norm)
 
     @staticmethod
     def backward(ctx, dy):
-        return E.blur15_bwd(dy.detach().float().contiguous(), ctx.norm), None
+        return E.blur_gauss_bwd(dy.detach().float().contiguous(), ctx.l, ctx.sigma, ctx.norm), None, None, None
 
 
 class _LaplacianFn(torch.autograd.Function):

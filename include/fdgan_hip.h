@@ -478,6 +478,13 @@ int fdgan_ssim_fwd(const float* x, const float* y, int64_t planes, int64_t h, in
 int fdgan_ssim_bwd(const float* x, const float* y, const float* da, const float* db, const float* dc, int64_t planes,
                    int64_t h, int64_t w, float weight, float* dx, FdStream stream);
 
+/* SSIM(window_size) for odd window sizes <= 11 (models/pytorch_ssim/__init__.py:39-73 takes the argument; 11 is the default the
+ * reference uses): the zero-extended window on the same kernels. */
+int fdgan_ssim_fwd_w(const float* x, const float* y, int64_t planes, int64_t h, int64_t w, int window_size, float* partial,
+                     int64_t partial_floats, float* da, float* db, float* dc, FdStream stream);
+int fdgan_ssim_bwd_w(const float* x, const float* y, const float* da, const float* db, const float* dc, int64_t planes,
+                     int64_t h, int64_t w, int window_size, float weight, float* dx, FdStream stream);
+
 /* ---- scalar losses -----------------------------------------------------------------------------------
  * Mean reductions of a training loop over the reference's networks, value AND gradient in one pass, ordered two-stage
  * sums (bit-reproducible).  fdgan_loss_f32 on contiguous fp32 tensors of n elements:
@@ -538,6 +545,12 @@ int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t
  * reflection halo back; `tmp` is n*c*h*w floats of caller-owned scratch. */
 int fdgan_blur15_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w,
                      int use_input_norm, FdStream stream);
+/* Blur(l, isotropic_gaussian_kernel(l, sigma)) for any odd l <= 15 and sigma > 0 (the module's constructor arguments,
+ * loss.py:122-159; the reference builds l = 15, sigma = 3): the 15-tap kernels on zero-extended taps.  h, w >= 8 (16 backward). */
+int fdgan_blur_gauss_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int l, float sigma,
+                         int use_input_norm, FdStream stream);
+int fdgan_blur_gauss_bwd(const float* dy, float* tmp, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, int l, float sigma,
+                         int use_input_norm, FdStream stream);
 /* dx = Laplacian(dy): the operator is self-adjoint (symmetric kernel, zero padding); loss.py:286-301 under autograd. */
 int fdgan_laplacian3_bwd(const float* dy, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
 int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w, const FdTensor* y,

@@ -203,6 +203,23 @@ def test_frequency_split_matches_oracle_and_golden(golden_dir):
         loss.laplace_filter(torch.ones(3, 8, 8, device=DEV))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         loss.blur(x)
+    # Blur's own constructor arguments (loss.py:122-159): other odd kernel sizes and sigmas, forward and adjoint, vs the oracle;
+    # a kernel that is not isotropic_gaussian_kernel(l, sigma) is refused
+    for l, sigma in ((7, 1.5), (11, 2.0), (15, 4.5), (1, 1.0)):
+        mod = loss.Blur(l, loss.isotropic_gaussian_kernel(l, sigma), use_input_norm=(l == 11))
+        xr = x.clone().requires_grad_(True)
+        yr = freqsplit_ref.blur(xr, l, sigma, use_input_norm=(l == 11))
+        cot = det_input(tuple(yr.shape), seed=13, lo=-1.0, hi=1.0)
+        (yr * cot).sum().backward()
+        xh = x.to(DEV).requires_grad_(True)
+        yh = mod(xh)
+        (yh * cot.to(DEV)).sum().backward()
+        assert (yh.detach().cpu() - yr.detach()).abs().max() < 3e-5, (l, sigma)
+        assert rel_rms(xh.grad.cpu(), xr.grad) < 1e-5, (l, sigma)
+    with pytest.raises(NotImplementedError):
+        loss.Blur(15, torch.rand(15, 15, generator=torch.Generator().manual_seed(3)))      # not a Gaussian
+    with pytest.raises(NotImplementedError):
+        loss.Blur(17, loss.isotropic_gaussian_kernel(17, 3.0))
     # fused D input: [img | LF | HF] as NHWC bf16, larger ragged image
     x2 = det_input((2, 3, 70, 90), seed=12).to(DEV)
     buf = E.new_act(2, 70, 90, 16, torch.device(DEV), zero=True)
@@ -835,8 +852,16 @@ def test_ssim_forward_backward(manifest):
     assert v.shape == (3,) and (v.cpu() - vo.detach()).abs().max() < 2e-5, (v, vo)
     assert rel_rms(ag.grad.cpu(), ao.grad) < 1e-3
     assert (hs.ssim(a.to(DEV), b.to(DEV), size_average=False).cpu() - vo.detach()).abs().max() < 2e-5
+    # window sizes other than the default (:39-40, :65): odd <= 11 on the same kernel (zero-extended window); even ones are refused
+    ao2 = a.clone().requires_grad_(True)
+    v7o = ssim_ref.ssim(ao2, b, window_size=7)
+    v7o.backward()
+    ag2 = a.to(DEV).requires_grad_(True)
+    v7 = hs.SSIM(window_size=7)(ag2, b.to(DEV))
+    v7.backward()
+    assert abs(float(v7) - float(v7o)) < 2e-5 and rel_rms(ag2.grad.cpu(), ao2.grad) < 1e-3
     with pytest.raises(NotImplementedError):
-        hs.ssim(same, same, window_size=7)
+        hs.ssim(same, same, window_size=8)
 
 
 def test_training_step_smoke():
