@@ -532,3 +532,51 @@ extern "C" int fdgan_add_transposed_f32(float* dst, const float* src, int64_t ro
   return fd_launch(&add_transposed_kernel, "add_transposed_f32", dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
+
+// ---- element-wise dropout of the dy blocks (dropRate > 0; /root/reference/models/dehaze1113.py:270-274, :367-368) --------
+// F.dropout(out, p, training) = out * mask / (1 - p) with an element-wise Bernoulli mask.  The host draws the mask (torch's
+// generator, as the reference does) into an NHWC fp16 tensor that already holds 0 or 1 / (1 - p); forward and backward are the same
+// in-place multiply, on an fp16 activation view or a bf16 gradient view.  up2: the view is the 2x nearest-upsampled image of
+// what the mask covers (TransitionBlockdy drops BEFORE it upsamples): pixel (y, x) takes mask (y / 2, x / 2).
+namespace {
+struct MulMaskArgs {
+  unsigned short* d;
+  long long d_sn;
+  int d_sh, d_sw;
+  const unsigned short* m;
+  long long m_sn;
+  int m_sh, m_sw;
+  int N, H, W, C8, up2, grad;
+};
+__global__ __launch_bounds__(256) void mul_mask_kernel(MulMaskArgs a) {
+  const unsigned u = blockIdx.x * 256u + threadIdx.x;
+  if (u >= (unsigned)a.N * a.H * a.W * a.C8) return;
+  const int c8 = (int)(u % (unsigned)a.C8);
+  unsigned r = u / (unsigned)a.C8;
+  const int x = (int)(r % (unsigned)a.W);
+  r /= (unsigned)a.W;
+  const int y = (int)(r % (unsigned)a.H), n = (int)(r / (unsigned)a.H);
+  unsigned short* dp = a.d + n * a.d_sn + (long long)y * a.d_sh + (long long)x * a.d_sw + c8 * 8;
+  const unsigned short* mp = a.m + n * a.m_sn + (long long)(a.up2 ? y >> 1 : y) * a.m_sh + (long long)(a.up2 ? x >> 1 : x) * a.m_sw + c8 * 8;
+  const f32x8 mk = fd_cvt8<FmtA>(*reinterpret_cast<const u32x4*>(mp));
+  const u32x4 raw = *reinterpret_cast<const u32x4*>(dp);
+  if (a.grad) *reinterpret_cast<u32x4*>(dp) = fd_pk8<FmtG>(fd_cvt8<FmtG>(raw) * mk);
+  else *reinterpret_cast<u32x4*>(dp) = fd_pk8<FmtA>(fd_cvt8<FmtA>(raw) * mk);
+}
+}  // namespace
+
+extern "C" int fdgan_mul_mask_nhwc(const FdTensor* mask, const FdTensor* dst, int up2, FdStream stream) {
+  FD_REQUIRE(mask && dst && mask->ptr && dst->ptr, "mul_mask_nhwc: NULL tensor");
+  FD_REQUIRE(mask->dtype == FD_F16 && (dst->dtype == FD_F16 || dst->dtype == FD_BF16), "mul_mask_nhwc: an fp16 mask and a 16-bit view");
+  const int f = up2 ? 2 : 1;
+  FD_REQUIRE(mask->n == dst->n && mask->h * f == dst->h && mask->w * f == dst->w && mask->c == dst->c, "mul_mask_nhwc: shape mismatch");
+  for (const FdTensor* t : {mask, dst})
+    FD_REQUIRE(t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0,
+               "mul_mask_nhwc: NHWC 16-bit views with 8-element aligned strides expected");
+  MulMaskArgs a{static_cast<unsigned short*>(dst->ptr), dst->stride[0], (int)dst->stride[1], (int)dst->stride[2],
+                static_cast<const unsigned short*>(mask->ptr), mask->stride[0], (int)mask->stride[1], (int)mask->stride[2],
+                (int)dst->n, (int)dst->h, (int)dst->w, (int)((dst->c + 7) / 8), up2 ? 1 : 0, dst->dtype == FD_BF16 ? 1 : 0};
+  const long long total = (long long)a.N * a.H * a.W * a.C8;
+  FD_REQUIRE(total > 0 && total < (1ll << 31), "mul_mask_nhwc: %lld groups", total);
+  return fd_launch(&mul_mask_kernel, "mul_mask_nhwc", dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+}

@@ -239,7 +239,7 @@ class PlanBackward:
         # skipped, whether an all-reduce hook rides along) and is only made when every gradient goes straight into an
         # optimizer's flat buffer (FlatAdam sinks: stable addresses) and the plan holds no legacy op with host-side arithmetic.
         self.tape_enabled = (os.environ.get("FDGAN_NO_BACKWARD_TAPE") is None and dev.type == "cuda" and not self.recompute and
-                             all(r["kind"] in ("conv", "copy", "maxpool") for r in self.recs))
+                             all(r["kind"] in ("conv", "copy", "maxpool", "dropout") for r in self.recs))
         self.tapes = {}
         self._rec = None
         self._persist = {}
@@ -871,6 +871,10 @@ class PlanBackward:
             if r["kind"] == "maxpool":
                 self.flush(r["dst"])
                 E.maxpool2_bwd(r["src"], self.G(r["dst"]), self.G(r["src"]))
+                continue
+            if r["kind"] == "dropout":      # y = x * mask in place: the gradient takes the same multiply
+                self.flush(r["dst"])
+                E.mul_mask(r["mask"], self.G(r["dst"]), r["up2"])
                 continue
             if r["kind"] in ("pyramid", "bn_dropout", "maxpool3"):      # the legacy DCPDN networks' own ops (csrc/legacy_bwd.hip)
                 self.flush(r["dst"])

@@ -664,6 +664,11 @@ def add_transposed(dst, src):
     L.check(L.load().fdgan_add_transposed_f32(dst.data_ptr(), src.data_ptr(), rows, cols, stream_ptr()), "add_transposed_f32")
 
 
+def mul_mask(mask, dst, up2=False):
+    """dst (activation or gradient View) *= mask (fp16 View holding 0 or 1 / (1 - p)); up2: dst is the x2 upsampled image of the mask's extent."""
+    L.check(L.load().fdgan_mul_mask_nhwc(C.byref(mask.fd), C.byref(dst.fd), int(bool(up2)), stream_ptr()), "mul_mask_nhwc")
+
+
 GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK, GRAD_LEAKY_MASK = 0, 1, 2, 3, 4
 
 

@@ -124,6 +124,7 @@ SIGNATURES = {
     "fdgan_blur_gauss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "fdgan_blur_gauss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_int,
                                        C.c_void_p]),
+    "fdgan_mul_mask_nhwc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_int, C.c_void_p]),
     "fdgan_plan_set_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "fdgan_plan_record_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "fdgan_plan_launch_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),

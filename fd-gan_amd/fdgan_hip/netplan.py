@@ -40,6 +40,8 @@ class NetPlan:
         self.grad_alias = {}       # activation buffer data_ptr -> data_ptr of the buffer whose GRADIENT buffer it shares
         self._param_versions = None
         self.records = []          # per op, in forward order: what the backward pass needs (fdgan_hip/backward.py)
+        self.drops = []            # (mask buffer, channels, p) of every element-wise dropout, in plan order
+        self.forced_dropout = None
         import os
         # Opt-in: the producer's last workgroup finalizes the batch statistics (86 fdgan_bn_finalize launches less per netG
         # forward).  Measured twice, slower both times.  With device-scope release / acquire fences in every workgroup (an L2
@@ -134,6 +136,32 @@ class NetPlan:
         self.keep += [src, dst]
         self.records.append(dict(kind="maxpool", src=src, dst=dst))
 
+    def dropout(self, view, p, up2=False):
+        """F.dropout(view, p, training=True) in place (the dy blocks' dropRate > 0, /root/reference/models/dehaze1113.py:270-274,
+        :367-368): a fresh element-wise mask per forward, drawn by torch into a plan-owned fp16 tensor holding 0 or 1 / (1 - p)
+        (`refresh_dropout`, called by `launch`), multiplied in by one recorded launch; the reverse walk multiplies the gradient by the
+        same tensor.  up2: `view` is already the nearest x2 image of the dropped tensor (TransitionBlockdy)."""
+        n, h, w, c = view.shape
+        f = 2 if up2 else 1
+        mbuf = E.new_act(n, h // f, w // f, (c + 7) // 8 * 8, self.device, zero=True)
+        mview = E.View(mbuf, 0, c)
+        self.drops.append((mbuf, c, float(p)))
+        self._ops.append((lambda: E.mul_mask(mview, view, up2), 0, dict(label="dropout", flops=0.0, flops_done=0.0,
+                                                                      bytes=4 * n * h * w * c)))
+        self.records.append(dict(kind="dropout", src=view, dst=view, mask=mview, up2=bool(up2)))
+        self.keep += [view, mview]
+
+    def refresh_dropout(self, forced=None):
+        """New masks for the next launch.  forced: test hook -- a list of NCHW 0 / 1 tensors, one per dropout in plan order (what the
+        oracle drew), used instead of the generator."""
+        for i, (mbuf, c, p) in enumerate(self.drops):
+            if forced is not None:
+                m = forced[i].to(mbuf.device).permute(0, 2, 3, 1).to(mbuf.dtype)
+                mbuf[..., :c].copy_(m / (1.0 - p))
+            else:
+                keep = torch.empty(mbuf.shape[:3] + (c,), dtype=torch.float32, device=mbuf.device).bernoulli_(1.0 - p)
+                mbuf[..., :c].copy_(keep / (1.0 - p))
+
     def op(self, fn, record=None, need=0):
         """An arbitrary launch sequence.  record: what the reverse walk needs to know about it (fdgan_hip/backward.py: kinds
         "pyramid", "bn_dropout", "maxpool3" with `src` / `dst` views); need: floats of the shared workspace it uses."""
@@ -184,6 +212,8 @@ class NetPlan:
 
     def launch(self):
         self.refresh_weights()
+        if self.drops:
+            self.refresh_dropout(self.forced_dropout)
         self.main.launch()
 
     def param_ptrs(self):

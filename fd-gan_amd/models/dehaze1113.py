@@ -52,6 +52,7 @@ class _PlannedModule(nn.Module):
                 cache.pop(next(iter(cache)))
         cache[key] = plan
         self.__dict__.setdefault("_last_plan", {})[key[:3]] = key     # a key, not the plan: eviction must free it
+        plan.forced_dropout = self.__dict__.get("_forced_dropout_masks")     # tests: the masks the oracle drew (NetPlan.refresh_dropout)
         return plan
 
     def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
@@ -162,9 +163,7 @@ class BottleneckBlockdy(_PlannedModule):
         self.conv1 = nn.Conv2d(in_planes, inter, 1, 1, 0, bias=False)
         self.bn2 = nn.BatchNorm2d(inter)
         self.conv2 = nn.Conv2d(inter, out_planes, 3, 1, 1, bias=False)
-        self.droprate = dropRate
-        if dropRate > 0:
-            raise NotImplementedError("dropRate > 0 is never used by FDGAN (dehaze1113.py:731-739)")
+        self.droprate = dropRate          # > 0: F.dropout after each conv in training mode (:270-274; FDGAN passes the default 0)
         self.in_planes, self.inter, self.out_planes = in_planes, inter, out_planes
 
     def emit(self, P, blk, tmp):
@@ -173,8 +172,13 @@ class BottleneckBlockdy(_PlannedModule):
         w1 = P.weight(self.conv1.weight, self.inter, cin, 1)
         w2 = P.weight(self.conv2.weight, cout, self.inter, 3)
         relu = E.make_prologue(act=L.ACT_RELU)
+        drop = self.droprate > 0 and self.training
         P.conv(E.View(blk.buf, blk.c0, cin), w1, tmp, 1, pro=relu)
+        if drop:
+            P.dropout(tmp, self.droprate)
         P.conv(tmp, w2, E.View(blk.buf, blk.c0 + cin, cout), 3, pad=1, pro=relu)
+        if drop:
+            P.dropout(E.View(blk.buf, blk.c0 + cin, cout), self.droprate)
 
     def _build_plan(self, shape, dev):
         n, c, h, w = shape
@@ -235,14 +239,14 @@ class TransitionBlockdy(_PlannedModule):
         self.bn1 = nn.BatchNorm2d(in_planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv1 = nn.ConvTranspose2d(in_planes, out_planes, 1, 1, 0, bias=False)
-        self.droprate = dropRate
-        if dropRate > 0:
-            raise NotImplementedError("dropRate > 0 is never used by FDGAN")
+        self.droprate = dropRate          # > 0: F.dropout between the conv and the upsample in training mode (:367-368)
         self.in_planes, self.out_planes = in_planes, out_planes
 
     def emit(self, P, x, y):
         w = P.weight(self.conv1.weight, self.out_planes, self.in_planes, 1, transposed=True)
         P.conv(x, w, y, 1, pro=E.make_prologue(act=L.ACT_RELU), upsample=True)
+        if self.droprate > 0 and self.training:
+            P.dropout(y, self.droprate, up2=True)       # the mask is drawn at the conv's resolution, before the nearest x2
 
     def _build_plan(self, shape, dev):
         n, c, h, w = shape

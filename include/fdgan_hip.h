@@ -270,6 +270,12 @@ int fdgan_scatter_dehaze_bwd(const float* x, const float* tran, const float* atp
                              int64_t w, float slope, float eps, const float* g_dehaze2, const float* g_atp, const FdTensor* g_cat,
                              float* d_tran, float* d_atp, float* scratch, int64_t scratch_floats, FdStream stream);
 
+/* Element-wise dropout of the dy blocks (dropRate > 0: F.dropout at /root/reference/models/dehaze1113.py:270-274, :367-368; FDGAN
+ * itself constructs them with 0): dst *= mask in place, mask an NHWC fp16 tensor holding 0 or 1 / (1 - p) that the host drew.  dst:
+ * the fp16 activation (forward) or the bf16 gradient of it (backward: the same multiply).  up2 != 0: dst is twice the mask's
+ * size, pixel (y, x) takes mask (y / 2, x / 2) -- TransitionBlockdy drops before its nearest x2 upsample. */
+int fdgan_mul_mask_nhwc(const FdTensor* mask, const FdTensor* dst, int up2, FdStream stream);
+
 /* ---- plan: record once, replay many ----------------------------------------- */
 /* Between fdgan_plan_begin and fdgan_plan_end every launching entry point above,
  * called from the same thread, is recorded into the plan instead of being

@@ -30,12 +30,23 @@ class BottleneckBlockdy(nn.Module):
         self.conv1 = nn.Conv2d(in_planes, inter, 1, 1, 0, bias=False)
         self.bn2 = nn.BatchNorm2d(inter)
         self.conv2 = nn.Conv2d(inter, out_planes, 3, 1, 1, bias=False)
-        assert dropRate == 0.0  # every FDGAN call site passes the default (:731-739)
+        self.droprate = dropRate        # every FDGAN call site passes the default 0 (:731-739); > 0: F.dropout after each conv (:270-274)
+        self.masks = []                 # the 0 / 1 masks of the last training forward, in order (tests hand them to the HIP path)
+
+    def _dropout(self, out):
+        """F.dropout(out, p, inplace=False, training=self.training) spelled out (ATen: noise = empty_like(out).bernoulli_(1 - p);
+        out * noise / (1 - p)) so that the mask it drew can be read back."""
+        if self.droprate > 0 and self.training:
+            m = torch.empty_like(out).bernoulli_(1.0 - self.droprate)
+            self.masks.append(m)
+            return out * (m / (1.0 - self.droprate))
+        return out
 
     def forward(self, x):
+        self.masks = []
         x.relu_()                       # aliasing kept on purpose (Appendix E.2)
-        mid = self.conv1(x)
-        out = self.conv2(torch.relu(mid))
+        mid = self._dropout(self.conv1(x))
+        out = self._dropout(self.conv2(torch.relu(mid)))
         return torch.cat([x, out], 1)
 
 
@@ -47,10 +58,16 @@ class TransitionBlockdy(nn.Module):
         super().__init__()
         self.bn1 = nn.BatchNorm2d(in_planes)    # registered, unused (:361)
         self.conv1 = nn.ConvTranspose2d(in_planes, out_planes, 1, 1, 0, bias=False)
-        assert dropRate == 0.0
+        self.droprate = dropRate        # > 0: F.dropout between the conv and the upsample (:367-368)
+        self.masks = []
 
     def forward(self, x):
+        self.masks = []
         y = self.conv1(x.relu_())
+        if self.droprate > 0 and self.training:
+            m = torch.empty_like(y).bernoulli_(1.0 - self.droprate)
+            self.masks.append(m)
+            y = y * (m / (1.0 - self.droprate))
         return F.interpolate(y, scale_factor=2, mode="nearest")   # F.upsample_nearest (:370)
 
 

@@ -155,6 +155,28 @@ def main():
     man["ref_vs_oracle_maxabs"]["transitiondy"] = float((yt_o - yt_r).abs().max())
     np.savez_compressed(os.path.join(OUT, "dyblocks.npz"), y_bottleneck=yb_r.numpy(),
                         x_after=xb_r.numpy(), y_transition=yt_r.numpy())
+    # the same two blocks with dropRate > 0 in training mode (/root/reference/models/dehaze1113.py:270-274, :367-368; FDGAN itself
+    # passes 0): the REAL modules under a seed give the outputs, the oracle under the same seed must give the same bits and hands
+    # out the masks F.dropout drew (stored as bits), so that the HIP path can be run on exactly those masks
+    obd, rbd = o1113.BottleneckBlockdy(64, 32, 0.3), r1113.BottleneckBlockdy(64, 32, 0.3)
+    fill_state_dict(obd, seed=3)
+    _copy_weights(rbd, obd)
+    otd, rtd = o1113.TransitionBlockdy(96, 16, 0.25), r1113.TransitionBlockdy(96, 16, 0.25)
+    fill_state_dict(otd, seed=4)
+    _copy_weights(rtd, otd)
+    with torch.no_grad():
+        torch.manual_seed(2024)
+        ybd_r = rbd(xb.clone())
+        ytd_r = rtd(ybd_r.clone())
+        torch.manual_seed(2024)
+        ybd_o = obd(xb.clone())
+        ytd_o = otd(ybd_o.clone())
+    man["ref_vs_oracle_maxabs"]["bottleneckdy_dropout_train"] = float((ybd_o - ybd_r).abs().max())
+    man["ref_vs_oracle_maxabs"]["transitiondy_dropout_train"] = float((ytd_o - ytd_r).abs().max())
+    np.savez_compressed(os.path.join(OUT, "dyblocks_dropout.npz"), y_bottleneck=ybd_r.numpy(), y_transition=ytd_r.numpy(),
+                        mask_b0=np.packbits(obd.masks[0].numpy().astype(np.uint8)), mask_b1=np.packbits(obd.masks[1].numpy().astype(np.uint8)),
+                        mask_t0=np.packbits(otd.masks[0].numpy().astype(np.uint8)),
+                        shape_b0=np.array(obd.masks[0].shape), shape_b1=np.array(obd.masks[1].shape), shape_t0=np.array(otd.masks[0].shape))
 
     # ---------------- Fusion-D (9,36) and dehaze22.D, 2x9x64x64 ----------------
     od, rd = o1113.D(9, 36), r1113.D(9, 36)

@@ -94,6 +94,36 @@ def test_dy_blocks_match_golden(golden_dir):
     assert z.shape == (2, 16, 32, 32)
 
 
+def _dropout_masks(gold):
+    return [torch.from_numpy(np.unpackbits(gold["mask_" + k])[:int(np.prod(gold["shape_" + k]))].reshape(tuple(gold["shape_" + k])).astype(np.float32))
+            for k in ("b0", "b1", "t0")]
+
+
+def test_dy_blocks_with_dropout_match_golden(golden_dir, manifest):
+    """dropRate > 0 (/root/reference/models/dehaze1113.py:270-274, :367-368): the REAL blocks under seed 2024 wrote the fixture; the
+    oracle's spelled-out F.dropout under the same seed gives the same bits and draws exactly the stored masks."""
+    gold = _load(golden_dir, "dyblocks_dropout.npz")
+    assert manifest["ref_vs_oracle_maxabs"]["bottleneckdy_dropout_train"] == 0.0 and manifest["ref_vs_oracle_maxabs"]["transitiondy_dropout_train"] == 0.0
+    b, t = o1113.BottleneckBlockdy(64, 32, 0.3), o1113.TransitionBlockdy(96, 16, 0.25)
+    fill_state_dict(b, seed=3), fill_state_dict(t, seed=4)
+    x = det_input((2, 64, 16, 16), seed=5, lo=-1.0, hi=1.0)
+    with torch.no_grad():
+        torch.manual_seed(2024)
+        y = b(x)
+        z = t(y.clone())
+    np.testing.assert_allclose(y.numpy(), gold["y_bottleneck"], **TOL)
+    np.testing.assert_allclose(z.numpy(), gold["y_transition"], **TOL)
+    for got, want in zip(b.masks + t.masks, _dropout_masks(gold)):
+        assert torch.equal(got, want)
+    frac = float(b.masks[0].mean())
+    assert 0.65 < frac < 0.75                                            # keep probability 1 - 0.3
+    b0 = o1113.BottleneckBlockdy(64, 32)                                 # eval mode: F.dropout(training=False) is the identity
+    b0.load_state_dict(b.state_dict())
+    b.eval(), b0.eval()
+    with torch.no_grad():
+        assert torch.equal(b(x.clone()), b0(x.clone())) and not b.masks
+
+
 def test_fusion_d_matches_golden(golden_dir):
     gold = _load(golden_dir, "d_2x64.npz")
     d = o1113.D(9, 36)
