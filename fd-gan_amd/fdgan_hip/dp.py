@@ -34,7 +34,7 @@ class DpContext:
         if not 0 <= rank < world:
             raise ValueError("RANK %d outside WORLD_SIZE %d" % (rank, world))
         if device is None and torch.cuda.is_available():
-            device = torch.device("cuda", local)
+            device = torch.device("cuda", 0 if os.environ.get("FDGAN_DP_SHARED_GPU") == "1" else local)      # test hook: all ranks on cuda:0
             torch.cuda.set_device(device)
         owns = False
         # FDGAN_DP_FORCE_EXCHANGE=1 (tests, single-GPU boxes): build the process group and run the gradient collectives even
@@ -43,8 +43,8 @@ class DpContext:
         if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            if backend is None:
-                backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+            if backend is None:      # FDGAN_DP_BACKEND: tests put two ranks on ONE GPU, which RCCL refuses: gloo there
+                backend = os.environ.get("FDGAN_DP_BACKEND") or ("nccl" if (device is not None and device.type == "cuda") else "gloo")
             dist.init_process_group(backend, rank=rank, world_size=world)
             owns = True
         ctx = cls(rank, world, local, device, owns)

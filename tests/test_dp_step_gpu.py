@@ -194,3 +194,37 @@ def test_c_abi_allreduce_one_rank_communicator():
     side.synchronize()
     assert torch.equal(buf, want)
     L.check(lib.fdgan_allreduce_comm_destroy(comm), "allreduce_comm_destroy")
+
+
+def test_train_py_real_data_loop_single_and_two_ranks(tmp_path):
+    """`train.py --dataroot` end to end on .h5 pairs (the reference's data format, /root/reference/datasets/pix2pix.py:62-77): one
+    process (the reference's loader as it is: shuffled, ragged last batch), then TWO ranks sharing this GPU over gloo on a dataset
+    whose batch count is odd per rank pair -- the ADVICE r3 deadlock scenario on the real loop: both ranks must finish both epochs
+    (fdgan_hip.dp.RankBatches: equal step counts), rank 0 writes `module.`-prefixed checkpoints that demo.py's loader accepts."""
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "fd-gan_amd")]
+    from datasets.pix2pix import write_pair
+    data = str(tmp_path / "data")
+    rng = np.random.default_rng(3)
+    for i in range(7):
+        gt = rng.random((64, 64, 3), dtype=np.float32)
+        write_pair(data, i, np.clip(gt * 0.6 + 0.3, 0, 1), gt)
+    base = [os.path.join(root, "fd-gan_amd", "train.py"), "--dataroot", data, "--batchSize", "2", "--imageSize", "64", "--originalSize", "64",
+            "--niter", "2", "--display", "1", "--workers", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run([sys.executable] + base + ["--exp", str(tmp_path / "ck1")], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    assert one.stdout.count(" ms/step") == 8, one.stdout[-2000:]                  # 2 epochs x ceil(7 / 2) steps, ragged last batch included
+    assert os.path.exists(str(tmp_path / "ck1" / "netG_epoch_1.pth"))
+    env2 = dict(env, FDGAN_DP_BACKEND="gloo", FDGAN_DP_SHARED_GPU="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port())] + base + ["--exp", str(tmp_path / "ck2")], env=env2, capture_output=True, text=True,
+                         timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    assert two.stdout.count(" ms/step") == 2, two.stdout[-2000:]                  # rank 0 prints: 2 epochs x (7 // (2 ranks x 2)) = 1 step each
+    import torch
+    sd = torch.load(str(tmp_path / "ck2" / "netG_epoch_1.pth"), map_location="cpu")
+    assert all(k.startswith("module.") for k in sd) and len(sd) == 786
