@@ -14,6 +14,14 @@
 //   * row phase as in the MK kernels (accumulator tile transposed through a wave-private LDS area, whole 16-byte pieces
 //     of pixel rows in and out) with the xb / G rows of the NEXT output row already requested (two register sets);
 //     a lane owns the same 8 channels for the whole kernel: coefficients and BatchNorm sums in registers.
+// (Round 4, measured and taken out again: the pending affine term of dy -- dy += B * y + C on the conv's own 32 output channels, 43
+// fdgan_affine_accumulate launches per generator walk at 2.2 TB/s, a 64-byte slice of a 0.5-2 KB pixel pitch (tools/pitch_probe.py:
+// the rate does not depend on the pitch, so it is not HBM channel camping) -- folded into the second-generation kernel's dy staging,
+// the finished dy also stored dense for the weight gradient.  One more load, four coefficient reads, a stochastically rounded
+// repack and a store per staged piece cost 16 spilled registers in front of the row prefetch: 209.6 us against 134.2 + 55.3 at
+// 256x256, 54.9 against 37.5 + 19.8 at 128x128, 22.3 against 17.0 + 9.7 at 64x64; the step with one stream was unchanged (28.03 /
+// 28.05 ms) and with the weight-gradient stream 0.9 ms LONGER, because the growth conv's weight gradient then starts behind this
+// kernel instead of beside it.  Results were bitwise those of the separate pass by construction -- the parity test was not the issue.)
 // Reference: autograd of conv2 / norm2 / relu2 of torchvision's _DenseLayer as used by
 // /root/reference/models/dehaze1113.py:713-724.
 #include <stdlib.h>
@@ -255,8 +263,8 @@ __global__ __launch_bounds__(512) void conv3x3_bwd2_kernel(Bwd3Args a) {
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
   typedef __attribute__((ext_vector_type(4))) float f4_t;
-  // ---- filter fragments of this wave's two 16-channel tiles, once: filter rows 0 and 1 stay in registers (48), row 2 in
-  // a wave-private LDS area (all 18 in registers did not fit beside the row phase: scratch reloads drained the prefetch)
+  // ---- filter fragments of this wave's two 16-channel tiles, once: filter row 0 stays in registers (24), rows 1 and 2 in
+  // a wave-private LDS area (B4_WF)
   bf16x8 A[3][2];
   char* wf = b3_lds + 4 * B4_DROW + 8 * B4_TB + wave * B4_WF + lane * 16;
 #pragma unroll

@@ -30,6 +30,7 @@ E.conv_bwd_weight_job = timed_job
 os.environ["FDGAN_NO_WGRAD_STREAM"] = "1"      # events of a launch on the walk's own stream
 import fdgan_hip.backward as BW
 BW.E = E
+BW.FORCE_EAGER = True                          # a recorded walk replays launches; the timed wrappers above need the eager walk
 
 B, S = 16, 256
 ts = T.TrainStep(device="cuda:0") if "device" in T.TrainStep.__init__.__code__.co_varnames else T.TrainStep()
