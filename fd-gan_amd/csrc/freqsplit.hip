@@ -29,6 +29,8 @@ struct FsArgs {
   float mean[3], istd[3];
   int tiles_x, tiles_y;
   int mode;         // 0 blur, 1 laplacian, 2 fused NHWC
+  long long y_sn;   // row-streaming form only: elements between the output planes of consecutive images (0: C * H * W, planes packed)
+  float* y_copy;    // row-streaming Laplacian only: also receives the INPUT planes, laid out like y (or NULL)
 };
 
 __device__ __forceinline__ int reflect(int i, int n) {   // nn.ReflectionPad2d: -i -> i, n-1+i -> n-1-i
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
 // registers, and the last 15 (3) such rows live in a REGISTER ring -- the loop is unrolled by the ring length so ring
 // positions are compile-time -- from which the vertical pass produces one output row per input row.  Column halo: 16 of 272
 // pixels (6 %); row halo per segment: 14 rows.  Rows are requested FS_PF ahead so a wave has several loads in flight.
-constexpr int FSR_W = 256, FSR_PF = 3;
+constexpr int FSR_W = 256;
 
 
 struct FsRowArgs {
@@ -123,6 +125,8 @@ struct FsRowArgs {
   int strips, segs, seg_rows;
   float g[15];
   float mean[3], istd[3];
+  long long y_sn;   // elements between the output planes of consecutive images
+  float* y_copy;    // Laplacian: the input planes again, laid out like y (fdgan_fusion_input_nchw), or NULL
 };
 
 template <int R, bool REFLECT>   // R = 7: Blur (reflection padding); R = 1: Laplacian box part (zero padding)
@@ -145,6 +149,9 @@ __device__ __forceinline__ float fs_lane(float v, int k) {             // the va
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
 }
 
+#ifndef FSR_PF_BLUR
+#define FSR_PF_BLUR 3
+#endif
 template <int R, bool DPP>
 __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
   constexpr bool BLUR = R == 7;
@@ -157,34 +164,54 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
   const int seg = item % a.segs, plane = item / a.segs;
   const int x0 = strip * FSR_W, r_begin = seg * a.seg_rows, r_end = min(a.H, r_begin + a.seg_rows);
   const float* xp = a.x + (long long)plane * a.H * a.W;
-  float* yp = a.y + (long long)plane * a.H * a.W;
   const int ch = plane % a.C;
+  const long long yoff = (long long)(plane / a.C) * a.y_sn + (long long)ch * a.H * a.W;
+  float* yp = a.y + yoff;
   const int cx = x0 + 4 * lane;                       // this lane's four columns
   // edge lanes also fetch one 4-pixel piece of the halo: lanes 0, 1 left (x0 - 8, x0 - 4), lanes 2, 3 right (x0 + 256, + 260)
   const int hx = lane < 2 ? x0 - 8 + 4 * lane : x0 + FSR_W + 4 * (lane - 2);
   const int hslot = lane < 2 ? 4 * lane : 8 + FSR_W + 4 * (lane - 2);
   typedef __attribute__((ext_vector_type(4))) float f4;
 
+  // Where a lane's pieces come from, worked out ONCE: W is a multiple of 4 and so is every piece's first column, so a piece lies
+  // entirely inside the image or entirely outside.  Outside, Blur reads the reflection -- columns c .. c + 3 are 2 (W - 1) - c down
+  // to 2 (W - 1) - c - 3, i.e. the piece that starts at 2 W - 5 - c (left: at -c - 3) in reversed order -- and the Laplacian zeros.
+  // Every fetch is then the same two unconditional 16-byte loads: with the edge cases as branches (the first version), hipcc waited
+  // for each load at the join right behind it (s_waitcnt vmcnt(0)) and the rows requested ahead were never in flight --
+  // 1.4 us per row, the whole memory latency.
+  auto piece_src = [&](int c, int& col, bool& rev, bool& zero) __attribute__((always_inline)) {
+    const bool out = c < 0 || c >= a.W;
+    rev = BLUR && out;
+    zero = !BLUR && out;
+    col = !out ? c : (c < 0 ? -c - 3 : 2 * a.W - 5 - c);
+    col = min(max(col, 0), a.W - 4);        // pieces further out than the window reaches: any readable address
+  };
+  int vcol, hcol;
+  bool vrev, vzero, hrev, hzero;
+  piece_src(cx, vcol, vrev, vzero);
+  piece_src(lane < 4 ? hx : cx, hcol, hrev, hzero);      // lanes 4 .. 63 fetch their own piece twice (a cache hit) instead of branching
   auto fetch = [&](int iy, f4& v, f4& hv) __attribute__((always_inline)) {   // input row iy (may lie outside the image)
-    const bool rin = iy >= 0 && iy < a.H;
-    if (BLUR || rin) {
-      const int ry = BLUR ? reflect(iy, a.H) : iy;
-      if (cx + 3 < a.W) v = *reinterpret_cast<const f4*>(xp + (long long)ry * a.W + cx);
-      else
-        for (int e = 0; e < 4; ++e) v[e] = fsr_at<R, BLUR>(xp, iy, cx + e, a.H, a.W);
-      if (lane < 4) {
-        if (hx >= 0 && hx + 3 < a.W) hv = *reinterpret_cast<const f4*>(xp + (long long)ry * a.W + hx);
-        else
-          for (int e = 0; e < 4; ++e) hv[e] = fsr_at<R, BLUR>(xp, iy, hx + e, a.H, a.W);
-      }
-    } else {
-      v = f4{0.f, 0.f, 0.f, 0.f};
-      hv = f4{0.f, 0.f, 0.f, 0.f};
+    const int ry = BLUR ? reflect(iy, a.H) : min(max(iy, 0), a.H - 1);
+    const float* row = xp + (long long)ry * a.W;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // a reflected piece starts at a column = 3 mod 4
+    v = *reinterpret_cast<const f4u*>(row + vcol), hv = *reinterpret_cast<const f4u*>(row + hcol);
+  };
+  // ... and what is done to the pieces when they are USED (rows later: touching them in fetch() would wait for the load there)
+  auto finish = [&](int iy, f4& v, f4& hv) __attribute__((always_inline)) {
+    const f4 t = v, u = hv;
+    v = vrev ? f4{t[3], t[2], t[1], t[0]} : t;
+    hv = hrev ? f4{u[3], u[2], u[1], u[0]} : u;
+    if (!BLUR) {
+      const bool rin = iy >= 0 && iy < a.H;
+      const bool vz = vzero || !rin, hz = hzero || !rin;
+      v = vz ? f4{0.f, 0.f, 0.f, 0.f} : v;
+      hv = hz ? f4{0.f, 0.f, 0.f, 0.f} : hv;
     }
   };
 
   f4 ring[NTAP];       // horizontally filtered rows; ring[k % NTAP] = row (first + k)
   f4 ctr[3];           // Laplacian: the raw centre pixels of the last 3 rows
+  constexpr int FSR_PF = BLUR ? FSR_PF_BLUR : 3;      // rows requested ahead
   f4 pv[FSR_PF], ph[FSR_PF];
   const int first = r_begin - R, last = r_end + R;     // input rows [first, last)
 #pragma unroll
@@ -195,7 +222,8 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
     for (int j = 0; j < NTAP; ++j) {                   // unrolled: ring / prefetch positions are constants (15 bodies: fits the I-cache; 45 did not)
       const int k = k0 + j, iy = first + k;
       if (iy >= last) continue;          // (a `break` here kept the loop rolled: the ring went to scratch memory)
-      const f4 v = pv[j % FSR_PF], hv = ph[j % FSR_PF];
+      f4 v = pv[j % FSR_PF], hv = ph[j % FSR_PF];
+      finish(iy, v, hv);
       fetch(iy + FSR_PF, pv[j % FSR_PF], ph[j % FSR_PF]);     // FSR_PF rows ahead (rows past `last` are harmless reads inside the plane / zeros)
       float win[20];                                    // columns cx - 8 .. cx + 11
       if (DPP) {
@@ -222,23 +250,62 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       f4 hsum;
+      if constexpr (BLUR) {
+        // Packed fp32 math wants its two operands in one aligned register pair, and output e reads win[e + 1 + t] -- for a fixed pair
+        // of outputs every other tap is misaligned (the first version paid one register move per v_pk_fma_f32 for that).  So the
+        // taps are split by parity over OVERLAPPING output pairs: (out0, out1) and (out2, out3) take the odd taps, (out-1, out0),
+        // (out1, out2), (out3, out4) the even ones -- every operand is an aligned pair of the window as it was read, 38 packed
+        // FMAs and 4 adds per row instead of 60 + 60 moves.
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        f2 P[10];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s_ = 0.f;
+        for (int q = 0; q < 10; ++q) P[q] = f2{win[2 * q], win[2 * q + 1]};
+        f2 qa = {0.f, 0.f}, qb = qa, qc = qa, qd = qa, qz = qa;
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) s_ = BLUR ? fmaf(a.g[t], win[8 + e + t - R], s_) : s_ + win[8 + e + t - R];
-        hsum[e] = s_;
+        for (int t = 0; t < NTAP; ++t) {
+          const f2 g2 = {a.g[t], a.g[t]};
+          if (t & 1) {
+            qa = __builtin_elementwise_fma(g2, P[(1 + t) / 2], qa);
+            qc = __builtin_elementwise_fma(g2, P[(3 + t) / 2], qc);
+          } else {
+            qz = __builtin_elementwise_fma(g2, P[t / 2], qz);
+            qb = __builtin_elementwise_fma(g2, P[(2 + t) / 2], qb);
+            qd = __builtin_elementwise_fma(g2, P[(4 + t) / 2], qd);
+          }
+        }
+        hsum = f4{qa[0] + qz[1], qa[1] + qb[0], qb[1] + qc[0], qc[1] + qd[0]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) s_ += win[8 + e + t - R];
+          hsum[e] = s_;
+        }
       }
       ring[j % NTAP] = hsum;
       if (!BLUR) ctr[j % 3] = v;
       const int oy = iy - R;                            // the output row this input row completes
       if (k >= 2 * R && oy >= r_begin && oy < r_end) {
         f4 o = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BLUR) {
+          typedef __attribute__((ext_vector_type(2))) float f2;
+          f2 o01 = {0.f, 0.f}, o23 = o01;
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) {                // rows oy - R .. oy + R = ring positions j - 2R + t
-          const f4 hr = ring[(j + 2 * NTAP - 2 * R + t) % NTAP];
+          for (int t = 0; t < NTAP; ++t) {              // rows oy - R .. oy + R = ring positions j - 2R + t
+            const f4 hr = ring[(j + 2 * NTAP - 2 * R + t) % NTAP];
+            const f2 g2 = {a.g[t], a.g[t]};
+            o01 = __builtin_elementwise_fma(g2, f2{hr[0], hr[1]}, o01);
+            o23 = __builtin_elementwise_fma(g2, f2{hr[2], hr[3]}, o23);
+          }
+          o = f4{o01[0], o01[1], o23[0], o23[1]};
+        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = BLUR ? fmaf(a.g[t], hr[e], o[e]) : o[e] + hr[e];
+          for (int t = 0; t < NTAP; ++t) {
+            const f4 hr = ring[(j + 2 * NTAP - 2 * R + t) % NTAP];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += hr[e];
+          }
         }
         if (BLUR) {
           if (a.norm)
@@ -248,6 +315,7 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
           const f4 c = ctr[(j + 3 * NTAP - 1) % 3];   // centre row = the previous input row
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] -= 9.f * c[e];
+          if (a.y_copy != nullptr && cx < a.W) *reinterpret_cast<f4*>(a.y_copy + yoff + (long long)oy * a.W + cx) = c;
         }
         if (cx + 3 < a.W) *reinterpret_cast<f4*>(yp + (long long)oy * a.W + cx) = o;
         else
@@ -323,11 +391,12 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
   // row-streaming form (one wave per strip segment).  Measured, B=4 @1024^2 / B=16 @256^2: Laplacian 23.8 / 9.2 us against
   // 52.9 / 15.9 us for the tile kernel (4.2 TB/s); Blur 40.5 / 21.6 us against 55.8 / 18.0 us -- its 14 halo rows per
   // 16-row segment cost more than the tile kernel's halo once the planes are small, so small planes stay on the tiles
-  const bool rows_pay = a.mode == 1 || planes * (long long)a.H * a.W >= (6ll << 20);
-  if (a.mode != 2 && rows_pay && a.W % 4 == 0 && a.H >= 16 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 &&
+  const bool rows_pay = a.mode == 1 || a.y_sn != 0 || planes * (long long)a.H * a.W >= (6ll << 20);
+  if (a.mode != 2 && rows_pay && a.W % 4 == 0 && a.W >= 16 && a.H >= 16 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 &&
       FD_TUNE_GETENV("FDGAN_DEBUG_NO_FS_ROWS") == nullptr) {
     FsRowArgs r{};
     r.x = a.x, r.y = a.y, r.H = a.H, r.W = a.W, r.C = a.C, r.norm = a.norm;
+    r.y_sn = a.y_sn ? a.y_sn : (long long)a.C * a.H * a.W, r.y_copy = a.y_copy;
     for (int i = 0; i < 15; ++i) r.g[i] = a.g[i];
     for (int i = 0; i < 3; ++i) r.mean[i] = a.mean[i], r.istd[i] = a.istd[i];
     r.strips = (a.W + FSR_W - 1) / FSR_W;
@@ -342,9 +411,10 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
     const unsigned grid = (unsigned)(planes * r.strips * r.segs);
     // Lane crossing: measured both ways (tools/freqsplit_bench.py, B=4 @1024^2 / B=16 @256^2, round 3).  Laplacian (3 taps: the
     // crossing IS the kernel): DPP wave shifts 21.6 / 8.4 us (4.66 / 3.0 TB/s) against 24.2 / 10.7 us through the LDS line.
-    // Blur (15 taps): 45.9 us with DPP against 41.9 us -- its row costs 160 vector instructions either way (60 v_pk_fma_f32 and
-    // as many register moves pairing the sliding window for them), it is ALU-bound at 3 waves per SIMD, and the 32 extra
-    // v_mov_dpp / v_readlane per row cost more than the five ds_read_b128 whose latency the other waves hide.
+    // Blur (15 taps): 45.9 us with DPP against 41.9 us (round 3).  Round 4: the row fetch without branches (the loads requested
+    // ahead really are in flight now) and the horizontal pass on aligned register pairs (106 vector instructions per row, 68 of
+    // them v_pk_fma_f32): 40.6 -> 27.1 us at 4 x 3 x 1024^2 = 3.7 TB/s; 3 or 5 rows ahead is the same, 15 is slower (37 us), longer
+    // row segments are slower (32 rows: 29.4 us, 64: 37.1 us -- fewer waves), shorter ones too (8: 29.0 us -- more halo rows).
     static const char* dpp_env = FD_TUNE_GETENV("FDGAN_DEBUG_FS_DPP");   // tuning aid: '0' the LDS line, '1' DPP wave shifts
     const bool dpp = dpp_env ? dpp_env[0] == '1' : a.mode == 1;
     if (a.mode == 0) return dpp ? fd_launch(&freqsplit_rows_kernel<7, true>, name, dim3(grid), dim3(64), 0, r, stream)
@@ -352,6 +422,7 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
     return dpp ? fd_launch(&freqsplit_rows_kernel<1, true>, name, dim3(grid), dim3(64), 0, r, stream)
                : fd_launch(&freqsplit_rows_kernel<1, false>, name, dim3(grid), dim3(64), 0, r, stream);
   }
+  if (a.y_sn != 0 || a.y_copy != nullptr) FD_FAIL(FD_EUNSUPPORTED, "%s: image-strided output needs the row-streaming form (W %% 4 == 0, W, H >= 16, 16-byte aligned planes)", name);
   return fd_launch(&freqsplit_kernel, name, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)planes), dim3(256), 0, a,
                    stream);
 }
@@ -390,6 +461,24 @@ extern "C" int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t
  * padding -- so dx = Laplacian(dy).  A separate entry point because SURVEY 8(b) names one and a binding reads better with it. */
 extern "C" int fdgan_laplacian3_bwd(const float* dy, float* dx, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream) {
   return fdgan_laplacian3_fwd(dy, dx, n, c, h, w, stream);
+}
+
+/* cat([img, Blur(img), Laplacian(img)], 1) as NCHW fp32 planes in ONE buffer (include/fdgan_hip.h). */
+extern "C" int fdgan_fusion_input_nchw(const float* img, float* out, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
+                                       FdStream stream) {
+  FD_REQUIRE(img && out, "fusion_input_nchw: NULL pointer");
+  FD_REQUIRE(!use_input_norm || c == 3, "fusion_input_nchw: use_input_norm needs 3 channels (ImageNet mean/std)");
+  FD_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "fusion_input_nchw: empty tensor");
+  if (!(w % 4 == 0 && w >= 16 && h >= 16 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0 && (h * w) % 4 == 0))
+    FD_FAIL(FD_EUNSUPPORTED, "fusion_input_nchw: needs W %% 4 == 0, W, H >= 16 and 16-byte aligned tensors (use the two filters and a concatenation)");
+  const long long plane = (long long)h * w;
+  FsArgs a{};
+  a.x = img, a.H = (int)h, a.W = (int)w, a.C = (int)c;
+  a.y_sn = 3 * c * plane;
+  a.y = out + c * plane, a.norm = use_input_norm ? 1 : 0, a.mode = 0;
+  if (int rc = launch(a, n * c, static_cast<hipStream_t>(stream), "fusion_blur15")) return rc;
+  a.y = out + 2 * c * plane, a.norm = 0, a.mode = 1, a.y_copy = out;      // the image itself: channels 0 .. c - 1, same image stride
+  return launch(a, n * c, static_cast<hipStream_t>(stream), "fusion_laplacian3_copy");
 }
 
 extern "C" int fdgan_fusion_input_nhwc(const float* img, int64_t n, int64_t c, int64_t h, int64_t w,

@@ -270,6 +270,18 @@ def laplacian3_bwd(dy):
     return dx
 
 
+def fusion_input_nchw(img, use_input_norm=True):
+    """cat([img, Blur(img), Laplacian(img)], 1) for a contiguous NCHW fp32 tensor, the three parts written in place by the two
+    filter launches (include/fdgan_hip.h); None when the shape is outside the row-streaming kernels (nothing launched)."""
+    n, c, h, w = img.shape
+    out = torch.empty((n, 3 * c, h, w), dtype=torch.float32, device=img.device)
+    rc = L.load().fdgan_fusion_input_nchw(img.data_ptr(), out.data_ptr(), n, c, h, w, int(bool(use_input_norm)), stream_ptr())
+    if rc == L.FD_EUNSUPPORTED:
+        return None
+    L.check(rc, "fusion_input_nchw")
+    return out
+
+
 def fusion_input_nhwc(img, view, use_input_norm=True):
     """img: NCHW fp32 (n,c,h,w) -> channels [img | LF | HF] of the NHWC fp16 view (D's input)."""
     n, c, h, w = img.shape

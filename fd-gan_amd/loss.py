@@ -199,4 +199,8 @@ def fusion_input(img, use_input_norm=True):
         E.require_gpu(img, "fusion_input")
         return torch.cat([img.float(), _BlurFn.apply(img, use_input_norm), _LaplacianFn.apply(img)], 1)
     x = _gpu_f32(img, "fusion_input")
+    if not use_input_norm or x.shape[1] == 3:
+        out = E.fusion_input_nchw(x, use_input_norm)      # the filters write into the concatenation; the Laplacian pass copies img
+        if out is not None:
+            return out
     return torch.cat([x, E.blur15(x, use_input_norm), E.laplacian3(x)], 1)

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 12
+#define FDGAN_ABI_VERSION 13
 
 enum FdStatus {
   FD_OK = 0,
@@ -546,6 +546,14 @@ int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTenso
 int fdgan_blur15_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
                      FdStream stream);
 int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
+/* What the Fusion-discriminator is fed (train.py's fusion_input; /root/reference/facades/network.png, the frequency split of
+ * /root/reference/__pycache__/loss.cpython-36.pyc): out[n] = cat([img[n], Blur(img)[n], Laplacian(img)[n]]) as NCHW fp32,
+ * (n, 3 c, h, w) in ONE buffer -- the two filters write their planes where the concatenation wants them and the Laplacian
+ * pass, which holds every input row in registers anyway, stores the image planes too: 1 read + 3 writes of the image instead
+ * of the filters' 2 reads + 2 writes followed by a 3-plane copy.  Needs W % 4 == 0, W and H >= 16 and 16-byte aligned tensors:
+ * FD_EUNSUPPORTED otherwise (nothing launched; use the two filters and a concatenation). */
+int fdgan_fusion_input_nchw(const float* img, float* out, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
+                            FdStream stream);
 /* Backward of the two filters (they feed D, whose gradient reaches the generator through them): the Laplacian
  * is self-adjoint (symmetric kernel, zero padding): call fdgan_laplacian3_fwd on dy.  Blur's adjoint folds the
  * reflection halo back; `tmp` is n*c*h*w floats of caller-owned scratch. */

@@ -505,6 +505,24 @@ def test_frequency_split_1024():
     got = fused[..., :9].float().cpu().permute(0, 3, 1, 2)
     assert rel_rms(got, cat) < 4e-3 and (got - cat).abs().max() < 2e-2 * float(cat.abs().max())     # bf16 storage
     assert float(fused[..., 9:].abs().max()) == 0.0
+    # train.py's fusion_input: the two filters write straight into the concatenation and the Laplacian pass stores the image
+    # planes (fdgan_fusion_input_nchw) -- the same kernels, so bitwise the concatenation of the separate calls; also for a ragged
+    # batch / channel count and a width that is not a multiple of the 256-column strip, and the fallback for a width it cannot take
+    with torch.no_grad():
+        one = hl.fusion_input(xd)
+        assert one.shape == (4, 9, 1024, 1024) and torch.equal(one, torch.cat([xd, E.blur15(xd, True), E.laplacian3(xd)], 1))
+        assert (one[:, 3:6].cpu() - lf).abs().max() < 2e-6      # (the Blur module passes its sigma through a float: taps differ in the last bit)
+        assert E.fusion_input_nchw(xd) is not None
+        for shape, norm in (((3, 3, 40, 72), True), ((2, 5, 64, 300), False), ((1, 3, 37, 50), True)):
+            xs = det_input(shape, seed=7, lo=0.0, hi=1.0).to(DEV)
+            sep = torch.cat([xs, E.blur15(xs, norm), E.laplacian3(xs)], 1)
+            got = hl.fusion_input(xs, norm)      # (small planes: the separate Blur call takes the tile kernel -- another summation order)
+            c = shape[1]
+            assert torch.equal(got[:, :c], xs) and torch.equal(got[:, 2 * c:], sep[:, 2 * c:]) and (got - sep).abs().max() < 2e-5, shape
+            assert (E.fusion_input_nchw(xs, norm) is None) == (shape[3] % 4 != 0), shape
+            assert (sep[:, 2 * shape[1]:].cpu() - fr.laplacian(xs.cpu())).abs().max() < 2e-5
+            if norm:
+                assert (sep[:, shape[1]:2 * shape[1]].cpu() - fr.blur(xs.cpu())).abs().max() < 2e-5
 
 
 def test_fdgan_backward_all_parameters_vs_reference_golden(nets, golden_dir):
