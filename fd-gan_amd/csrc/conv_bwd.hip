@@ -64,25 +64,6 @@ struct WgradArgs {
   int dbg_skip;               // FDGAN_DEBUG_PHASES (results wrong): 1 no global loads, 2 no LDS stores, 4 no fragment reads / MFMAs
 };
 
-__device__ __forceinline__ u32x4 wg_load_x(const WgradArgs& a, const float* sc_s, const float* sh_s, long long n, int oy, int ox,
-                                          int ky, int kx, int ci_off, bool x_ok, bool& raw) {
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  raw = false;
-  const int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-  if (!x_ok) return zero4;
-  if (a.pool) {   // 1x1 conv on the 2x2 average of the activated input (transition / skip pooling)
-    const unsigned short* src = a.x + n * a.x_sn + (long long)(2 * iy) * a.x_sh + (long long)(2 * ix) * a.x_sw + ci_off;
-    f32x8 f = fd_affine_act(*reinterpret_cast<const u32x4*>(src), sc_s, sh_s, a.p_slope);
-    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sw), sc_s, sh_s, a.p_slope);
-    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh), sc_s, sh_s, a.p_slope);
-    f += fd_affine_act(*reinterpret_cast<const u32x4*>(src + a.x_sh + a.x_sw), sc_s, sh_s, a.p_slope);
-    return fd_pack8<FmtG>(f * 0.25f);   // fp16 in, the bf16 operand out
-  }
-  if (iy < 0 || iy >= a.Hs || ix < 0 || ix >= a.Ws) return zero4;   // zero padding of the activated input
-  raw = true;   // fp16 -> (prologue) -> bf16 by the caller just before the LDS store (keeps the load in flight over the MFMAs)
-  return *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)iy * a.x_sh + (long long)ix * a.x_sw + ci_off);
-}
-
 // 4 k-entries x 8 channels (one u32x4 per entry) -> 8 x (4 entries of one channel), written to rows ch0 .. ch0+7.
 // The 16-byte column of a row is XORed with the row's chunk index ((row >> 3) & 7): adjacent lanes hold adjacent
 // chunks (rows 8 apart = 32 banks apart at this pitch), and the swizzle spreads them over the banks.
@@ -100,7 +81,12 @@ __device__ __forceinline__ void wg_store_transposed(char* tile, int ch0, int px4
 
 // T = 64: workgroup tile 64 cout x 64 cin (wave 32 x 32); T = 128: 128 x 128 (wave 64 x 64, 4x the MFMA work for
 // 2x the staging: the 1x1 bottleneck / transition shapes, whose dy would otherwise be re-staged by 16 cin tiles).
-template <int T, int NW>
+// POOL: a.pool != 0 (1x1 conv on the 2x2 average of the activated input: the transitions).
+// The loads of a step are UNCONDITIONAL (a unit outside the pixel range / the channels / the image reads the tensor's first bytes
+// and is zeroed when it is used) and nothing touches their results until the MFMAs of the previous step are issued: with the edge
+// cases as branches -- and, pooled, with the four taps averaged right where they were loaded -- every load was waited for at the
+// join behind it and the "software pipeline" below prefetched nothing (5 % MFMA busy on the pooled transitions, round 4).
+template <int T, int NW, bool POOL>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NTM = T / 32;             // MFMA tiles per wave along cout (2 waves along cout)
   constexpr int NTN = T / (NW / 2) / 16;  // ... along cin (NW / 2 waves along cin)
@@ -171,7 +157,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
   const long long p_begin = (long long)split * a.split_px;
   const long long p_end = p_begin + a.split_px < a.P ? p_begin + a.split_px : a.P;
   // software pipeline: the global loads of step s+1 are in flight while the MFMAs of step s run
-  u32x4 dv[UPT][4], xv[UPT][4];
+  constexpr int XT = POOL ? 4 : 1;      // loads per x unit
+  u32x4 dv[UPT][4], xv[UPT][4], xl[UPT][4][XT];
   // (image, row, column) of this thread's first pixel, advanced by 128 per step: the 64-bit divisions of the
   // first version (two per pixel and operand) cost more VALU time than the transposition itself
   int q_n, q_oy, q_ox;
@@ -180,23 +167,33 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
     const long long n = p / HW, r = p - n * HW;
     q_n = (int)n, q_oy = (int)(r / a.Wo), q_ox = (int)(r - (long long)q_oy * a.Wo);
   }
-  unsigned xraw = 0;   // bit (4 u + j): xv[u][j] still needs the prologue transform
+  unsigned xokm = 0, dokm = 0;   // bit (4 u + j): the unit holds data (else it is zero: padding, a channel or pixel past the end)
   auto load_step = [&](long long p0) __attribute__((always_inline)) {
-    xraw = 0;
+    xokm = dokm = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long p = p0 + 32 * j + px4;
+      const bool pin = p < p_end && !(a.dbg_skip & 1);
 #pragma unroll
       for (int u = 0; u < UPT; ++u) {
         const int chunk = chunk0 + CHUNK_STEP * u;
         const bool x_ok = ci0 / 8 + chunk < a.Cin8, dy_ok = co0 / 8 + chunk < a.Cout8;
-        dv[u][j] = zero4, xv[u][j] = zero4;
-        if (p < p_end && !(a.dbg_skip & 1)) {
-          if (dy_ok) dv[u][j] = *reinterpret_cast<const u32x4*>(a.dy + (long long)q_n * a.dy_sn + (long long)q_oy * a.dy_sh + (long long)q_ox * a.dy_sw + co0 + chunk * 8);
-          bool raw;
-          xv[u][j] = wg_load_x(a, sc_s + chunk * 8, sh_s + chunk * 8, q_n, q_oy, q_ox, ky, kx, ci0 + chunk * 8, x_ok, raw);
-          if (raw) xraw |= 1u << (u * 4 + j);
+        const bool dok = pin && dy_ok;
+        const long long doff = (long long)q_n * a.dy_sn + (long long)q_oy * a.dy_sh + (long long)q_ox * a.dy_sw + co0 + chunk * 8;
+        dv[u][j] = *reinterpret_cast<const u32x4*>(a.dy + (dok ? doff : 0));
+        const int iy = q_oy * a.stride + ky - a.pad, ix = q_ox * a.stride + kx - a.pad;
+        const bool xok = pin && x_ok && (POOL || (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws));
+        const long long xoff = (long long)q_n * a.x_sn + (long long)(POOL ? 2 * iy : iy) * a.x_sh + (long long)(POOL ? 2 * ix : ix) * a.x_sw + ci0 + chunk * 8;
+        const unsigned short* src = a.x + (xok ? xoff : 0);
+        xl[u][j][0] = *reinterpret_cast<const u32x4*>(src);
+        if constexpr (POOL) {
+          const int dxs = xok ? a.x_sw : 0, dys = xok ? a.x_sh : 0;
+          xl[u][j][1] = *reinterpret_cast<const u32x4*>(src + dxs);
+          xl[u][j][2] = *reinterpret_cast<const u32x4*>(src + dys);
+          xl[u][j][3] = *reinterpret_cast<const u32x4*>(src + dys + dxs);
         }
+        if (dok) dokm |= 1u << (u * 4 + j);
+        if (xok) xokm |= 1u << (u * 4 + j);
       }
       q_ox += 32;   // the position of pixel p + 32 (after j = 3: this thread's first pixel of the next step)
       while (q_ox >= a.Wo) {
@@ -205,8 +202,32 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   };
+  // what the loaded units become, when they are used: zeros where they hold nothing, the prologue (and the 2x2 average) on x
+  auto finish_step = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < UPT; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int chunk = chunk0 + CHUNK_STEP * u;
+        const bool dok = (dokm >> (u * 4 + j)) & 1, xok = (xokm >> (u * 4 + j)) & 1;
+        u32x4 d = dv[u][j], x;
+        if constexpr (POOL) {
+          f32x8 f = fd_affine_act(xl[u][j][0], sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);
+          f += fd_affine_act(xl[u][j][1], sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);
+          f += fd_affine_act(xl[u][j][2], sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);
+          f += fd_affine_act(xl[u][j][3], sc_s + chunk * 8, sh_s + chunk * 8, a.p_slope);
+          x = fd_pack8<FmtG>(f * 0.25f);   // fp16 in, the bf16 operand out
+        } else {
+          x = fd_xform8<FmtA, FmtG>(xl[u][j][0], sc_s + chunk * 8, sh_s + chunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = dok ? d[q] : 0u, x[q] = xok ? x[q] : 0u;
+        dv[u][j] = d, xv[u][j] = x;
+      }
+  };
   if (p_begin < p_end) load_step(p_begin);
   for (long long p0 = p_begin; p0 < p_end; p0 += WG_KPX) {
+    finish_step();
     if (want_bias)
 #pragma unroll
       for (int u = 0; u < UPT; ++u)
@@ -218,10 +239,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_kernel(WgradArgs a) {
     if (!(a.dbg_skip & 2))
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (xraw & (1u << (u * 4 + j)))
-          xv[u][j] = fd_xform8<FmtA, FmtG>(xv[u][j], sc_s + (chunk0 + CHUNK_STEP * u) * 8, sh_s + (chunk0 + CHUNK_STEP * u) * 8, a.pro_mode != 0 ? a.p_slope : 1.f);
       wg_store_transposed(At, (chunk0 + CHUNK_STEP * u) * 8, px4, xv[u]);
       wg_store_transposed(Dt, (chunk0 + CHUNK_STEP * u) * 8, px4, dv[u]);
     }
@@ -530,6 +547,10 @@ struct BnActBwdArgs {
   int dx_sh, dx_sw;
 };
 
+// POOL / DX: a.pool != 0 / a.dx != NULL as compile-time facts, and no branch around a load in the pixel loop -- a lane past the last
+// pixel reads its first pixel again and only its stores and sums are predicated.  (With `if (p < a.P) { loads }` hipcc waited for
+// every load at the join behind it: 428 us = 1 TB/s on the Fusion-discriminator's 16 x 127 x 127 x 288 BatchNorm input, round 4.)
+template <bool POOL, bool DX>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
   __shared__ float red[2][32][64];   // [which][pixel slot][channel within this thread column]: reduced below
   const int tid = threadIdx.x;
@@ -559,42 +580,42 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
       u32x4 dvv[4], xvv[4], gvv[4];
       unsigned short* dp[4];
       unsigned short* gp[4];
+      bool ok[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const long long p = p0 + k * stride;
-        dp[k] = nullptr;
-        if (p < a.P) {
-          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
-          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
-          dp[k] = a.da + n * a.da_sn + (long long)(a.pool ? y >> 1 : y) * a.da_sh + (long long)(a.pool ? xx >> 1 : xx) * a.da_sw + c8 * 8;
-          dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
-          xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
-          if (a.dx != nullptr) {
-            gp[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
-            gvv[k] = *reinterpret_cast<const u32x4*>(gp[k]);
-          }
+        const long long pk = p0 + k * stride;
+        ok[k] = pk < a.P;
+        const long long p = ok[k] ? pk : p0;
+        const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
+        const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
+        dp[k] = a.da + n * a.da_sn + (long long)(POOL ? y >> 1 : y) * a.da_sh + (long long)(POOL ? xx >> 1 : xx) * a.da_sw + c8 * 8;
+        dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
+        xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+        if constexpr (DX) {
+          gp[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+          gvv[k] = *reinterpret_cast<const u32x4*>(gp[k]);
         }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (dp[k] == nullptr) continue;
         const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dvv[k]), f32x8);
         const f32x8 xf = fd_cvt8<FmtA>(xvv[k]);     // the forward input: fp16
+        const float live = ok[k] ? 1.f : 0.f;
         f32x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float pre = fmaf(xf[e], sc[e], sh[e]);
           const float gsl = pre > 0.f ? 1.f : a.slope;   // slope 1: identity, 0: ReLU, 0.2: LeakyReLU
-          o[e] = d[e] * (a.pool ? 0.25f * gsl : gsl);
+          o[e] = d[e] * (POOL ? 0.25f * gsl : gsl) * live;
           s1[e] += o[e];
           s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
         }
-        if (!a.pool) *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
-        if (a.dx != nullptr) {
+        if (!POOL && ok[k]) *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+        if constexpr (DX) {
           f32x8 g = __builtin_convertvector(__builtin_bit_cast(bf16x8, gvv[k]), f32x8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = fmaf(sc[e], o[e], g[e]);
-          *reinterpret_cast<u32x4*>(gp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(g, bf16x8));
+          if (ok[k]) *reinterpret_cast<u32x4*>(gp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(g, bf16x8));
         }
       }
     }
@@ -732,6 +753,7 @@ struct BnApplyArgs {
 };
 // dx = A[c] * dpre + B[c] * x + C[c] with A = gamma*rstd, B = -gamma*rstd^2*dgamma/M, C = -A*dbeta/M - B*mean:
 // a thread keeps one 8-channel group (24 coefficients in registers) and walks pixels with a grid stride.
+template <bool POOL, bool ACCUM>      // (no branch around a load in the pixel loop: see bn_act_bwd_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
   const int grp = threadIdx.x & 7, slot = threadIdx.x >> 3;   // 8 channel groups x 32 pixels per workgroup pass
   const long long HW = (long long)a.H * a.W;
@@ -758,35 +780,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnApplyArgs a) {
     for (long long p0 = (long long)blockIdx.x * 32 + slot; p0 < a.P; p0 += 4 * stride) {
       u32x4 dv[4], xv[4], gv[4];
       unsigned short* op[4];
+      bool ok[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const long long p = p0 + k * stride;
-        op[k] = nullptr;
-        if (p < a.P) {
-          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
-          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
-          dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)(a.pool ? y >> 1 : y) * a.dp_sh +
-                                                  (long long)(a.pool ? xx >> 1 : xx) * a.dp_sw + c8 * 8);
-          xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
-          op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
-          if (a.accumulate) gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
-        }
+        const long long pk = p0 + k * stride;
+        ok[k] = pk < a.P;
+        const long long p = ok[k] ? pk : p0;
+        const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;      // 32-bit: a 64-bit division is ~100 VALU instructions,
+        const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);         // two of them per pixel were most of this kernel
+        dv[k] = *reinterpret_cast<const u32x4*>(a.dpre + n * a.dp_sn + (long long)(POOL ? y >> 1 : y) * a.dp_sh +
+                                                (long long)(POOL ? xx >> 1 : xx) * a.dp_sw + c8 * 8);
+        xv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
+        op[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
+        if constexpr (ACCUM) gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (op[k] == nullptr) continue;
         const f32x8 d = __builtin_convertvector(__builtin_bit_cast(bf16x8, dv[k]), f32x8);
         const f32x8 xf = fd_cvt8<FmtA>(xv[k]);      // the forward input: fp16
         f32x8 o;
-        if (a.accumulate) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
+        if constexpr (ACCUM) o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float de = d[e];
-          if (a.pool) de *= fmaf(A[e], xf[e], Sh[e]) > 0.f ? 0.25f : 0.25f * a.slope;
+          if constexpr (POOL) de *= fmaf(A[e], xf[e], Sh[e]) > 0.f ? 0.25f : 0.25f * a.slope;
           const float v = fmaf(A[e], de, fmaf(B[e], xf[e], Cc[e]));
-          o[e] = a.accumulate ? o[e] + v : v;
+          o[e] = ACCUM ? o[e] + v : v;
         }
-        *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
+        if (ok[k]) *reinterpret_cast<u32x4*>(op[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
       }
     }
   }
@@ -1128,7 +1149,18 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
   long long nsplit = 1;
   if (workspace != nullptr) {
     nsplit = (T == 128 ? 512 : 768) / base;
-    const long long max_by_px = (a.P + 2047) / 2048;
+    static const char* minpx_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_MINPX");   // tuning aid
+    const long long minpx = minpx_env ? atoll(minpx_env) : 2048;
+    long long max_by_px = (a.P + minpx - 1) / minpx;
+    // few pixels AND few tiles (the transitions at 32x32, the narrow 1x1s): 2048 pixels per split would leave most CUs without a
+    // workgroup -- 256 -> 128 pooled at 32x32 ran as 16 workgroups, 105 us.  Split down to 256 pixels then, up to one round of
+    // workgroups (T = 128: one per CU; T = 64: two): 105 -> 29 us, 64 -> 32 pooled 74 -> 58, 512 -> 64 40 -> 31, 96 -> 16 44 -> 35
+    const long long one_round = T == 128 ? 256 : 512;
+    if (!minpx_env && base * max_by_px < one_round) {
+      max_by_px = (a.P + 255) / 256;
+      const long long fill = one_round / base > 0 ? one_round / base : 1;
+      if (nsplit > fill) nsplit = fill;
+    }
     if (nsplit > max_by_px) nsplit = max_by_px;
     const long long per = numel + (dbias ? cout : 0);
     if (nsplit * per > workspace_floats) nsplit = workspace_floats / per;
@@ -1149,13 +1181,19 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
   const unsigned lds = 2u * T * WG_ROWB + 2u * T * 4 + (dbias ? 32u * T * 4 : 0u);
   static bool attr128 = false;
   if (T == 128 && !attr128) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 8>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 8, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_wgrad<128>): %s", hipGetErrorString(e));
     attr128 = true;
   }
-  int rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128, 8>, "conv_wgrad_t128", grid, dim3(512), lds, a, st)
-                    : fd_launch(&conv_wgrad_kernel<64, 4>, "conv_wgrad", grid, dim3(256), lds, a, st);
+  int rc;
+  if (a.pool) rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128, 8, true>, "conv_wgrad_t128_pool", grid, dim3(512), lds, a, st)
+                            : fd_launch(&conv_wgrad_kernel<64, 4, true>, "conv_wgrad_pool", grid, dim3(256), lds, a, st);
+  else rc = T == 128 ? fd_launch(&conv_wgrad_kernel<128, 8, false>, "conv_wgrad_t128", grid, dim3(512), lds, a, st)
+                     : fd_launch(&conv_wgrad_kernel<64, 4, false>, "conv_wgrad", grid, dim3(256), lds, a, st);
   if (rc != FD_OK || direct) return rc;
   WredArgs r{workspace, dw, numel, (int)nsplit, accumulate};
   rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, st);
@@ -1204,7 +1242,12 @@ extern "C" int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const
   if (a.partial) FD_REQUIRE(rows * a.cpad * 2 <= capacity_floats, "bn_act_bwd: workspace too small (%lld floats needed)", rows * a.cpad * 2);
   if (rows_out) *rows_out = rows;
   if (cpad_out) *cpad_out = a.cpad;
-  return fd_launch(&bn_act_bwd_kernel, "bn_act_bwd", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a, static_cast<hipStream_t>(stream));
+  const dim3 grid((unsigned)rows, (unsigned)chunks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.pool) return a.dx ? fd_launch(&bn_act_bwd_kernel<true, true>, "bn_act_bwd", grid, dim3(256), 0, a, st)
+                          : fd_launch(&bn_act_bwd_kernel<true, false>, "bn_act_bwd", grid, dim3(256), 0, a, st);
+  return a.dx ? fd_launch(&bn_act_bwd_kernel<false, true>, "bn_act_bwd", grid, dim3(256), 0, a, st)
+              : fd_launch(&bn_act_bwd_kernel<false, false>, "bn_act_bwd", grid, dim3(256), 0, a, st);
 }
 
 extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
@@ -1287,6 +1330,7 @@ struct AffineAccArgs {
   const float *bsum, *csum;
   int gpp, dense;   // channel groups per pixel in a workgroup pass (<= 8); both views pixel-dense
 };
+template <bool DENSE>
 __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
   // G channel groups x (256 / G) pixels per workgroup pass: a 32-channel slice (G = 4) keeps all 256 threads busy (the fixed
   // 8 x 32 split left half of them idle); pixel offsets are p * pitch on pixel-dense views (every concat buffer is), 32-bit
@@ -1296,45 +1340,50 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
   const int c8 = blockIdx.y * G + grp;
   if (slot >= ppp || c8 >= a.C8) return;
   const unsigned HWu = (unsigned)(a.H * a.W), Wu = (unsigned)a.W;
+  // No branch around a load anywhere below: out-of-range lanes read a clamped (valid) address and only their STORE is predicated.
+  // With `if (p < a.P) load` hipcc put s_waitcnt vmcnt(0) at every join, i.e. right behind each pair of loads -- of the eight
+  // 16-byte loads a thread issues per pass at most four were ever in flight (2.2 TB/s in the step; same finding as
+  // csrc/freqsplit.hip's row fetch, round 4).
   float B[8], Cc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int c = c8 * 8 + e;
-    B[e] = c < a.C ? a.bsum[c] : 0.f;
-    Cc[e] = c < a.C ? a.csum[c] : 0.f;
+    const int c = c8 * 8 + e, cc = min(c, a.C - 1);
+    const float b = a.bsum[cc], k = a.csum[cc];
+    B[e] = c < a.C ? b : 0.f;
+    Cc[e] = c < a.C ? k : 0.f;
   }
   const long long stride = (long long)gridDim.x * ppp;
   for (long long p0 = (long long)blockIdx.x * ppp + slot; p0 < a.P; p0 += 4 * stride) {
     u32x4 xv[4], gv[4];
     unsigned short* op[4];
+    bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const long long p = p0 + k * stride;
-      op[k] = nullptr;
-      if (p < a.P) {
-        long long xo, go;
-        if (a.dense) {
-          xo = p * a.x_sw, go = p * a.dx_sw;
-        } else {
-          const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;
-          const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);
-          xo = n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw;
-          go = n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw;
-        }
-        xv[k] = *reinterpret_cast<const u32x4*>(a.x + xo + c8 * 8);
-        op[k] = a.dx + go + c8 * 8;
-        gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
+      const long long pk = p0 + k * stride;
+      ok[k] = pk < a.P;
+      const long long p = ok[k] ? pk : p0;
+      long long xo, go;
+      if constexpr (DENSE) {
+        xo = p * a.x_sw, go = p * a.dx_sw;
+      } else {
+        const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;
+        const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);
+        xo = n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw;
+        go = n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw;
       }
+      xv[k] = *reinterpret_cast<const u32x4*>(a.x + xo + c8 * 8);
+      op[k] = a.dx + go + c8 * 8;
+      gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (op[k] == nullptr) continue;
       const f32x8 xf = fd_cvt8<FmtA>(xv[k]);      // the normalised tensor: a forward activation, fp16
       f32x8 o = __builtin_convertvector(__builtin_bit_cast(bf16x8, gv[k]), f32x8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += fmaf(B[e], xf[e], Cc[e]);
       // a small coherent term on top of a value already on the bf16 grid: stochastic rounding (csrc/common.h: fd_pk8_sr)
-      *reinterpret_cast<u32x4*>(op[k]) = fd_pk8_sr(o, (unsigned)((p0 + k * stride) * (long long)a.C8) + (unsigned)c8);
+      const u32x4 res = fd_pk8_sr(o, (unsigned)((p0 + k * stride) * (long long)a.C8) + (unsigned)c8);
+      if (ok[k]) *reinterpret_cast<u32x4*>(op[k]) = res;
     }
   }
 }
@@ -1368,7 +1417,10 @@ extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, con
   long long rows = (a.P + ppp - 1) / ppp, cap = 1024 / chunks;      // ~4 workgroups per CU in all
   if (cap < 16) cap = 16;
   if (rows > cap) rows = cap;
-  return fd_launch(&affine_acc_kernel, "affine_accumulate", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
+  if (a.dense)
+    return fd_launch(&affine_acc_kernel<true>, "affine_accumulate", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
+                     static_cast<hipStream_t>(stream));
+  return fd_launch(&affine_acc_kernel<false>, "affine_accumulate", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
                    static_cast<hipStream_t>(stream));
 }
 
@@ -1407,8 +1459,12 @@ extern "C" int fdgan_bn_bwd_apply(const FdTensor* dpre, const FdTensor* x, const
   long long cap = (cap_env ? atoll(cap_env) : 512) / chunks;
   if (cap < 16) cap = 16;
   if (rows > cap) rows = cap;
-  return fd_launch(&bn_bwd_apply_kernel, "bn_bwd_apply", dim3((unsigned)rows, (unsigned)chunks), dim3(256), 0, a,
-                   static_cast<hipStream_t>(stream));
+  const dim3 grid((unsigned)rows, (unsigned)chunks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.pool) return a.accumulate ? fd_launch(&bn_bwd_apply_kernel<true, true>, "bn_bwd_apply", grid, dim3(256), 0, a, st)
+                                  : fd_launch(&bn_bwd_apply_kernel<true, false>, "bn_bwd_apply", grid, dim3(256), 0, a, st);
+  return a.accumulate ? fd_launch(&bn_bwd_apply_kernel<false, true>, "bn_bwd_apply", grid, dim3(256), 0, a, st)
+                      : fd_launch(&bn_bwd_apply_kernel<false, false>, "bn_bwd_apply", grid, dim3(256), 0, a, st);
 }
 
 extern "C" int fdgan_conv2d_bwd_data_direct(const FdTensor* dy, const float* w, int cout, int cin, const FdConvDesc* d,

@@ -27,5 +27,5 @@ def run(P_hw, C, Ct, N=16):
     tp = t(lambda: E.bn_bwd_apply(dv.fd, xv.fd, pro, dg, db, gv.fd, True))
     print(f"hw {P_hw} C {C}/{Ct}: act_bwd {ta:7.1f} us {6*Pn*C/ta/1e6:6.2f} TB/s | apply {tp:7.1f} us {8*Pn*C/tp/1e6:6.2f} TB/s")
 
-for hw, C, Ct in [(256, 224, 256), (256, 128, 128), (128, 480, 512), (64, 992, 1024), (256, 64, 256)]:
+for hw, C, Ct in [(127, 288, 288), (128, 144, 144), (128, 72, 72), (256, 224, 256), (256, 128, 128), (128, 480, 512), (64, 992, 1024), (256, 64, 256)]:
     run(hw, C, Ct)
