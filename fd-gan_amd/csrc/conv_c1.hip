@@ -62,15 +62,20 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(C1FwdArgs a) {
   const unsigned short* xn = a.x + (long long)n * a.x_sn;
   constexpr int UNITS = NPIX * 4, UPT = (UNITS + 255) / 256;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 rin[UPT];
+  u32x4 rin[UPT], rwt;
+  const int wtap = tid < KS * KS * 4 ? tid >> 2 : 0;      // the chunk's weights: tap tid / 4, 8-channel group tid % 4 (threads past them: tap 0 again)
   auto load = [&](int chunk) {
+    rwt = *reinterpret_cast<const u32x4*>(a.w + ((long long)(chunk * KS * KS + wtap) * 512 + (tid & 3) * 16 * 8));   // fragment image: cout row 0 = lanes 0, 16, 32, 48
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + i * 256, p = u >> 2, kg = u & 3;           // the four 16-byte groups of a pixel are adjacent lanes: 64 B runs
       const int py = p / IW, px = p - py * IW;
       const int gy = oy0 - a.pad + py, gx = ox0 - a.pad + px;
       const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && chunk * 32 + kg * 8 < a.Cin;
-      rin[i] = ok ? *reinterpret_cast<const u32x4*>(xn + (long long)gy * a.x_sh + (long long)gx * a.x_sw + chunk * 32 + kg * 8) : zero4;
+      // unconditional load of a clamped address, zeroed afterwards: a load inside `ok ? load : zero` is a branch, and hipcc waits for
+      // every load at the join behind it (s_waitcnt vmcnt(0)) -- the units of a chunk were fetched one after the other
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xn + (ok ? (long long)gy * a.x_sh + (long long)gx * a.x_sw + chunk * 32 + kg * 8 : 0));
+      rin[i] = ok ? v : zero4;
     }
   };
   auto store = [&](char* buf, char* wbuf, int chunk) {
@@ -85,10 +90,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(C1FwdArgs a) {
       if (a.pro_mode != 0) v = fd_xform8(v, sc_lds + chunk * 32 + kg * 8, sh_lds + chunk * 32 + kg * 8, a.slope);
       lds_write16(buf + kg * PLANE + p * 16, ok ? v : zero4);          // zero padding applies to the ACTIVATED input
     }
-    if (tid < KS * KS * 4) {   // the chunk's weights: tap tid / 4, 8-channel group tid % 4 (fragment image: cout row 0 = lanes 0, 16, 32, 48)
-      const int tap = tid >> 2, kg = tid & 3;
-      lds_write16(wbuf + tid * 16, *reinterpret_cast<const u32x4*>(a.w + ((long long)(chunk * KS * KS + tap) * 512 + kg * 16 * 8)));
-    }
+    if (tid < KS * KS * 4) lds_write16(wbuf + tid * 16, rwt);
   };
   const int ly = tid / C1_TW, lx = tid % C1_TW;
   float acc4[4] = {0.f, 0.f, 0.f, 0.f};                    // four independent chains (v_dot2c accumulates in place)
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(C1FwdArgs a) {
   __syncthreads();
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     const bool more = chunk + 1 < a.nchunk;
-    if (more) load(chunk + 1);
+    load(more ? chunk + 1 : chunk);      // (unconditional: behind `if (more)` the loads were waited for at the join, before the taps)
     const char* ib = in_lds + (chunk & 1) * IN_B;
     const char* wb = w_lds + (chunk & 1) * W_B;
 #pragma unroll 1
@@ -154,7 +156,7 @@ struct C1BwdArgs {
 // against this kernel's 128.  The MFMA result layout leaves a wave instruction with 16 pixels x 64 bytes, half a cache line per
 // pixel, and that access pattern costs more than the arithmetic it saves; a version that transposes through LDS to whole rows is
 // what it would take.)
-template <int KS>
+template <int KS, bool ACC1>      // ACC1: a.acc == 1 (G += ...), its read of G requested with the mask operand, ahead of the taps
 __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
   // Third form (round 3).  Unit = one 8-channel piece of FOUR vertically adjacent pixels; units are numbered piece-fastest, then
   // pixel, so the 64 lanes of a wave instruction touch 1 KB of ONE contiguous run of the NHWC row (whole 128-byte lines -- the
@@ -165,14 +167,25 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
   float* wl = reinterpret_cast<float*>(c1_lds);            // [taps][2][C8][4] fp32, forward tap order
   constexpr int KK = KS * KS, R = 4;
   const int cp = a.C8 * 8;
-  for (int i = threadIdx.x; i < KK * cp; i += 256) {
-    const int t = i / cp, c = i - t * cp;
-    float v = 0.f;
-    if (c < a.C) {   // flipped image: Wf[cout' = c][cin' = 0][tap'] = W[0][c][KK - 1 - tap'];  fragment order, lane = c & 15 (cin' group 0), e = 0
+  // (four independent, unconditional loads per pass: as `if (c < C) v = load` in a rolled loop this was 18 dependent loads, each
+  // waited for, in front of every workgroup's ~4 units of work)
+  for (int i0 = threadIdx.x; i0 < KK * cp; i0 += 4 * 256) {
+    float v[4];
+    int dst[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + 256 * q, ic = i < KK * cp ? i : 0;
+      const int t = ic / cp, c = ic - t * cp;
+      const bool ok = i < KK * cp && c < a.C;
+      // flipped image: Wf[cout' = c][cin' = 0][tap'] = W[0][c][KK - 1 - tap'];  fragment order, lane = c & 15 (cin' group 0), e = 0
       const int tp = KK - 1 - t;
-      v = fd_cvt1<FmtG>(a.w[((long long)tp * a.ntile + (c >> 4)) * 512 + (c & 15) * 8]);
+      const float w = fd_cvt1<FmtG>(a.w[ok ? ((long long)tp * a.ntile + (c >> 4)) * 512 + (c & 15) * 8 : 0]);
+      v[q] = ok ? w : 0.f;
+      dst[q] = i < KK * cp ? ((t * 2 + ((c >> 2) & 1)) * a.C8 + (c >> 3)) * 4 + (c & 3) : -1;
     }
-    wl[((t * 2 + ((c >> 2) & 1)) * a.C8 + (c >> 3)) * 4 + (c & 3)] = v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (dst[q] >= 0) wl[dst[q]] = v[q];
   }
   __syncthreads();
   const unsigned units = (unsigned)a.total;                 // N * ceil(H / 4) * W * C8 (launcher: < 2^31)
@@ -186,9 +199,12 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
     const unsigned short* dn = a.dy + (long long)n * a.dy_sn;
     const long long xo = (long long)n * a.x_sn + (long long)y0 * a.x_sh + (long long)x * a.x_sw + c8 * 8;
     const long long go = (long long)n * a.g_sn + (long long)y0 * a.g_sh + (long long)x * a.g_sw + c8 * 8;
-    u32x4 xv[R];                                            // the mask operand, requested now and used after the taps
+    u32x4 xv[R], gv[R];                                     // the mask operand (and G), requested now and used after the taps
 #pragma unroll
-    for (int i = 0; i < R; ++i) xv[i] = *reinterpret_cast<const u32x4*>(a.x + xo + (long long)(y0 + i < a.H ? i : 0) * a.x_sh);
+    for (int i = 0; i < R; ++i) {
+      xv[i] = *reinterpret_cast<const u32x4*>(a.x + xo + (long long)(y0 + i < a.H ? i : 0) * a.x_sh);
+      if constexpr (ACC1) gv[i] = *reinterpret_cast<const u32x4*>(a.g + go + (long long)(y0 + i < a.H ? i : 0) * a.g_sh);
+    }
     f32x2 da[R][4];
 #pragma unroll
     for (int i = 0; i < R; ++i)
@@ -203,7 +219,9 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
 #pragma unroll
       for (int wr = 0; wr < R + KS - 1; ++wr) {
         const int oy = y0 + a.pad - (KS - 1) + wr;
-        dv[wr] = cok && oy >= 0 && oy < a.Ho ? fd_cvt1<FmtG>(dn[oy * a.dy_sh + ox * a.dy_sw]) : 0.f;
+        const bool ok = cok && oy >= 0 && oy < a.Ho;      // (clamped address, zeroed after: see conv_cout1_kernel's load; this one had 28
+        const float v = fd_cvt1<FmtG>(dn[ok ? oy * a.dy_sh + ox * a.dy_sw : 0]);      // dependent 2-byte loads per unit, each waited for)
+        dv[wr] = ok ? v : 0.f;
       }
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky) {
@@ -221,14 +239,13 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      if (y0 + i >= a.H) break;
       const f32x8 fx = fd_cvt8<FmtA>(xv[i]);
       unsigned short* gp = a.g + go + (long long)i * a.g_sh;
       f32x8 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.acc == 1) o = fd_cvt8<FmtG>(*reinterpret_cast<const u32x4*>(gp));
+      if constexpr (ACC1) o = fd_cvt8<FmtG>(gv[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += (c8 * 8 + e < a.C) ? da[i][e >> 1][e & 1] * (fx[e] > 0.f ? 1.f : a.slope) : 0.f;
-      *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
+      if (y0 + i < a.H) *reinterpret_cast<u32x4*>(gp) = fd_pk8<FmtG>(o);
     }
   }
 }
@@ -288,9 +305,13 @@ int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const F
   if (lds > 64 * 1024 || c.total >= (1ll << 31) || dy->n * dy->stride[0] >= (1ll << 31)) return 1;
   const long long nb = (c.total + 255) / 256;
   const dim3 grid((unsigned)(nb < 2048 ? nb : 2048));
+  const bool acc1 = accumulate == 1;
   switch (d->ksize) {
-    case 4: return fd_launch(&dgrad_cout1_kernel<4>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
-    case 3: return fd_launch(&dgrad_cout1_kernel<3>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
-    default: return fd_launch(&dgrad_cout1_kernel<2>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+    case 4: return acc1 ? fd_launch(&dgrad_cout1_kernel<4, true>, "dgrad_cout1", grid, dim3(256), lds, c, stream)
+                        : fd_launch(&dgrad_cout1_kernel<4, false>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+    case 3: return acc1 ? fd_launch(&dgrad_cout1_kernel<3, true>, "dgrad_cout1", grid, dim3(256), lds, c, stream)
+                        : fd_launch(&dgrad_cout1_kernel<3, false>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+    default: return acc1 ? fd_launch(&dgrad_cout1_kernel<2, true>, "dgrad_cout1", grid, dim3(256), lds, c, stream)
+                         : fd_launch(&dgrad_cout1_kernel<2, false>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
   }
 }
