@@ -716,6 +716,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
     // accumulate mode) the gradient buffer are read in that same shape -- whole coalesced rows, one latency for both --
     // and the lane keeps the 8 channels it owns for the whole tile: 16 coefficient registers, 16 running sums.
     // v = da * act'(bn(x));  sums (v, v * x) per channel;  store v, or y += gamma * rstd * v.
+    // (Round 4, measured and taken out again: the x / G loads of the row loop below sit inside `if (ok ...)` and are each waited
+    // for at the join behind them.  Issued unconditionally from clamped addresses -- with or without a second register set one
+    // accumulator row ahead -- the kernels need 12-16 more registers, lose a wave per SIMD and get SLOWER: D's 4x4 data gradient
+    // 587 -> 674 us, VGG16's 3x3 137 -> 149 us, the training step 27.4 -> 28.9 ms.  Occupancy, not this tail, is what they live on.)
     using R = RowStore<CT>;
     typedef f32x4 f4_t;
     float* msc = red + WM * WN * CT * 16 * 2;   // [BN] scale, [BN] shift of this workgroup's channels
