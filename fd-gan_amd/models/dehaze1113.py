@@ -377,6 +377,9 @@ class FDGAN(_PlannedModule):
         h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
         A = lambda hh, ww, cc: E.new_act(n, hh, ww, cc, dev)
         P.in8 = E.new_act(n, h, w, 8, dev, zero=True)
+        # (pixel pitches 512 / 1024 / 2048 B: powers of two.  affine_accumulate alone streams a 256-channel range 55 % faster at a pitch of
+        # 2112 B than at 2048 (tools/pitch_probe.py 128 256), so padded concat buffers were tried, round 4: +32 channels 27.9 ms per
+        # step against 26.9, +64 channels 27.2 -- the conv kernels' rows want whole aligned 128-byte lines more than the odd pitch helps)
         blk1, bott1, cat1 = A(h, w, 256), A(h, w, 128), A(h2, w2, 160)
         blk2, bott2 = A(h2, w2, 512), A(h2, w2, 128)
         blk3, bott3 = A(h4, w4, 1024), A(h4, w4, 128)
@@ -402,17 +405,17 @@ class FDGAN(_PlannedModule):
                bias=self.conv_refin2.bias, pro=E.make_prologue(pool=True))
         # x1 = trans_block1(dense_block1(x0))                                     (:767-769)
         _emit_dense_block(P, self.dense_block1, blk1, st1, bott1, cnt1, keep)
-        _emit_transition(P, self.trans_block1, E.View(blk1), st1, E.View(cat1, 32, 128), cnt1)
+        _emit_transition(P, self.trans_block1, E.View(blk1, 0, 256), st1, E.View(cat1, 32, 128), cnt1)
         # x10 = conv_refine4(cat[x01, x1])                                        (:773)
         P.conv(E.View(cat1), P.weight(self.conv_refine4.weight, 128, 160, 3), E.View(blk2, 0, 128), 3, pad=1,
                bias=self.conv_refine4.bias, stats=st2)
         # x2 = trans_block2(dense_block2(x10))                                    (:774)
         _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt2, keep)
-        _emit_transition(P, self.trans_block2, E.View(blk2), st2, E.View(blk3, 0, 256), cnt2, out_stats=st3)
+        _emit_transition(P, self.trans_block2, E.View(blk2, 0, 512), st2, E.View(blk3, 0, 256), cnt2, out_stats=st3)
         P.copy(E.View(blk3, 0, 256), E.View(blk5, 128, 256))                      # x2 half of x42 (:786)
         # x3 = trans_block3(dense_block3(x2))                                     (:778)
         _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt3, keep)
-        _emit_transition(P, self.trans_block3, E.View(blk3), st3, E.View(cat6, 0, 512), cnt3)
+        _emit_transition(P, self.trans_block3, E.View(blk3, 0, 1024), st3, E.View(cat6, 0, 512), cnt3)
         # x22 = conv_refin5(avg_pool2d(x2, 2))                                    (:780)
         P.conv(E.View(blk3, 0, 256), P.weight(self.conv_refin5.weight, 128, 256, 1), E.View(cat6, 512, 128), 1,
                bias=self.conv_refin5.bias, pro=E.make_prologue(pool=True))
@@ -612,7 +615,7 @@ class _DenseBase(_PlannedModule):
                stats=st3 if train else None, stats_also=((s5, 128),) if train else ())
         P.copy(E.View(blk3, 0, 256), E.View(b5, 128, 256))
         _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt16)
-        _emit_transition(P, self.trans_block3, E.View(blk3), st3, E.View(b4, 0, 512), cnt16, out_stats=s4 if train else None)
+        _emit_transition(P, self.trans_block3, E.View(blk3, 0, 1024), st3, E.View(b4, 0, 512), cnt16, out_stats=s4 if train else None)
         # ---- decoder
         self.dense_block4.emit(P, b4, s4, t4, cnt32)
         self.trans_block4.emit(P, b4, s4, cnt32, E.View(b5, 0, 128), out_stats=s5 if train else None)
