@@ -35,21 +35,21 @@ __global__ void pack_weight_kernel(PackArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ci = ci0 + e;
-    float x = 0.f;
-    if (co < a.cout && ci < a.cin) {
-      // logical filter F[co][ci][tap]; source tensor S is OIHW (or IOHW if transposed).
-      // flip: F[co][ci][tap] = S'[ci][co][kk-1-tap] (data-gradient filter)
-      int o = co, i = ci, t = tap;
-      if (a.flip) {
-        o = ci;
-        i = co;
-        t = a.kk - 1 - tap;
-      }
-      const int d0 = a.flip ? a.cin : a.cout, d1 = a.flip ? a.cout : a.cin;  // S' logical dims (O', I')
-      long long idx = a.transposed ? ((long long)i * d0 + o) * a.kk + t : ((long long)o * d1 + i) * a.kk + t;
-      x = a.w[idx];
+    // logical filter F[co][ci][tap]; source tensor S is OIHW (or IOHW if transposed).
+    // flip: F[co][ci][tap] = S'[ci][co][kk-1-tap] (data-gradient filter)
+    // (the eight loads are unconditional -- element 0 for a padding position, zeroed after: inside `if (in range)` each of them was
+    // waited for before the next was issued)
+    const bool ok = co < a.cout && ci < a.cin;
+    int o = co, i = ci, t = tap;
+    if (a.flip) {
+      o = ci;
+      i = co;
+      t = a.kk - 1 - tap;
     }
-    v[e] = x;
+    const int d0 = a.flip ? a.cin : a.cout, d1 = a.flip ? a.cout : a.cin;  // S' logical dims (O', I')
+    const long long idx = a.transposed ? ((long long)i * d0 + o) * a.kk + t : ((long long)o * d1 + i) * a.kk + t;
+    const float x = a.w[ok ? idx : 0];
+    v[e] = ok ? x : 0.f;
   }
   *reinterpret_cast<u32x4*>(a.out + u * 8) = a.dtype == FD_F16 ? fd_pk8<FmtA>(v) : fd_pk8<FmtG>(v);
 }
@@ -126,19 +126,17 @@ __global__ void pack_weights_kernel(PackJobsArgs b) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ci = ci0 + e;
-    float x = 0.f;
-    if (co < j.cout && ci < j.cin) {
-      int o = co, i = ci, t = tap;
-      if (j.flip) {
-        o = ci;
-        i = co;
-        t = kk - 1 - tap;
-      }
-      const int d0 = j.flip ? j.cin : j.cout, d1 = j.flip ? j.cout : j.cin;
-      const long long idx = j.transposed ? ((long long)i * d0 + o) * kk + t : ((long long)o * d1 + i) * kk + t;
-      x = j.w[idx];
+    const bool ok = co < j.cout && ci < j.cin;      // (unconditional loads: see pack_weight_kernel)
+    int o = co, i = ci, t = tap;
+    if (j.flip) {
+      o = ci;
+      i = co;
+      t = kk - 1 - tap;
     }
-    v[e] = x;
+    const int d0 = j.flip ? j.cin : j.cout, d1 = j.flip ? j.cout : j.cin;
+    const long long idx = j.transposed ? ((long long)i * d0 + o) * kk + t : ((long long)o * d1 + i) * kk + t;
+    const float x = j.w[ok ? idx : 0];
+    v[e] = ok ? x : 0.f;
   }
   *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(j.packed) + u * 8) = j.dtype == FD_F16 ? fd_pk8<FmtA>(v) : fd_pk8<FmtG>(v);
 }
