@@ -419,6 +419,40 @@ def forward_1024(g, dev, batch=4, size=1024, warm=2, steps=5):
             "GB/s": round(by / dt / 1e9, 1), "frac_hbm": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "finite": ok}
 
 
+def freqsplit_1024(dev, batch=4, size=1024, iters=20):
+    """BASELINE.json north_star's frequency split at configs[4]'s size: Blur, Laplacian and the Fusion-discriminator's input
+    (cat([img, LF, HF]): train.py's fusion_input) on batch 4 x 3 x 1024 x 1024 fp32 planes, each timed with stream events over
+    `iters` launches.  Algorithmic bytes: one read + one write of the tensor for a filter, one read + three writes for the
+    concatenation (kernel table)."""
+    import torch
+    from fdgan_hip import engine as E
+    from loss import fusion_input
+    x = torch.rand(batch, 3, size, size, device=dev)
+    tensor_bytes = x.numel() * 4
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    out = {"workload": "Blur(15, sigma 3) / Laplacian(3) / cat([img, LF, HF]) on %d x 3 x %d x %d fp32" % (batch, size, size)}
+    with torch.no_grad():
+        for name, fn, nbytes in (("blur15", lambda: E.blur15(x, True), 2 * tensor_bytes), ("laplacian3", lambda: E.laplacian3(x), 2 * tensor_bytes),
+                                 ("fusion_input", lambda: fusion_input(x), 4 * tensor_bytes)):
+            us = timed(fn)
+            out[name] = {"us": round(us, 1), "GB/s": round(nbytes / us / 1e3, 1), "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    del x
+    torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves, one process
     per GPU, exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` would, and
@@ -627,6 +661,7 @@ def main():
                                          "workload": res["config"]["workload"], "roofline": res["roofline"]}
             if not a.no_forward_1024:
                 train_res["forward_1024"] = forward_1024(g, dev)
+                train_res["freqsplit_1024"] = freqsplit_1024(dev)
             if world == 1 and not a.no_cpu_baseline:
                 train_res["cpu_baseline"] = cpu_baseline_train(S, a.cpu_seconds)
             print(json.dumps(train_res), flush=True)

@@ -10,4 +10,7 @@ if f:
     print("forward %.3f ms  %.0f img/s  headline %s" % (f["ms_per_step"], f["value"], f["roofline"].get("headline_3x3")))
 if d.get("forward_1024"):
     print("forward_1024", d["forward_1024"]["value"], d["forward_1024"]["ms_per_step"])
+if d.get("freqsplit_1024"):
+    q = d["freqsplit_1024"]
+    print("freqsplit_1024", {k: (v["us"], v["frac_hbm"]) for k, v in q.items() if isinstance(v, dict)})
 print("losses", d["config"].get("last_losses"))
