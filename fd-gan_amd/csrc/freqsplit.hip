@@ -29,6 +29,7 @@ struct FsArgs {
   float mean[3], istd[3];
   int tiles_x, tiles_y;
   int mode;         // 0 blur, 1 laplacian, 2 fused NHWC
+  int lap_r;        // Laplacian: radius (k - 1) / 2 of the box (0: 1, the 3x3 filter)
   long long y_sn;   // row-streaming form only: elements between the output planes of consecutive images (0: C * H * W, planes packed)
   float* y_copy;    // row-streaming Laplacian only: also receives the INPUT planes, laid out like y (or NULL)
 };
@@ -75,16 +76,15 @@ __global__ __launch_bounds__(256) void freqsplit_kernel(FsArgs a) {
       if (a.norm) lf = (lf - a.mean[ch]) * a.istd[ch];
     }
     const float ctr = tin[r + FS_R][c + FS_R];
-    if (a.mode != 0) {   // 3x3 box sum with ZERO padding minus 9 * centre
+    if (a.mode != 0) {   // k x k box sum with ZERO padding minus k^2 * centre (k = 2 lap_r + 1; 3 x 3 in the network)
+      const int lr = a.lap_r > 0 ? a.lap_r : 1;
       float s = 0.f;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
+      for (int dy = -lr; dy <= lr; ++dy)
+        for (int dx = -lr; dx <= lr; ++dx) {
           const int yy = oy + dy, xx = ox + dx;
           s += (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? tin[r + FS_R + dy][c + FS_R + dx] : 0.f;
         }
-      hf = s - 9.f * ctr;
+      hf = s - (float)((2 * lr + 1) * (2 * lr + 1)) * ctr;
     }
     // (mode 2's three 2-byte stores per pixel and plane: a form with all three planes per workgroup, the nine values staged in LDS
     // and ONE 32-byte store per pixel was measured in round 3 -- 39.8 against 35.7 us at 16 x 3 x 256^2, 124 against 140 us at
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
   };
 
   f4 ring[NTAP];       // horizontally filtered rows; ring[k % NTAP] = row (first + k)
-  f4 ctr[3];           // Laplacian: the raw centre pixels of the last 3 rows
-  constexpr int FSR_PF = BLUR ? FSR_PF_BLUR : 3;      // rows requested ahead
+  f4 ctr[NTAP];        // Laplacian: the raw centre pixels of the last NTAP rows (the centre row is R rows back)
+  constexpr int FSR_PF = BLUR ? FSR_PF_BLUR : (NTAP == 3 ? 3 : NTAP);      // rows requested ahead (divides the unrolled block of NTAP rows)
   f4 pv[FSR_PF], ph[FSR_PF];
   const int first = r_begin - R, last = r_end + R;     // input rows [first, last)
 #pragma unroll
   for (int q = 0; q < FSR_PF; ++q) fetch(first + q, pv[q], ph[q]);
-  static_assert(NTAP % FSR_PF == 0 && NTAP % 3 == 0, "one unrolled block of NTAP rows keeps ring, prefetch and centre positions constant");
+  static_assert(NTAP % FSR_PF == 0, "one unrolled block of NTAP rows keeps ring, prefetch and centre positions constant");
   for (int k0 = 0; first + k0 < last; k0 += NTAP) {
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {                   // unrolled: ring / prefetch positions are constants (15 bodies: fits the I-cache; 45 did not)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
         }
       }
       ring[j % NTAP] = hsum;
-      if (!BLUR) ctr[j % 3] = v;
+      if (!BLUR) ctr[j % NTAP] = v;
       const int oy = iy - R;                            // the output row this input row completes
       if (k >= 2 * R && oy >= r_begin && oy < r_end) {
         f4 o = {0.f, 0.f, 0.f, 0.f};
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(64) void freqsplit_rows_kernel(FsRowArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (o[e] - a.mean[ch]) * a.istd[ch];
         } else {
-          const f4 c = ctr[(j + 3 * NTAP - 1) % 3];   // centre row = the previous input row
+          const f4 c = ctr[(j + NTAP - R) % NTAP];   // centre row = the input row R back
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] -= 9.f * c[e];
+          for (int e = 0; e < 4; ++e) o[e] -= (float)(NTAP * NTAP) * c[e];
           if (a.y_copy != nullptr && cx < a.W) *reinterpret_cast<f4*>(a.y_copy + yoff + (long long)oy * a.W + cx) = c;
         }
         if (cx + 3 < a.W) *reinterpret_cast<f4*>(yp + (long long)oy * a.W + cx) = o;
@@ -392,7 +392,8 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
   // 52.9 / 15.9 us for the tile kernel (4.2 TB/s); Blur 40.5 / 21.6 us against 55.8 / 18.0 us -- its 14 halo rows per
   // 16-row segment cost more than the tile kernel's halo once the planes are small, so small planes stay on the tiles
   const bool rows_pay = a.mode == 1 || a.y_sn != 0 || planes * (long long)a.H * a.W >= (6ll << 20);
-  if (a.mode != 2 && rows_pay && a.W % 4 == 0 && a.W >= 16 && a.H >= 16 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 &&
+  const int lap_r = a.lap_r > 0 ? a.lap_r : 1;
+  if (a.mode != 2 && rows_pay && (a.mode == 0 || lap_r <= 3) && a.W % 4 == 0 && a.W >= 16 && a.H >= 16 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 &&
       FD_TUNE_GETENV("FDGAN_DEBUG_NO_FS_ROWS") == nullptr) {
     FsRowArgs r{};
     r.x = a.x, r.y = a.y, r.H = a.H, r.W = a.W, r.C = a.C, r.norm = a.norm;
@@ -419,6 +420,10 @@ int launch(FsArgs& a, long long planes, hipStream_t stream, const char* name) {
     const bool dpp = dpp_env ? dpp_env[0] == '1' : a.mode == 1;
     if (a.mode == 0) return dpp ? fd_launch(&freqsplit_rows_kernel<7, true>, name, dim3(grid), dim3(64), 0, r, stream)
                                 : fd_launch(&freqsplit_rows_kernel<7, false>, name, dim3(grid), dim3(64), 0, r, stream);
+    if (lap_r == 2) return dpp ? fd_launch(&freqsplit_rows_kernel<2, true>, name, dim3(grid), dim3(64), 0, r, stream)
+                               : fd_launch(&freqsplit_rows_kernel<2, false>, name, dim3(grid), dim3(64), 0, r, stream);
+    if (lap_r == 3) return dpp ? fd_launch(&freqsplit_rows_kernel<3, true>, name, dim3(grid), dim3(64), 0, r, stream)
+                               : fd_launch(&freqsplit_rows_kernel<3, false>, name, dim3(grid), dim3(64), 0, r, stream);
     return dpp ? fd_launch(&freqsplit_rows_kernel<1, true>, name, dim3(grid), dim3(64), 0, r, stream)
                : fd_launch(&freqsplit_rows_kernel<1, false>, name, dim3(grid), dim3(64), 0, r, stream);
   }
@@ -455,6 +460,23 @@ extern "C" int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t
   a.C = (int)c;
   a.mode = 1;
   return launch(a, n * c, static_cast<hipStream_t>(stream), "laplacian3");
+}
+
+/* Laplacian(kernel_size).forward for any odd kernel_size <= 15 (loss.py:245-301: ones(k, k) with centre 1 - k^2, zero padding
+ * (k - 1) / 2, depthwise): the k x k box sum minus k^2 x the centre.  k = 3, 5, 7 on the row-streaming kernel, larger ones on the tile
+ * kernel (its 7-pixel halo is what bounds k).  Self-adjoint like the 3 x 3 one: the backward is the same call on dy. */
+extern "C" int fdgan_laplacian_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int ksize, FdStream stream) {
+  FD_REQUIRE(x && y, "laplacian_fwd: NULL pointer");
+  FD_REQUIRE(ksize >= 3 && ksize <= 15 && (ksize & 1), "laplacian_fwd: kernel_size must be odd, 3 .. 15 (got %d)", ksize);
+  FsArgs a{};
+  a.x = x;
+  a.y = y;
+  a.H = (int)h;
+  a.W = (int)w;
+  a.C = (int)c;
+  a.mode = 1;
+  a.lap_r = ksize / 2;
+  return launch(a, n * c, static_cast<hipStream_t>(stream), ksize == 3 ? "laplacian3" : "laplacian_k");
 }
 
 /* Laplacian's backward under autograd (loss.py:286-301): the operator is self-adjoint -- a symmetric 3x3 kernel with zero

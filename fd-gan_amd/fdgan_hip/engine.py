@@ -263,6 +263,14 @@ def laplacian3(x):
     return y
 
 
+def laplacian(x, ksize):
+    """Laplacian(ksize) for odd ksize in 3 .. 15; also its own adjoint (call it on dy)."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().fdgan_laplacian_fwd(x.data_ptr(), y.data_ptr(), n, c, h, w, int(ksize), stream_ptr()), "laplacian_fwd")
+    return y
+
+
 def laplacian3_bwd(dy):
     n, c, h, w = dy.shape
     dx = torch.empty_like(dy)

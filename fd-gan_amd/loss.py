@@ -154,16 +154,16 @@ class Laplacian(nn.Module):
 
     def __init__(self, kernel_size):
         super().__init__()
-        if kernel_size != 3:
-            raise NotImplementedError("the HIP Laplacian implements kernel_size=3 (loss.py:304)")
+        if not (isinstance(kernel_size, int) and 3 <= kernel_size <= 15 and kernel_size % 2 == 1):
+            raise NotImplementedError("the HIP Laplacian takes an odd kernel_size in 3 .. 15 (loss.py:304 builds 3), got %r" % (kernel_size,))
         self.kernel_size = kernel_size
         self._padding = (kernel_size - 1) // 2
         self.register_buffer("kernel", get_laplacian_kernel2d(kernel_size))
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
-            return _LaplacianFn.apply(x)
-        return E.laplacian3(_gpu_f32(x, "Laplacian.forward"))
+            return _LaplacianFn.apply(x, self.kernel_size)
+        return E.laplacian(_gpu_f32(x, "Laplacian.forward"), self.kernel_size)
 
 
 blur_kernel = isotropic_gaussian_kernel(l=15, sigma=3.0)       # loss.py:161
@@ -184,12 +184,13 @@ class _BlurFn(torch.autograd.Function):
 
 class _LaplacianFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
-        return E.laplacian3(_gpu_f32(x, "Laplacian.forward"))
+    def forward(ctx, x, ksize=3):
+        ctx.ksize = ksize
+        return E.laplacian(_gpu_f32(x, "Laplacian.forward"), ksize)
 
     @staticmethod
     def backward(ctx, dy):
-        return E.laplacian3_bwd(dy.detach().float().contiguous())     # self-adjoint: symmetric kernel, zero padding
+        return E.laplacian(dy.detach().float().contiguous(), ctx.ksize), None     # self-adjoint: symmetric kernel, zero padding
 
 
 def fusion_input(img, use_input_norm=True):

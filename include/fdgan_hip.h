@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 13
+#define FDGAN_ABI_VERSION 14
 
 enum FdStatus {
   FD_OK = 0,
@@ -546,6 +546,10 @@ int fdgan_maxpool2_bwd_nhwc(const FdTensor* x, const FdTensor* dy, const FdTenso
 int fdgan_blur15_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int use_input_norm,
                      FdStream stream);
 int fdgan_laplacian3_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, FdStream stream);
+/* Laplacian(kernel_size) for any odd kernel_size in 3 .. 15 (the class of loss.py:245-301 takes one; the network builds
+ * Laplacian(3), loss.py:304): k x k box sum with zero padding (k - 1) / 2 minus k^2 x the centre, depthwise, unnormalised.
+ * Self-adjoint: its backward is the same call on dy. */
+int fdgan_laplacian_fwd(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, int ksize, FdStream stream);
 /* What the Fusion-discriminator is fed (train.py's fusion_input; /root/reference/facades/network.png, the frequency split of
  * /root/reference/__pycache__/loss.cpython-36.pyc): out[n] = cat([img[n], Blur(img)[n], Laplacian(img)[n]]) as NCHW fp32,
  * (n, 3 c, h, w) in ONE buffer -- the two filters write their planes where the concatenation wants them and the Laplacian

@@ -890,6 +890,27 @@ def test_frequency_split_backward():
         (y * cot.to(DEV)).sum().backward()
         torch.cuda.synchronize()
         assert rel_rms(xg.grad.cpu(), xo.grad) < 1e-5, shape
+    # Laplacian(k) for the other odd kernel sizes the class takes (the network builds k = 3): k = 3, 5, 7 on the row-streaming kernel,
+    # 9 .. 15 (and widths that are not a multiple of 4) on the tile kernel; forward and adjoint vs the oracle, and the known answers
+    # of SURVEY 4.3 generalised (a constant image gives 0 in the interior)
+    for k, shape in ((5, (2, 3, 40, 56)), (7, (1, 2, 33, 300)), (5, (1, 3, 21, 30)), (9, (2, 3, 24, 40)), (15, (1, 1, 40, 36)), (3, (1, 3, 17, 18))):
+        x = det_input(shape, seed=90 + k, lo=0.0, hi=1.0)
+        cot = det_input(shape, seed=91 + k, lo=-1.0, hi=1.0)
+        xo = x.clone().requires_grad_(True)
+        yo = fr.laplacian(xo, k)
+        (yo * cot).sum().backward()
+        xg = x.to(DEV).requires_grad_(True)
+        y = hl.Laplacian(k)(xg)
+        (y * cot.to(DEV)).sum().backward()
+        assert (y.detach().cpu() - yo.detach()).abs().max() < 1e-4 * k, (k, shape)
+        assert rel_rms(xg.grad.cpu(), xo.grad) < 1e-5, (k, shape)
+        with torch.no_grad():
+            flat = hl.Laplacian(k)(torch.full(shape, 0.5, device=DEV))
+        r = k // 2
+        assert float(flat[..., r:shape[2] - r, r:shape[3] - r].abs().max()) < 1e-4
+    for bad in (4, 1, 17):
+        with pytest.raises(NotImplementedError):
+            hl.Laplacian(bad)
     # module forms
     xg = det_input((2, 3, 32, 32), seed=83).to(DEV).requires_grad_(True)
     (hl.Blur(15, use_input_norm=False)(xg).sum() + hl.Laplacian(3)(xg).sum()).backward()
