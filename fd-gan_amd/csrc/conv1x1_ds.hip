@@ -379,5 +379,10 @@ static int ds_dispatch(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool 
 int conv_dispatch_k1_ds(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream) {
   // measured: 12 waves x 16 pixels (3 waves per SIMD) is 10-30 % SLOWER than 8 x 32 -- half the A-fragment
   // reuse, twice the LDS reads per MFMA -- and 16 waves do not fit LDS; one configuration is instantiated
+  // (tuning aid, round 4: 8 x 16 pixels = 112 KB of LDS instead of 157, so that a 26-31 KB workgroup of the MFMA-bound kernels the
+  // other stream runs beside the generator's forward -- D on the real batch, VGG16 on the target -- could share the CU.  Measured:
+  // the forward alone 5.06 -> 5.43 ms, the training step 27.58 -> 27.83 ms: the slower kernel is not paid back.)
+  static const char* small_env = FD_TUNE_GETENV("FDGAN_DEBUG_DS_SMALL");
+  if (small_env && small_env[0] == '1') return ds_dispatch<8, 1>(a, info, stats_cap, dry, stream);
   return ds_dispatch<8, 2>(a, info, stats_cap, dry, stream);
 }
