@@ -1057,6 +1057,19 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
   a.pool = pool ? 1 : 0;
   fill_pro(pro, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma, a.p_beta);
   if (pool && a.pro_mode == 0) a.pro_mode = 1;   // the pooled path always goes through the affine helper (scale 1, shift 0)
+  // the discriminators' last conv (ONE filter): a vector-ALU streaming reduction (conv_c1.hip)
+  if (cout == 1 && !pool && dbias == nullptr) {
+    long long ns = 0;
+    hipStream_t st1 = static_cast<hipStream_t>(stream);
+    const int rc1 = wgrad_cout1_launch(x, dy, d->ksize, d->stride, d->pad, a.pro_mode, a.p_slope, a.eps, a.p_mean, a.p_var, a.p_gamma,
+                                       a.p_beta, workspace, workspace_floats, &ns, st1);
+    if (rc1 < 0) return rc1;
+    if (rc1 == 0) {
+      const long long numel1 = (long long)a.Cin * d->ksize * d->ksize;
+      WredArgs r1{workspace, dw, numel1, (int)ns, accumulate};
+      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel1 + 63) / 64)), dim3(256), 0, r1, st1);
+    }
+  }
   // the few-channel convs at the ends of the networks (3 -> 64, 16 -> 3, 9 -> 36 stride 2): one GEMM over all taps
   if (workspace != nullptr && !pool && a.Cin <= 16 && cout <= 64) {
     long long ns = 0;

@@ -250,6 +250,141 @@ __global__ __launch_bounds__(256) void dgrad_cout1_kernel(C1BwdArgs a) {
   }
 }
 
+// ---- weight gradient of the one-filter conv: dW[c][ky][kx] = sum over output pixels of dy[p] * a[p + (ky, kx) - pad][c] ----------------
+// On the matrix-pipe kernels the single output channel is a 32-wide tile with one live row (conv_wgrad4x4_tr: 150 us at B = 16 @
+// 127 x 127 x 288 for 149 MB of input, 19 us of HBM time).  Read the other way round it is a streaming reduction: every input pixel
+// a[iy][ix][c] meets the KS x KS gradient values around it -- dW[c][ky][kx] += a[iy][ix][c] * dy[iy + pad - ky][ix + pad - kx] -- so a
+// thread owns 8 channels, walks input pixels and keeps all KS^2 x 8 sums in registers: one 16-byte load and KS^2 x 4 packed FMAs per
+// pixel.  Workgroup = (image, band of W1_ROWS input rows), 256 threads = C / 8 channel groups x 256 / (C / 8) pixel slots; the band's
+// dy rows sit in LDS as fp32 with a zero frame (no bounds tests in the tap loop); the slots are summed through LDS in a fixed order
+// and the workgroup leaves ONE partial [C][KS][KS], which wgrad_reduce_kernel sums over the workgroups.
+#ifndef W1_PF
+#define W1_PF 2
+#endif
+#ifndef W1_ROWS_N
+#define W1_ROWS_N 4
+#endif
+constexpr int W1_ROWS = W1_ROWS_N;
+struct C1WgArgs {
+  const unsigned short* x;     // NHWC fp16 view of the conv's input
+  long long x_sn;
+  int x_sh, x_sw, H, W, C, C8;
+  const unsigned short* dy;    // NHWC bf16 view, channel 0 used
+  long long dy_sn;
+  int dy_sh, dy_sw, Ho, Wo, pad, bands;
+  int pro_mode;
+  float slope, eps;
+  const float *mean, *var, *gamma, *beta;
+  float* part;                 // [workgroup][C][KS][KS]
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_cout1_kernel(C1WgArgs a) {
+  constexpr int KK = KS * KS, DR = W1_ROWS + KS - 1;
+  extern __shared__ __attribute__((aligned(16))) char c1_lds[];
+  const int dw_ = a.Wo + 2 * (KS - 1);                       // dy band row width with the zero frame
+  float* dyl = reinterpret_cast<float*>(c1_lds);              // [DR][dw_]
+  float* red = dyl;                                           // [slots][C8 * 8][KS] (after the pixel loop, over the band)
+  const int tid = threadIdx.x;
+  const int band = blockIdx.x % a.bands, n = blockIdx.x / a.bands;
+  const int iy0 = band * W1_ROWS;
+  const int nslot = 256 / a.C8;
+  const int c8 = tid % a.C8, slot = tid / a.C8;
+  const bool live = slot < nslot;
+  // dy band: rows oy = iy0 + pad - (KS - 1) .. iy0 + pad + W1_ROWS - 1, columns ox = -(KS - 1) .. Wo + KS - 2, zeros outside
+  const unsigned short* dn = a.dy + (long long)n * a.dy_sn;
+  for (int i = tid; i < DR * dw_; i += 256) {
+    const int r = i / dw_, cc = i - r * dw_;
+    const int oy = iy0 + a.pad - (KS - 1) + r, ox = cc - (KS - 1);
+    const bool ok = oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
+    const float v = fd_cvt1<FmtG>(dn[ok ? oy * a.dy_sh + ox * a.dy_sw : 0]);      // (unconditional load, clamped address)
+    dyl[i] = ok ? v : 0.f;
+  }
+  typedef f32x2 f2;
+  f2 sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e, cc = min(c, a.C - 1);
+    float s_ = 1.f, h_ = 0.f;
+    if (a.pro_mode == 2) {
+      const float g = a.gamma ? a.gamma[cc] : 1.f, b = a.beta ? a.beta[cc] : 0.f;
+      s_ = g / sqrtf(a.var[cc] + a.eps);
+      h_ = b - a.mean[cc] * s_;
+    }
+    sc[e >> 1][e & 1] = c < a.C ? s_ : 0.f, sh[e >> 1][e & 1] = c < a.C ? h_ : 0.f;
+  }
+  __syncthreads();
+  f2 acc[KK][4];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[t][q] = f2{0.f, 0.f};
+  const int rows = min(W1_ROWS, a.H - iy0);
+  const int npix = rows * a.W;
+  const unsigned short* xn = a.x + (long long)n * a.x_sn + c8 * 8;
+  if (live) {
+    for (int p0 = slot; p0 < npix; p0 += W1_PF * nslot) {      // W1_PF pixels in flight per thread
+      u32x4 xv[W1_PF];
+      int ry[W1_PF], rx[W1_PF];
+      bool ok[W1_PF];
+#pragma unroll
+      for (int k = 0; k < W1_PF; ++k) {
+        const int p = p0 + k * nslot;
+        ok[k] = p < npix;
+        const int pc = ok[k] ? p : p0;
+        ry[k] = pc / a.W, rx[k] = pc - ry[k] * a.W;
+        xv[k] = *reinterpret_cast<const u32x4*>(xn + (long long)(iy0 + ry[k]) * a.x_sh + (long long)rx[k] * a.x_sw);
+      }
+#pragma unroll
+      for (int k = 0; k < W1_PF; ++k) {
+        const f32x8 f = fd_cvt8<FmtA>(xv[k]);
+        const float lv = ok[k] ? 1.f : 0.f;
+        f2 av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f2 t = __builtin_elementwise_fma(f2{f[2 * q], f[2 * q + 1]}, sc[q], sh[q]);
+          if (a.pro_mode != 0) t = __builtin_elementwise_max(t, t * a.slope);
+          av[q] = t * lv;
+        }
+        // input pixel (ry, rx) of the band meets dy[iy + pad - ky][ix + pad - kx]: band row ry + (KS - 1) - ky, framed column rx + pad - kx + (KS - 1)
+        const float* dp = dyl + (ry[k] + KS - 1) * dw_ + rx[k] + a.pad + (KS - 1);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float d = dp[-ky * dw_ - kx];
+            const f2 d2 = {d, d};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[ky * KS + kx][q] = __builtin_elementwise_fma(d2, av[q], acc[ky * KS + kx][q]);
+          }
+      }
+    }
+  }
+  // the slots' sums, KS taps (one filter row) at a time through LDS -- all KS^2 at once would be 129 KB for C = 288 and leave room for
+  // one workgroup (4 waves) per CU; the dy band is dead by now
+  const int cp = a.C8 * 8;
+  float* out = a.part + (long long)blockIdx.x * a.C * KK;
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+    __syncthreads();
+    if (live)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          red[(slot * cp + c8 * 8 + 2 * q) * KS + kx] = acc[ky * KS + kx][q][0];
+          red[(slot * cp + c8 * 8 + 2 * q + 1) * KS + kx] = acc[ky * KS + kx][q][1];
+        }
+    __syncthreads();
+    for (int i = tid; i < a.C * KS; i += 256) {               // i = c * KS + kx
+      float t = 0.f;
+      for (int s_ = 0; s_ < nslot; ++s_) t += red[s_ * cp * KS + i];
+      const int c = i / KS, kx = i - c * KS;
+      out[c * KK + ky * KS + kx] = t;                          // dW[0][c][ky][kx] order
+    }
+  }
+}
+
 }  // namespace
 
 // forward: Cout == 1 exactly, 4x4 (or 3x3) stride 1, NCHW fp32 output, no bias, no upsample
@@ -313,5 +448,43 @@ int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const F
                         : fd_launch(&dgrad_cout1_kernel<3, false>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
     default: return acc1 ? fd_launch(&dgrad_cout1_kernel<2, true>, "dgrad_cout1", grid, dim3(256), lds, c, stream)
                          : fd_launch(&dgrad_cout1_kernel<2, false>, "dgrad_cout1", grid, dim3(256), lds, c, stream);
+  }
+}
+
+// weight gradient of a stride-1 conv with ONE filter: 0 launched (partials in `workspace`: *nsplit_out arrays of cin * k * k floats),
+// 1 the shape is not this kernel's (nothing launched), < 0 error
+int wgrad_cout1_launch(const FdTensor* x, const FdTensor* dy, int ksize, int stride, int pad, int pro_mode, float slope, float eps,
+                       const float* mean, const float* var, const float* gamma, const float* beta, float* workspace,
+                       long long workspace_floats, long long* nsplit_out, hipStream_t stream) {
+  if (stride != 1 || ksize < 2 || ksize > 4 || x->c % 8 != 0 || x->c < 8 || x->c > 2048 || workspace == nullptr ||
+      FD_TUNE_GETENV("FDGAN_DEBUG_NO_C1") != nullptr)
+    return 1;
+  C1WgArgs c{};
+  c.x = static_cast<const unsigned short*>(x->ptr), c.x_sn = x->stride[0], c.x_sh = (int)x->stride[1], c.x_sw = (int)x->stride[2];
+  c.H = (int)x->h, c.W = (int)x->w, c.C = (int)x->c, c.C8 = (int)(x->c / 8);
+  c.dy = static_cast<const unsigned short*>(dy->ptr), c.dy_sn = dy->stride[0], c.dy_sh = (int)dy->stride[1], c.dy_sw = (int)dy->stride[2];
+  c.Ho = (int)dy->h, c.Wo = (int)dy->w, c.pad = pad;
+  c.bands = (c.H + W1_ROWS - 1) / W1_ROWS;
+  c.pro_mode = pro_mode, c.slope = slope, c.eps = eps, c.mean = mean, c.var = var, c.gamma = gamma, c.beta = beta;
+  if (c.C8 > 256) return 1;
+  const int nslot = 256 / c.C8, kk = ksize * ksize, dr = W1_ROWS + ksize - 1, dwid = c.Wo + 2 * (ksize - 1);
+  const long long lds_band = (long long)dr * dwid * 4, lds_red = (long long)nslot * c.C8 * 8 * ksize * 4;
+  const long long lds = lds_band > lds_red ? lds_band : lds_red;
+  const long long nwg = (long long)x->n * c.bands;
+  if (lds > 160 * 1024 || nwg >= (1ll << 31) || nwg * c.C * kk > workspace_floats || dy->n * dy->stride[0] >= (1ll << 31)) return 1;
+  c.part = workspace;
+  *nsplit_out = nwg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_cout1_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_cout1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_cout1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)nwg);
+  switch (ksize) {
+    case 4: return fd_launch(&wgrad_cout1_kernel<4>, "wgrad_cout1", grid, dim3(256), (unsigned)lds, c, stream);
+    case 3: return fd_launch(&wgrad_cout1_kernel<3>, "wgrad_cout1", grid, dim3(256), (unsigned)lds, c, stream);
+    default: return fd_launch(&wgrad_cout1_kernel<2>, "wgrad_cout1", grid, dim3(256), (unsigned)lds, c, stream);
   }
 }

@@ -1012,6 +1012,9 @@ int conv_dispatch_k4(ConvArgs& a, long long nimg, int cout_total, int stride, bo
 // the one-filter convolution that ends the discriminators, and its data gradient (conv_c1.hip)
 bool conv_cout1_fits(const ConvArgs& a, int cout_total, int ksize, int stride, bool pool);
 int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* info, bool dry, hipStream_t stream);
+int wgrad_cout1_launch(const FdTensor* x, const FdTensor* dy, int ksize, int stride, int pad, int pro_mode, float slope, float eps,
+                       const float* mean, const float* var, const float* gamma, const float* beta, float* workspace,
+                       long long workspace_floats, long long* nsplit_out, hipStream_t stream);
 int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro, const FdTensor* dpre,
                        int accumulate, const FdConvDesc* d, hipStream_t stream);
 extern unsigned long long* g_fd_debug_timing;
