@@ -466,6 +466,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WredArgs a) {
   }
 }
 
+// Few outputs, many partial rows (bias gradients: 3 .. 288 sums over 300 .. 1024 rows; the few-channel filters): 64 outputs x 16 split
+// lanes per workgroup, eight loads in flight per thread, fixed summation order.  With wgrad_reduce_kernel's 4 lanes a 64-element bias
+// over 1024 rows was a chain of 32 dependent rounds on ONE workgroup (40-90 us); `pitch`: floats between partial rows (>= numel).
+struct WredWideArgs {
+  const float* part;
+  float* out;
+  long long numel, pitch;
+  int nsplit, accumulate;
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(WredWideArgs a) {
+  __shared__ float sh[16][64];
+  const int col = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + col;
+  float t = 0.f;
+  if (i < a.numel) {
+    const float* src = a.part + i;
+    int s_ = ty;
+    for (; s_ + 112 < a.nsplit; s_ += 128) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[(long long)(s_ + 16 * k) * a.pitch];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
+    }
+    for (; s_ < a.nsplit; s_ += 16) t += src[(long long)s_ * a.pitch];
+  }
+  sh[ty][col] = t;
+  __syncthreads();
+  if (ty == 0 && i < a.numel) {
+    t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][col];
+    a.out[i] = a.accumulate ? a.out[i] + t : t;
+  }
+}
+
 // Batched form: every [nsplit][numel] partial block of a backward walk in ONE launch (job table in device memory, as
 // fdgan_pack_conv_weights does for the filter images).  blockIdx.x walks 64-element column groups of all jobs.
 struct WredBatchArgs {
@@ -506,9 +542,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WredBatchArgs b
 }
 
 }  // namespace
+int fd_wgrad_reduce_wide(const float* part, float* out, long long numel, long long pitch, int nsplit, int accumulate, hipStream_t stream) {
+  WredWideArgs r{part, out, numel, pitch, nsplit, accumulate};
+  return fd_launch(&wgrad_reduce_wide_kernel, "wgrad_reduce_wide", dim3((unsigned)((numel + 63) / 64)), dim3(1024), 0, r, stream);
+}
 int fd_wgrad_reduce(const float* part, float* out, long long numel, int nsplit, int accumulate, hipStream_t stream) {
+  if (numel <= 4096 && nsplit >= 128) return fd_wgrad_reduce_wide(part, out, numel, numel, nsplit, accumulate, stream);
   WredArgs r{part, out, numel, nsplit, accumulate};
   return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, stream);
+}
+static int fd_wgrad_reduce_args(const WredArgs& r, hipStream_t st) {   // (picks the 16-lane form for few outputs x many rows)
+  return fd_wgrad_reduce(r.part, r.out, r.numel, r.nsplit, r.accumulate, st);
 }
 extern "C" int fdgan_wgrad_reduce_batch(const FdReduceJob* jobs_device, int64_t njobs, int64_t total_groups, FdStream stream) {
   FD_REQUIRE(jobs_device && njobs > 0 && njobs < (1 << 20) && total_groups > 0 && total_groups < (1ll << 31), "wgrad_reduce_batch: empty job table");
@@ -1067,7 +1111,7 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
     if (rc1 == 0) {
       const long long numel1 = (long long)a.Cin * d->ksize * d->ksize;
       WredArgs r1{workspace, dw, numel1, (int)ns, accumulate};
-      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel1 + 63) / 64)), dim3(256), 0, r1, st1);
+      return fd_wgrad_reduce_args(r1, st1);
     }
   }
   // the few-channel convs at the ends of the networks (3 -> 64, 16 -> 3, 9 -> 36 stride 2): one GEMM over all taps
@@ -1080,10 +1124,10 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
     if (rcs == 0) {
       const long long numels = (long long)cout * a.Cin * d->ksize * d->ksize;
       WredArgs rs{workspace, dw, numels, (int)ns, accumulate};
-      if (int rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numels + 63) / 64)), dim3(256), 0, rs, sts)) return rc;
+      if (int rc = fd_wgrad_reduce_args(rs, sts)) return rc;
       if (dbias == nullptr) return FD_OK;
       WredArgs rb{workspace + ns * numels, dbias, cout, (int)ns, accumulate};
-      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, rb, sts);
+      return fd_wgrad_reduce_args(rb, sts);
     }
   }
   // row-walking transpose-read kernels (conv_wgrad_tr.hip): the growth conv and the discriminator's 4x4 conv
@@ -1135,7 +1179,7 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
                           W3_XS_B + W3_DT_B + 256, w, st3);
       if (rc3 != FD_OK) return rc3;
       WredArgs r3{workspace, dw, numel3, (int)(strips * segs), accumulate};
-      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel3 + 63) / 64)), dim3(256), 0, r3, st3);
+      return fd_wgrad_reduce_args(r3, st3);
     }
   }
   // the dense-layer bottleneck (1x1, 128 filters): transpose-read kernel (conv_wgrad1x1_tr.hip)
@@ -1148,7 +1192,7 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
     if (rc1 == FD_OK) {
       const long long numel1 = 128LL * a.Cin;
       WredArgs r1{workspace, dw, numel1, (int)ns, accumulate};
-      return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel1 + 63) / 64)), dim3(256), 0, r1, st1);
+      return fd_wgrad_reduce_args(r1, st1);
     }
   }
   const long long numel = (long long)cout * a.Cin * d->ksize * d->ksize;
@@ -1209,10 +1253,10 @@ extern "C" int fdgan_conv2d_bwd_weight_job(const FdTensor* x, const FdPrologue* 
                      : fd_launch(&conv_wgrad_kernel<64, 4, false>, "conv_wgrad", grid, dim3(256), lds, a, st);
   if (rc != FD_OK || direct) return rc;
   WredArgs r{workspace, dw, numel, (int)nsplit, accumulate};
-  rc = fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, r, st);
+  rc = fd_wgrad_reduce_args(r, st);
   if (rc != FD_OK || !dbias) return rc;
   WredArgs rb{workspace + nsplit * numel, dbias, cout, (int)nsplit, accumulate};
-  return fd_launch(&wgrad_reduce_kernel, "wgrad_reduce", dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, rb, st);
+  return fd_wgrad_reduce_args(rb, st);
 }
 
 extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, float* partial,

@@ -982,6 +982,8 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
                        const FdTensor* dy_affine_x = nullptr, const float* dy_affine_b = nullptr, const float* dy_affine_c = nullptr);
 // [nsplit][numel] partial weight gradients -> out (+= when accumulate), fixed summation order (conv_bwd.hip)
 int fd_wgrad_reduce(const float* part, float* out, long long numel, int nsplit, int accumulate, hipStream_t stream);
+// few outputs x many partial rows (bias gradients); pitch: floats between rows
+int fd_wgrad_reduce_wide(const float* part, float* out, long long numel, long long pitch, int nsplit, int accumulate, hipStream_t stream);
 // row-streaming 3x3 data gradient of the growth conv + prologue backward (conv3x3_bwd.hip)
 bool conv3x3_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre, const FdConvDesc* d);
 int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor* fwd_x, const FdPrologue* pro, const FdTensor* dpre,
