@@ -594,7 +594,7 @@ struct BnActBwdArgs {
 // POOL / DX: a.pool != 0 / a.dx != NULL as compile-time facts, and no branch around a load in the pixel loop -- a lane past the last
 // pixel reads its first pixel again and only its stores and sums are predicated.  (With `if (p < a.P) { loads }` hipcc waited for
 // every load at the join behind it: 428 us = 1 TB/s on the Fusion-discriminator's 16 x 127 x 127 x 288 BatchNorm input, round 4.)
-template <bool POOL, bool DX>
+template <bool POOL, int DX>      // DX: 0 no dx, 1 dx += gamma * rstd * dpre, 2 dx = gamma * rstd * dpre (the buffer's first writer of a walk)
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
   __shared__ float red[2][32][64];   // [which][pixel slot][channel within this thread column]: reduced below
   const int tid = threadIdx.x;
@@ -635,9 +635,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
         dp[k] = a.da + n * a.da_sn + (long long)(POOL ? y >> 1 : y) * a.da_sh + (long long)(POOL ? xx >> 1 : xx) * a.da_sw + c8 * 8;
         dvv[k] = *reinterpret_cast<const u32x4*>(dp[k]);
         xvv[k] = *reinterpret_cast<const u32x4*>(a.x + n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw + c8 * 8);
-        if constexpr (DX) {
+        if constexpr (DX != 0) {
           gp[k] = a.dx + n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw + c8 * 8;
-          gvv[k] = *reinterpret_cast<const u32x4*>(gp[k]);
+          if constexpr (DX == 1) gvv[k] = *reinterpret_cast<const u32x4*>(gp[k]);
         }
       }
 #pragma unroll
@@ -655,8 +655,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActBwdArgs a) {
           s2[e] += o[e] * (xf[e] - xm[e]) * xr[e];
         }
         if (!POOL && ok[k]) *reinterpret_cast<u32x4*>(dp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(o, bf16x8));
-        if constexpr (DX) {
-          f32x8 g = __builtin_convertvector(__builtin_bit_cast(bf16x8, gvv[k]), f32x8);
+        if constexpr (DX != 0) {
+          f32x8 g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if constexpr (DX == 1) g = __builtin_convertvector(__builtin_bit_cast(bf16x8, gvv[k]), f32x8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = fmaf(sc[e], o[e], g[e]);
           if (ok[k]) *reinterpret_cast<u32x4*>(gp[k]) = __builtin_bit_cast(u32x4, __builtin_convertvector(g, bf16x8));
@@ -1266,6 +1267,11 @@ extern "C" int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdP
 
 extern "C" int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, float* partial,
                                     int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
+  return fdgan_bn_act_bwd_dx(da, x, pro, dx, 0, partial, capacity_floats, rows_out, cpad_out, stream);
+}
+
+extern "C" int fdgan_bn_act_bwd_dx(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, int dx_store,
+                                   float* partial, int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream) {
   if (int rc = check_view(da, "bn_act_bwd(da)")) return rc;
   if (int rc = check_view(x, "bn_act_bwd(x)", FD_F16)) return rc;
   const bool pooled = pro && pro->pool2;
@@ -1301,10 +1307,13 @@ extern "C" int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const
   if (cpad_out) *cpad_out = a.cpad;
   const dim3 grid((unsigned)rows, (unsigned)chunks);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (a.pool) return a.dx ? fd_launch(&bn_act_bwd_kernel<true, true>, "bn_act_bwd", grid, dim3(256), 0, a, st)
-                          : fd_launch(&bn_act_bwd_kernel<true, false>, "bn_act_bwd", grid, dim3(256), 0, a, st);
-  return a.dx ? fd_launch(&bn_act_bwd_kernel<false, true>, "bn_act_bwd", grid, dim3(256), 0, a, st)
-              : fd_launch(&bn_act_bwd_kernel<false, false>, "bn_act_bwd", grid, dim3(256), 0, a, st);
+  if (a.pool) {
+    if (a.dx && dx_store) return fd_launch(&bn_act_bwd_kernel<true, 2>, "bn_act_bwd", grid, dim3(256), 0, a, st);
+    return a.dx ? fd_launch(&bn_act_bwd_kernel<true, 1>, "bn_act_bwd", grid, dim3(256), 0, a, st)
+                : fd_launch(&bn_act_bwd_kernel<true, 0>, "bn_act_bwd", grid, dim3(256), 0, a, st);
+  }
+  return a.dx ? fd_launch(&bn_act_bwd_kernel<false, 1>, "bn_act_bwd", grid, dim3(256), 0, a, st)
+              : fd_launch(&bn_act_bwd_kernel<false, 0>, "bn_act_bwd", grid, dim3(256), 0, a, st);
 }
 
 extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,

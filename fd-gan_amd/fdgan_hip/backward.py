@@ -272,6 +272,34 @@ class PlanBackward:
                     per_gbuf.setdefault(id(self.gbuf[reads(r)[0]]), []).append(False)
                 r["_sole"] = sole
             self.nozero = {g for g, flags in per_gbuf.items() if all(flags)}
+            # First writers: the LAST forward reader of a buffer is the first op of the walk to touch its gradient.  When that op
+            # reads the WHOLE buffer through a pooled BatchNorm prologue (a dense block's transition: every channel, every pixel) its
+            # one-pass backward can store instead of add -- the block's gradient buffer (0.5 GB for block 1) then needs no zeroing at
+            # the start of a walk and is not read by that pass (fdgan_bn_act_bwd_dx).
+            if self.pool_one_pass and self.defer_affine and os.environ.get("FDGAN_NO_FIRST_WRITER_STORE") is None:
+                last_reader = {}
+                for i, r in enumerate(self.recs):
+                    reg = reads(r) if r["kind"] in ("conv", "copy", "maxpool") else None
+                    if reg is not None:
+                        last_reader[reg[0]] = i
+                    elif r["kind"] not in ("dropout",):      # an op this analysis does not model: leave its buffers alone
+                        for key in ("src", "dst"):
+                            v = r.get(key)
+                            if v is not None and hasattr(v, "buf"):
+                                last_reader[v.buf.data_ptr()] = -1
+                for ptr, i in last_reader.items():
+                    if i < 0:
+                        continue
+                    r = self.recs[i]
+                    if r["kind"] != "conv" or r.get("pro") is None:
+                        continue
+                    meta, x = r["pro"]._meta, r["x"]
+                    g = self.gbuf.get(ptr)
+                    whole = x.c0 == 0 and x.c == x.buf.shape[-1] and not isinstance(x, E.StridedView)
+                    if (g is not None and whole and meta["pool"] and meta.get("bn") is not None and r["stride"] == 1 and r["k"] == 1
+                            and ptr not in self.multi_version and sum(1 for q in self.gbuf.values() if q is g) == 1):
+                        r["_first_full"] = True
+                        self.nozero.add(id(g))
         # Verification hook: tests set `checks` to a list AND `check_reference` to a callable (r, dy_view, meta) -> (dW, dx)
         # that states the single fused op under torch autograd (tests/hiputil.op_reference); every op's two gradients are
         # then compared with it in place.  No reference implementation lives in the product package.
@@ -503,6 +531,8 @@ class PlanBackward:
                                                        " pool" if meta["pool"] else "", " bn" if meta.get("bn") is not None else ""),
                        dw=float((tmp - dw_ref).norm() / (dw_ref.norm() + 1e-30)))
         if not need_dx:
+            if r.get("_first_full", False) and self.checks is None:      # nobody stores into this buffer now: zero it after all
+                E.fill_zero(self.gbuf[x.buf.data_ptr()])
             if check:
                 self.checks.append(rec)
             return
@@ -689,7 +719,10 @@ class PlanBackward:
             dbt = self._tmp((cin,), torch.float32)
             train_bn = bn.weight is not None and bn.weight.requires_grad
             one_pass = self.defer_affine and not check and self.pool_one_pass     # G += gamma * rstd * dpre rides in the pass that forms the sums
-            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn, dx_fd=gx.fd if one_pass else None)
+            # (the buffer's first writer of the walk, reading all of it: store -- its gradient buffer is not zeroed, see __init__)
+            first = bool(r.get("_first_full", False)) and one_pass and self.checks is None
+            assert first or not r.get("_first_full", False) or self.checks is not None, "a first-writer record left the one-pass path"
+            rows, cpad = E.bn_act_bwd(Tv.fd, x.fd, pool_pro, self.ws_bn, dx_fd=gx.fd if one_pass else None, dx_store=first)
             E.bn_bwd_finalize(self.ws_bn, rows, cpad, cin, dg, dbt, sink_dgamma=grad_target(grads, bn.weight) if train_bn else None,
                               sink_dbeta=grad_target(grads, bn.bias) if train_bn else None)
             for lo, hi in _constant_entries(meta, cin):

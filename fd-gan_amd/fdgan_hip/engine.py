@@ -509,14 +509,15 @@ class TrReduceTable:
         L.check(L.load().fdgan_wgrad_tr_reduce_batch(self.table.data_ptr(), self.n, self.groups, stream_ptr()), "wgrad_tr_reduce_batch")
 
 
-def bn_act_bwd(da_fd, x_fd, pro, ws=None, dx_fd=None):
+def bn_act_bwd(da_fd, x_fd, pro, ws=None, dx_fd=None, dx_store=False):
     """In place: da <- da * act'(bn(x)).  With a norm in `pro`, also fills `ws` with the partial sums and
-    returns (rows, cpad) for bn_bwd_finalize.  dx_fd (pooled prologues only): dx += gamma * rstd * dpre in the same pass."""
+    returns (rows, cpad) for bn_bwd_finalize.  dx_fd (pooled prologues only): dx += gamma * rstd * dpre in the same pass
+    (dx_store: dx = ..., the buffer's first writer of a walk)."""
     rows, cpad = C.c_int64(0), C.c_int64(0)
-    L.check(L.load().fdgan_bn_act_bwd_acc(C.byref(da_fd), C.byref(x_fd), C.byref(pro) if pro is not None else None,
-                                          C.byref(dx_fd) if dx_fd is not None else None,
-                                          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
-                                          C.byref(rows), C.byref(cpad), stream_ptr()), "bn_act_bwd")
+    L.check(L.load().fdgan_bn_act_bwd_dx(C.byref(da_fd), C.byref(x_fd), C.byref(pro) if pro is not None else None,
+                                         C.byref(dx_fd) if dx_fd is not None else None, int(bool(dx_store)),
+                                         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                         C.byref(rows), C.byref(cpad), stream_ptr()), "bn_act_bwd")
     return rows.value, cpad.value
 
 

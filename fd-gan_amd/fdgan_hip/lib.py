@@ -17,7 +17,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class FdganLibraryError(RuntimeError):
@@ -173,6 +173,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_bn_act_bwd_acc": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor), C.c_void_p,
                                        C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "fdgan_bn_act_bwd_dx": (C.c_int, [C.POINTER(FdTensor), C.POINTER(FdTensor), C.POINTER(FdPrologue), C.POINTER(FdTensor), C.c_int, C.c_void_p,
+                                      C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "fdgan_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p]),
     "fdgan_bn_bwd_finalize_sink": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,

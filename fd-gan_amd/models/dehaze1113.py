@@ -413,12 +413,14 @@ class FDGAN(_PlannedModule):
         _emit_dense_block(P, self.dense_block2, blk2, st2, bott2, cnt2, keep)
         _emit_transition(P, self.trans_block2, E.View(blk2, 0, 512), st2, E.View(blk3, 0, 256), cnt2, out_stats=st3)
         P.copy(E.View(blk3, 0, 256), E.View(blk5, 128, 256))                      # x2 half of x42 (:786)
+        # x22 = conv_refin5(avg_pool2d(x2, 2))                                    (:780) -- emitted ahead of dense block 3 (it only needs
+        # x2): trans_block3 is then the LAST reader of blk3, i.e. the first writer of its gradient buffer in the backward walk, reads
+        # all of it, and stores instead of adding (fdgan_hip/backward.py: first writers) -- no zeroing of the block's gradient buffer
+        P.conv(E.View(blk3, 0, 256), P.weight(self.conv_refin5.weight, 128, 256, 1), E.View(cat6, 512, 128), 1,
+               bias=self.conv_refin5.bias, pro=E.make_prologue(pool=True))
         # x3 = trans_block3(dense_block3(x2))                                     (:778)
         _emit_dense_block(P, self.dense_block3, blk3, st3, bott3, cnt3, keep)
         _emit_transition(P, self.trans_block3, E.View(blk3, 0, 1024), st3, E.View(cat6, 0, 512), cnt3)
-        # x22 = conv_refin5(avg_pool2d(x2, 2))                                    (:780)
-        P.conv(E.View(blk3, 0, 256), P.weight(self.conv_refin5.weight, 128, 256, 1), E.View(cat6, 512, 128), 1,
-               bias=self.conv_refin5.bias, pro=E.make_prologue(pool=True))
         # x4 = trans_block4(dense_block4(conv_refin6(cat[x3, x22])))              (:783)
         P.conv(E.View(cat6), P.weight(self.conv_refin6.weight, 512, 640, 3), E.View(blk4, 0, 512), 3, pad=1,
                bias=self.conv_refin6.bias)

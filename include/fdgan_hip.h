@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 14
+#define FDGAN_ABI_VERSION 15
 
 enum FdStatus {
   FD_OK = 0,
@@ -348,6 +348,11 @@ int fdgan_bn_act_bwd(const FdTensor* da, const FdTensor* x, const FdPrologue* pr
  * input -- fdgan_bn_bwd_apply -- is not needed (torchvision _Transition under autograd, dehaze1113.py:716-728). */
 int fdgan_bn_act_bwd_acc(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, float* partial,
                          int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
+/* The same with dx_store != 0: dx = gamma * rstd * dpre instead of +=, for the FIRST writer of a gradient buffer in a backward walk
+ * when it covers the whole buffer (a dense block's transition, the last forward reader of the block's concat buffer: torchvision
+ * _Transition, dehaze1113.py:716-728): the buffer then needs no zeroing at the start of the walk and is not read here. */
+int fdgan_bn_act_bwd_dx(const FdTensor* da, const FdTensor* x, const FdPrologue* pro, const FdTensor* dx, int dx_store, float* partial,
+                        int64_t capacity_floats, int64_t* rows_out, int64_t* cpad_out, FdStream stream);
 int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t cpad, int64_t channels, float* dgamma,
                           float* dbeta, int accumulate, FdStream stream);
 /* Same, and the sums are ALSO added into sink_dgamma / sink_dbeta when non-NULL: the BatchNorm parameters' own

@@ -1079,6 +1079,44 @@ def test_training_step_full_size_configs2():
         assert want in names, (want, sorted(names))
 
 
+def test_first_writer_of_a_gradient_buffer_stores(monkeypatch, nets):
+    """A dense block's transition is the last forward reader of the block's concat buffer -- so the FIRST op of the backward walk to
+    touch that buffer's gradient -- and it reads every channel of every pixel: its one-pass BatchNorm backward stores
+    (fdgan_bn_act_bwd_dx, dx_store) and the three big gradient buffers are neither zeroed at the start of a walk nor read by that
+    pass.  0 + v == v: the gradients must be BITWISE those of the zero-and-add walk (FDGAN_NO_FIRST_WRITER_STORE)."""
+    net, _ = nets
+    from oracle.detweights import det_input, fill_state_dict
+    from models.dehaze1113 import _plan_backward
+    x = det_input((2, 3, 64, 64), seed=5).to(DEV)
+    tgt = det_input((2, 3, 64, 64), seed=6, lo=-1.0, hi=1.0).to(DEV)
+
+    def run(store):
+        if store:
+            monkeypatch.delenv("FDGAN_NO_FIRST_WRITER_STORE", raising=False)
+        else:
+            monkeypatch.setenv("FDGAN_NO_FIRST_WRITER_STORE", "1")
+        g = net.FDGAN()
+        fill_state_dict(g, seed=3)
+        g = g.to(DEV)
+        grads = []
+        for _ in range(2):                      # the second walk meets whatever the first left in the buffers
+            g.zero_grad()
+            ((g(x) - tgt) ** 2).mean().backward()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in g.parameters() if p.grad is not None])
+        B = _plan_backward(g._plan_for(x))
+        first = [r for r in B.recs if r.get("_first_full")]
+        return grads, first, B
+
+    a, fa, Ba = run(True)
+    b, fb, _ = run(False)
+    assert len(fa) == 3 and not fb, (len(fa), len(fb))                      # trans_block1 / 2 / 3
+    assert all(id(Ba.gbuf[r["x"].buf.data_ptr()]) in Ba.nozero for r in fa)
+    for ga, gb in zip(a, b):
+        assert len(ga) == len(gb) and all(torch.equal(u, v) for u, v in zip(ga, gb))
+    assert all(torch.equal(u, v) for u, v in zip(a[0], a[1]))              # and the walk is repeatable
+
+
 def test_recorded_backward_walk_is_bitwise_the_eager_walk(monkeypatch):
     """the reverse walks (generator, Fusion-D x3, VGG16) are recorded into multi-stream FdPlans on their third
     run and replayed from then on (fdgan_hip/backward.py: _Tape).  Five training steps at B = 4 @ 128x128 from the same seed, once
