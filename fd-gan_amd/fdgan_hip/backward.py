@@ -831,11 +831,46 @@ class PlanBackward:
                 return False
         return True
 
+    def _head_first_writer(self, head):
+        """The head conv (a network's last one, outside the plan) is the only reader of its input buffer in every network here: it
+        then STORES its data gradient and that buffer's gradient (142 MB for the Fusion-discriminator, three walks per step) is
+        neither zeroed per walk nor read.  Decided at the first walk that brings the head; a later walk without it zeroes the buffer."""
+        hs = self.__dict__.get("_head_store")
+        if head is None:
+            if hs:
+                E.fill_zero(hs[1])
+            return
+        r = head[0]
+        if hs is None:
+            self._head_store = hs = ()
+            rx = _region(r["x"])
+            g = self.gbuf.get(rx[0])
+            meta = r["pro"]._meta if r.get("pro") is not None else dict(pool=False)
+            others = False
+            for rk in self.recs:
+                v = rk.get("x") if rk["kind"] == "conv" else rk.get("src")
+                if v is not None and hasattr(v, "buf") and _overlap(_region(v), rx):
+                    others = True
+            ok = (self.fuse_mask and self.defer_affine and os.environ.get("FDGAN_NO_DX_STORE") is None and g is not None and not others
+                  and r["stride"] == 1 and not meta["pool"] and r["x"].c0 % 8 == 0 and rx[0] not in self.multi_version
+                  and sum(1 for q in self.gbuf.values() if q is g) == 1)
+            if ok:
+                r["_sole"] = True
+                self.nozero.add(id(g))
+                self._zero_tables.clear()
+                self._head_store = hs = (id(r), g)
+        elif hs and hs[0] != id(r):      # another head record on the same plan: back to zero-and-add for good
+            self.nozero.discard(id(hs[1]))
+            self._zero_tables.clear()
+            E.fill_zero(hs[1])
+            self._head_store = ()
+
     def run(self, grads, skip_dx_of=(), head=None):
         """Walks the records in reverse.  The caller has zeroed G and seeded the gradient of the plan's outputs.  `grads`: dict
         parameter -> fp32 gradient, filled / accumulated.  head = (record, dy_view): a conv outside the plan whose backward
         comes first (a network's last conv, launched per call because its output is a fresh tensor); dy_view must live in a
         `persistent` buffer.  From the third walk on (same key) the walk is a recorded tape."""
+        self._head_first_writer(head)
         key = None
         if self.tape_enabled and not FORCE_EAGER and self.checks is None and self.walks_done >= 2:
             key = self._tape_key(skip_dx_of, head)
