@@ -255,7 +255,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) {   // (unconditional, clamped: see conv_igemm.h)
+          const bool bok = a.bias != nullptr && cout0 + r < a.CoutW;
+          const float bval = (a.bias != nullptr ? a.bias : reinterpret_cast<const float*>(a.w))[bok ? cout0 + r : 0];
+          bv[r] = bok ? bval : 0.f;
+        }
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
           const bool pok = px0 + p * 16 < a.P;

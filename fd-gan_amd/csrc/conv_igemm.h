@@ -708,7 +708,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WD && PT * CT > 32) ? 1 : 2) void co
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = cbase + c * 16 + kgl * 4 + r;
-      bv[c][r] = (a.bias != nullptr && co < a.CoutW) ? a.bias[co] : 0.f;
+      // (unconditional load of a clamped index: inside `cond ? a.bias[co] : 0` each of the CT x 4 loads is waited for before the next is
+      // issued -- eight dependent L2 round trips at the tail of every workgroup of VGG16's convs)
+      const bool bok = a.bias != nullptr && co < a.CoutW;
+      const float bval = (a.bias != nullptr ? a.bias : reinterpret_cast<const float*>(a.w))[bok ? co : 0];
+      bv[c][r] = bok ? bval : 0.f;
     }
   if constexpr (MK != 0) {
     // Backward data.  Row phase only: each 16-pixel x (CT*16)-channel accumulator tile goes through the wave's LDS staging
