@@ -19,7 +19,8 @@ int conv_dispatch_k3(ConvArgs& a, long long nimg, int cout_total, int stride, bo
   // (Round 4, measured and not kept: 8 waves = 16 x 16 pixels x 128 channels per workgroup, i.e. half of wdA's filter bytes from L2 per
   // pixel -- 2048 workgroups each pull the whole 295 KB filter of a 128 -> 128 layer -- VGG16's forward 0.77 -> 0.86 ms: the filter
   // traffic is not what holds these kernels at 1.0-1.1 PFLOP/s.  Nor is occupancy: 4 rows per wave on 8 waves (110 registers, four
-  // waves per SIMD instead of three) runs the same layers at 0.87-0.90 PFLOP/s, 0.89 ms.)
+  // waves per SIMD instead of three) runs the same layers at 0.87-0.90 PFLOP/s, 0.89 ms; and 64 output channels per wave on 2 waves
+  // (half the input-fragment reads per MFMA) needs 256 registers, spills 28-31 and runs at 0.68-0.95 PFLOP/s, 0.99 ms.)
   {
     const char* sel = FD_TUNE_GETENV("FDGAN_DEBUG_WD");   // tuning aid: 0 forces the LDS-staged-filter kernels, A/G/H a variant
     char v = sel ? sel[0] : 'x';
