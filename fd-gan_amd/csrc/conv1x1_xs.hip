@@ -255,11 +255,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {   // (unconditional, clamped: see conv_igemm.h)
-          const bool bok = a.bias != nullptr && cout0 + r < a.CoutW;
-          const float bval = (a.bias != nullptr ? a.bias : reinterpret_cast<const float*>(a.w))[bok ? cout0 + r : 0];
-          bv[r] = bok ? bval : 0.f;
-        }
+        // (conditional on purpose: the unconditional clamped form of conv_igemm.h costs this kernel 14 registers at the end of its
+        // pixel loop -- 42 -> 290 scratch instructions over the instantiations, the pooled transitions 0 -> 64; tools/scratch_audit.py)
+        for (int r = 0; r < 4; ++r) bv[r] = (a.bias != nullptr && cout0 + r < a.CoutW) ? a.bias[cout0 + r] : 0.f;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
           const bool pok = px0 + p * 16 < a.P;

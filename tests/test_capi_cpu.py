@@ -122,3 +122,34 @@ def test_release_library_carries_no_tuning_switches():
             for m in re.finditer(r"(?<![A-Z_])getenv\s*\(", src):
                 line = src[src.rfind("\n", 0, m.start()) + 1:src.find("\n", m.start())]
                 assert "#define FD_TUNE_GETENV" in line, "%s: getenv outside FD_TUNE_GETENV: %s" % (fn, line.strip())
+
+
+def test_no_kernel_spills_outside_the_allow_list():
+    """spills have silently come and gone in three rounds (a scratch reload is a `vmcnt(0)` in a streaming
+    kernel).  Every csrc/*.hip is compiled to gfx950 assembly with the release flags; a kernel may contain `scratch_`
+    instructions only if tools/scratch_allow.json names it, and then at most the count recorded there."""
+    import json
+    import shutil
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scratch_audit
+    allow = json.load(open(os.path.join(ROOT, "tools", "scratch_allow.json")))
+    res = scratch_audit.audit()
+    bad = []
+    seen = set()
+    for f, per in res.items():
+        for k, v in per.items():
+            n = max(v["scratch"], 1 if (v["private"] or v["spill"]) else 0)
+            if n == 0:
+                continue
+            seen.add(k)
+            if k not in allow["kernels"]:
+                bad.append("%s: %s has %d scratch instructions (%d B private) and is not on the allow-list" % (f, k, v["scratch"], v["private"]))
+            elif v["scratch"] > allow["kernels"][k]["max_scratch"]:
+                bad.append("%s: %s has %d scratch instructions, allow-list says <= %d" % (f, k, v["scratch"], allow["kernels"][k]["max_scratch"]))
+    assert not bad, "\n".join(bad)
+    # a stale allow-list entry (the kernel is clean now or gone) is an error too: the list may only shrink
+    stale = sorted(set(allow["kernels"]) - seen)
+    assert not stale, "allow-list entries that no longer spill (remove them): %s" % stale
