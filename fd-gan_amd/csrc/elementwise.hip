@@ -567,6 +567,9 @@ extern "C" int fdgan_mul_mask_nhwc(const FdTensor* mask, const FdTensor* dst, in
   FD_REQUIRE(mask && dst && mask->ptr && dst->ptr, "mul_mask_nhwc: NULL tensor");
   FD_REQUIRE(mask->dtype == FD_F16 && (dst->dtype == FD_F16 || dst->dtype == FD_BF16), "mul_mask_nhwc: an fp16 mask and a 16-bit view");
   const int f = up2 ? 2 : 1;
+  // whole 8-channel groups only: the tail group of a view in the middle of a concat buffer would cover (and multiply by the mask's
+  // zero padding) the NEXT slice's first channels
+  FD_REQUIRE(dst->c % 8 == 0, "mul_mask_nhwc: %lld channels (a multiple of 8 expected)", (long long)dst->c);
   FD_REQUIRE(mask->n == dst->n && mask->h * f == dst->h && mask->w * f == dst->w && mask->c == dst->c, "mul_mask_nhwc: shape mismatch");
   for (const FdTensor* t : {mask, dst})
     FD_REQUIRE(t->stride[3] == 1 && t->stride[2] % 8 == 0 && t->stride[1] % 8 == 0 && t->stride[0] % 8 == 0 && ((uintptr_t)t->ptr & 15) == 0,

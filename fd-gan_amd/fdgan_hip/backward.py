@@ -43,6 +43,7 @@ class _Tape:
         self.inplace = []        # parameters whose gradient the walk adds straight into their optimizer sink
         self.sinks = []          # (parameter, data_ptr of the sink) the recorded launches write to
         self.side_used = False
+        self.cur_side = False    # the open plan segment has launches on slot 1
         self.launches = 0
 
     def _plan(self):
@@ -56,13 +57,15 @@ class _Tape:
             L.check(self.lib.fdgan_plan_end(self.cur.h), "plan_end")
             if len(self.cur):
                 self.launches += len(self.cur)
+                self.cur.side_used = self.cur_side
                 self.steps.append(self.cur)
             self.cur = None
+            self.cur_side = False
 
     def set_slot(self, slot):
         L.check(self.lib.fdgan_plan_set_slot(self._plan().h, slot), "plan_set_slot")
         if slot:
-            self.side_used = True
+            self.side_used = self.cur_side = True
 
     def wait(self, waiter, signaler):
         L.check(self.lib.fdgan_plan_record_wait(self._plan().h, waiter, signaler), "plan_record_wait")
@@ -77,11 +80,18 @@ class _Tape:
             self.lib.fdgan_plan_end(self.cur.h)
             self.cur = None
 
-    def replay(self, streams):
+    def replay(self, streams, owner=None):
+        """owner: the PlanBackward whose walk this is.  Its `_w_pending` flag is raised after EVERY segment that launched on the
+        side stream: a host step between two segments -- the optimizer's all-reduce hook -- calls
+        `owner.join_side()`, which waits for the side stream only while the flag is up and lowers it; raised once per walk, the
+        second and later buckets of a data-parallel step would be handed to RCCL without waiting for the weight gradients the
+        segments since the first join put on the side stream."""
         lib = self.lib
         for st in self.steps:
             if isinstance(st, E.Plan):
                 L.check(lib.fdgan_plan_launch_multi(st.h, streams, 2), "plan_launch_multi")
+                if owner is not None and getattr(st, "side_used", False):
+                    owner._w_pending = True
             else:
                 st()
 
@@ -443,6 +453,7 @@ class PlanBackward:
         for d in self.deferred.values():                                # the launch above cleared every pair
             d["dirty"].clear()
             d["stale"].clear()
+        self._zeroed = True
 
     # ---- one fused convolution ---------------------------------------------------------------
     def _fuse_w(self, r, need_dx):
@@ -871,6 +882,11 @@ class PlanBackward:
         comes first (a network's last conv, launched per call because its output is a fresh tensor); dy_view must live in a
         `persistent` buffer.  From the third walk on (same key) the walk is a recorded tape."""
         self._head_first_writer(head)
+        # a recorded walk replays raw pointers and assumes clean accumulation buffers: the caller's zero_() is part of its contract
+        # (ADVICE r4: nothing enforced it)
+        if self.tape_enabled and not getattr(self, "_zeroed", False):
+            raise RuntimeError("PlanBackward.run() without a zero_() since the previous walk")
+        self._zeroed = False
         key = None
         if self.tape_enabled and not FORCE_EAGER and self.checks is None and self.walks_done >= 2:
             key = self._tape_key(skip_dx_of, head)
@@ -917,9 +933,9 @@ class PlanBackward:
     def _replay(self, tape, grads):
         cur = torch.cuda.current_stream(self.plan.device).cuda_stream
         streams = (C.c_void_p * 2)(cur, self.wstream.cuda_stream if self.wstream is not None else cur)
-        self._w_pending = tape.side_used        # a hook that hands a slice to the all-reduce joins the side stream itself
-        tape.replay(streams)
-        self._w_pending = False                 # the tape ends with the join
+        self._w_pending = False                 # raised by the tape after each segment with side-stream launches: a hook that
+        tape.replay(streams, self)              # hands a slice to the all-reduce joins the side stream itself (join_side)
+        self._w_pending = False                 # the tape ends with the recorded join
         for q in tape.inplace:
             grads[q] = IN_PLACE
         self.walks_done += 1
@@ -984,11 +1000,15 @@ class PlanBackward:
             key = tuple((pt.data_ptr(), o.data_ptr(), n, s_, a) for pt, o, n, s_, a in self.reduce_jobs)
             if self.reduce_table is None or self.reduce_table.key != key:
                 self.reduce_table = E.ReduceTable(self.reduce_jobs, self.plan.device)
+            if self._rec is not None:         # the recorded launch carries the table's device pointer: the tape owns the table
+                self._rec.keep.append(self.reduce_table)      # (a later walk under another key may replace it)
             self.reduce_table.launch()
         if self.tr_jobs:      # the side stream's weight gradients: their partial sums, one launch (on that stream, behind them)
             key = tuple((j.part, j.out, j.item_stride, j.items, j.accumulate) for j in self.tr_jobs)
             if self.tr_table is None or self.tr_table.key != key:
                 self.tr_table = E.TrReduceTable(self.tr_jobs, list(self.tr_parts.values()), self.plan.device)
+            if self._rec is not None:
+                self._rec.keep.append(self.tr_table)
             with self._side():
                 self.tr_table.launch()
             self._w_pending = True

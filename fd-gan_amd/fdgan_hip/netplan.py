@@ -226,4 +226,8 @@ def bn_flags(module):
     bns = module.__dict__.get("_fd_bn_list")
     if bns is None or bns[0] != len(module._modules):
         bns = module.__dict__["_fd_bn_list"] = (len(module._modules), [m for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)])
-    return tuple(m.training for m in bns[1])
+    drops = module.__dict__.get("_fd_drop_list")
+    if drops is None or drops[0] != len(module._modules):     # blocks with an F.dropout behind their convs (BottleneckBlockdy, TransitionBlockdy, ...)
+        drops = module.__dict__["_fd_drop_list"] = (len(module._modules), [m for m in module.modules() if hasattr(m, "droprate")])
+    #  a plan bakes `droprate > 0 and training` of those blocks in: their mode is part of the key like the norms'
+    return tuple(m.training for m in bns[1]) + tuple((m.training, float(m.droprate)) for m in drops[1] if m.droprate > 0)

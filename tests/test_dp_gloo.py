@@ -218,3 +218,40 @@ def test_two_rank_epoch_loader_equal_steps_with_odd_batch_count(tmp_path):
         RankBatches(3, 2, 2, 0)                                      # cannot fill one global batch
     one = RankBatches(5, 2, 1, 0, shuffle=False)
     assert list(one) == [[0, 1], [2, 3]]
+
+
+def test_eight_rank_rendezvous_overlap_and_loader(tmp_path):
+    """configs[3] is EIGHT ranks and nothing with more than two had ever run.  The same workers as the
+    two-rank tests at world size 8 over gloo: the rendezvous, the sharding / timing collectives, the overlapped slice-wise
+    all-reduce of a flat gradient (mean over 8 ranks of rank + 1 = 4.5) and the epoch loader (37 items, batch 2: 2 full global
+    batches of 16 per epoch, every rank 2 steps, disjoint items, ragged tail dropped)."""
+    import numpy as np
+    from datasets.pix2pix import write_pair
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % i)) for i in range(world)]
+    assert [(x["lo"], x["hi"]) for x in r] == [(4 * i, 4 * i + 4) for i in range(world)]
+    assert sorted(sum((x["items"] for x in r), [])) == list(range(7)) and r[7]["items"] == []
+    assert all(x["slow"] == 8.0 and x["total"] == 32 and x["rate"] == 8 * 16 * 10 / 16.0 for x in r)
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "ov%d.pt" % i)) for i in range(world)]
+    assert all(torch.equal(r[0]["grad"], x["grad"]) for x in r[1:])
+    uses = {0: [2], 1: [3, 5], 2: [3], 3: [4], 4: [5], 5: [5], 6: [1], 7: [6]}
+    sizes = [300, 5, 700, 64, 1200, 9, 800, 33]
+    off = 0
+    for k, n in enumerate(sizes):
+        assert torch.allclose(r[0]["grad"][off:off + n], torch.full((n,), 4.5 * sum(uses[k]))), k
+        off += (n + 3) // 4 * 4
+    assert r[0]["early"] >= 1
+    root = str(tmp_path / "data")
+    for i in range(37):
+        img = np.full((8, 8, 3), i / 100.0, np.float32)
+        write_pair(root, i, img, img)
+    mp.spawn(_loader_worker, args=(world, _free_port(), str(tmp_path), root), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "l%d.pt" % i)) for i in range(world)]
+    assert all(x["n"] == 2 and x["steps"] == 4 for x in r)
+    for e in range(2):
+        seen = [x["seen"][e] for x in r]
+        assert all(len(s) == 4 for s in seen)
+        flat = sum(seen, [])
+        assert len(set(flat)) == len(flat) == 32 and set(flat) <= set(range(37))

@@ -143,12 +143,14 @@ def test_bench_py_single_rank_through_rccl(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [1, 2, 8])
 def test_bench_py_plain_python_launches_its_own_ranks(gpus):
     """The driver's command shape with NO launcher around it: `python bench.py --gpus N --steps K --warmup W` and WORLD_SIZE
     unset.  N = 1 runs in-process; N = 2 must start its own two ranks (bench.self_launch -> torch.distributed.run on
     127.0.0.1; both on cuda:0 over gloo through the FDGAN_BENCH_SHARED_GPU hook on this one-GPU box) instead of dying on an
-    argument check (VERDICT r3, next #1a).  The reference's only multi-GPU mechanism is /root/reference/demo.py:89."""
+    argument check (VERDICT r3, next #1a).  The reference's only multi-GPU mechanism is /root/reference/demo.py:89.
+    N = 8 (VERDICT r4, next #7c) is configs[3]'s rank count as a dry run at toy size: eight ranks' rendezvous, replica sync,
+    slice-wise all-reduce and per-rank step times, so that the first real 8-GPU lease does not meet an untested world size."""
     import json
     import subprocess
     import sys

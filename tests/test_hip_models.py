@@ -1003,6 +1003,8 @@ def test_training_step_matches_oracle_step():
     import train
     from oracle.train_ref import TrainStepRef
     from oracle.detweights import det_input
+    torch.manual_seed(31)
+    np.random.seed(31)
     ts = train.TrainStep(torch.device(DEV), synthetic=True)
     sd_g = {k: v.detach().cpu().clone() for k, v in ts.netG.state_dict().items()}
     sd_d = {k: v.detach().cpu().clone() for k, v in ts.netD.state_dict().items()}
@@ -1014,9 +1016,13 @@ def test_training_step_matches_oracle_step():
     r = ts.step(haze.to(DEV), gt.to(DEV))
     torch.cuda.synchronize()
     rep = {"hip": r, "oracle": r_ref}
-    tol = {"lossD": 0.02, "lossG": 0.02, "l1": 0.02, "ssim": 0.05, "perc": 0.05, "adv": 0.02}
+    # RELATIVE bounds, no absolute floor (`t * max(|ref|, 0.05)` let the 0.0014 SSIM term be off by 180 %):
+    # ten times the deltas measured on the GPU box (profiles/r5_parity_train_step_vs_oracle.json)
+    tol = {"lossD": 4e-4, "lossG": 1e-4, "l1": 1e-4, "ssim": 1e-3, "perc": 6e-4, "adv": 1.5e-3}
+    rep["rel_delta"] = {k: abs(r[k] - r_ref[k]) / abs(r_ref[k]) for k in tol}
+    _report("train_step_vs_oracle", rep)
     for k, t in tol.items():
-        assert abs(r[k] - r_ref[k]) <= t * max(abs(r_ref[k]), 0.05), (k, r[k], r_ref[k])
+        assert abs(r[k] - r_ref[k]) <= t * abs(r_ref[k]), (k, r[k], r_ref[k], rep["rel_delta"])
     # first Adam step: w <- w - lr * g / (|g| + eps): the update's sign is the gradient's sign
     agree = {}
     for name, net_hip, net_ref, sd0 in (("D", ts.netD, ref.netD, sd_d), ("G", ts.netG, ref.netG, sd_g)):
@@ -1035,6 +1041,80 @@ def test_training_step_matches_oracle_step():
     rep["first_update_sign_agreement"] = agree
     _report("train_step_vs_oracle", rep)
     assert agree["D"] > 0.98 and agree["G"] > 0.95, agree      # bf16 gradient storage flips the sign of some near-zero generator gradients
+
+
+def test_training_trajectory_matches_oracle_and_learns():
+    """VERDICT r4 next #7 (a) + (b).  One-step parity says nothing about drift (stochastic rounding, bf16 gradient storage,
+    the flat Adam): TEN steps of fd-gan_amd/train.py against ten steps of oracle/train_ref.py from the same weights on the
+    same fixed batch (2 x 64 x 64).  A GAN step is chaotic -- two CPU statements of it drift apart as well -- so the bounds
+    come from an EMULATION run made here, next to the comparison: a third trajectory, the oracle with every conv's operands
+    rounded to fp16 and its activation gradients to bf16 (tests/hiputil.emulate_kernel_operands, what the kernels round).
+    At every step every loss term of the HIP path is within max(3 x the emulation's largest deviation so far, 0.1 %) of the
+    oracle and never more than TRAJ_CAP off: 1 % for the generator's terms lossG and l1, 3 % for ssim / perc / adv, 25 % for
+    the discriminator's loss, which amplifies whatever the generator's output differs by; the parameters after step 10 are
+    cosine > 0.999 per tensor (tensors that start at zero -- BatchNorm biases -- are judged by their update), the ten-step
+    UPDATE (w10 - w0) of each network is as well aligned with the oracle's as the emulation's is (- 0.1); and -- the learning
+    check -- on this fixed batch L1 falls by more than 30 % within the ten steps on all three paths while SSIM rises
+    (the oracle alone, 30 steps: tests/test_oracle_golden.py::test_oracle_training_step_learns_on_a_fixed_batch)."""
+    import train
+    from hiputil import emulate_kernel_operands
+    from oracle.train_ref import TrainStepRef
+    from oracle.detweights import det_input
+    torch.manual_seed(32)
+    np.random.seed(32)
+    ts = train.TrainStep(torch.device(DEV), synthetic=True)
+    sd = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (ts.netG, ts.netD, ts.vgg)]
+    ref, emu = TrainStepRef(*sd), TrainStepRef(*sd)
+    for m in (emu.netG, emu.netD, emu.vgg):
+        emulate_kernel_operands(m, round_grads=True)
+    gt = det_input((2, 3, 64, 64), seed=5)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    hz, g_ = haze.to(DEV), gt.to(DEV)
+    traj_h, traj_r, traj_e = [], [], []
+    for _ in range(10):
+        traj_r.append(ref.step(haze, gt))
+        traj_e.append(emu.step(haze, gt))
+        traj_h.append(ts.step(hz, g_))
+    torch.cuda.synchronize()
+    rel = {k: [abs(h[k] - r[k]) / abs(r[k]) for h, r in zip(traj_h, traj_r)] for k in traj_r[0]}
+    rel_e = {k: [abs(e[k] - r[k]) / abs(r[k]) for e, r in zip(traj_e, traj_r)] for k in traj_r[0]}
+
+    def updates(net, sd0, cpu):
+        cw, du = [], []
+        for k, p in net.named_parameters():
+            a = p.detach().cpu().double().flatten()
+            d = a - sd0[k].double().flatten()
+            du.append(d)
+            cw.append((k, a, float(sd0[k].double().norm())))
+        return cw, torch.cat(du)
+    cos_w, cos_u, cos_ue = {}, {}, {}
+    for name, nh, nr, ne, sd0 in (("G", ts.netG, ref.netG, emu.netG, sd[0]), ("D", ts.netD, ref.netD, emu.netD, sd[1])):
+        (wh, uh), (wr, ur), (_, ue) = updates(nh, sd0, False), updates(nr, sd0, True), updates(ne, sd0, True)
+        never = ur == 0                               # never-trained tensors: no update on either path
+        assert float(uh[never].abs().max() if never.any() else 0.0) == 0.0
+        cos_w[name] = min(float(a @ b / (a.norm() * b.norm())) for (k, a, n0), (_, b, _) in zip(wh, wr) if n0 > 0)
+        cos_u[name] = float(uh @ ur / (uh.norm() * ur.norm()))
+        cos_ue[name] = float(ue @ ur / (ue.norm() * ur.norm()))
+    rep = {"hip": traj_h, "oracle": traj_r, "emulated": traj_e, "rel_delta": rel, "rel_delta_emulated": rel_e,
+           "min_param_cosine": cos_w, "update_cosine": cos_u, "update_cosine_emulated": cos_ue}
+    _report("train_trajectory", rep)
+    for k, v in rel.items():
+        worst_e = 0.0
+        for i, d in enumerate(v):
+            worst_e = max(worst_e, rel_e[k][i])
+            bound = min(max(3.0 * worst_e, 1e-3), TRAJ_CAP[k])
+            assert d <= bound, (k, i, d, bound, traj_h[i][k], traj_r[i][k])
+    assert min(cos_w.values()) > 0.999, cos_w
+    for name in ("G", "D"):
+        assert cos_u[name] > cos_ue[name] - 0.1, (cos_u, cos_ue)
+    for traj in (traj_h, traj_r, traj_e):
+        assert traj[-1]["l1"] < 0.7 * traj[0]["l1"], (traj[0]["l1"], traj[-1]["l1"])
+        assert traj[-1]["ssim"] > traj[0]["ssim"] + 0.05, (traj[0]["ssim"], traj[-1]["ssim"])
+
+
+# whatever the emulation drifts by, never more than this (three times the HIP path's worst step in the run recorded in
+# profiles/r5_parity_train_trajectory.json: lossG 5.5e-4, l1 3.3e-3, ssim 8.2e-3, perc 6.0e-3, adv 9.1e-3, lossD 8.4e-2)
+TRAJ_CAP = {"lossG": 1e-2, "l1": 1e-2, "ssim": 3e-2, "perc": 3e-2, "adv": 3e-2, "lossD": 0.25}
 
 
 def test_training_step_full_size_configs2():
@@ -1198,6 +1278,63 @@ def test_overlapped_allreduce_slices_are_final_when_sent():
     early_bytes = sum(hi - lo for lo, hi, _ in sent[:n_early])
     assert n_early >= 3 and early_bytes > 0.5 * opt.grad.numel(), (n_early, early_bytes, opt.grad.numel())
     assert float(opt.grad.abs().sum()) > 0
+
+
+def test_taped_walk_joins_the_side_stream_before_every_bucket(monkeypatch):
+    """under data parallelism the RECORDED walk is cut into plan segments by the optimizer's all-reduce hook.
+    Every bucket handed to the collective must first wait for the weight gradients the segments since the previous join put
+    on the side stream -- round 4 raised the `_w_pending` flag once per walk, so the second and later buckets of a taped walk
+    went out unjoined.  Small buckets (many sends per walk), five walks (the third records, the fourth and fifth replay):
+    (1) mechanism, deterministic: in a replayed walk more than one join actually waits; (2) every snapshot taken at send
+    time equals the final gradient; (3) the replayed walk's flat gradient is bitwise the eager walk's."""
+    import models.dehaze1113 as net
+    from fdgan_hip import backward as BW
+    from fdgan_hip.optim import FlatAdam
+    import train
+    monkeypatch.delenv("FDGAN_NO_BACKWARD_TAPE", raising=False)
+    torch.manual_seed(13)
+    g = net.FDGAN().to(DEV)
+    opt = FlatAdam(train.TrainStep._params_with_grad(g, torch.device(DEV)))
+    x = torch.rand(4, 3, 128, 128, device=DEV)
+    tgt = torch.rand(4, 3, 128, 128, device=DEV) * 2 - 1
+    real_waits = []
+    orig = BW.PlanBackward.join_side
+
+    def counting(self):
+        real_waits.append(bool(self._w_pending))
+        return orig(self)
+    monkeypatch.setattr(BW.PlanBackward, "join_side", counting)
+    grads, nsend, nwait = [], [], []
+    for step in range(5):
+        opt.zero_grad()
+        y = g(x)
+        sent = []
+        del real_waits[:]
+        with opt.overlap(None, bucket_mb=0.25, reduce_fn=lambda lo, hi: sent.append((lo, hi, opt.grad[lo:hi].clone()))):
+            ((y - tgt) ** 2).mean().backward()
+            n_early = len(sent)
+            w_early = sum(real_waits)
+        torch.cuda.synchronize()
+        for lo, hi, snap in sent:
+            assert torch.equal(snap, opt.grad[lo:hi]), (step, lo, hi)
+        grads.append(opt.grad.clone())
+        nsend.append(n_early)
+        nwait.append(w_early)
+    bwd = [getattr(pl, "_bwd", None) for pl in g.__dict__.get("_plans", {}).values()]
+    tapes = [t for b in bwd if b is not None for t in b.tapes.values() if t is not None]
+    assert tapes and any(len(t.steps) > 3 for t in tapes), [len(t.steps) for t in tapes]     # the hook cut the tape into segments
+    assert nsend[-1] >= 8, nsend
+    # eager walks raise the flag after every side launch; a replayed walk must wait about as often (not once)
+    assert nwait[-1] >= max(2, nwait[0] // 2), (nwait, nsend)
+    assert torch.equal(grads[3], grads[4])
+    monkeypatch.setattr(BW, "FORCE_EAGER", True)          # the same walk once more, eagerly, with the same hook
+    opt.zero_grad()
+    y = g(x)
+    with opt.overlap(None, bucket_mb=0.25, reduce_fn=lambda lo, hi: None):
+        ((y - tgt) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(opt.grad, grads[4])
+    _report("taped_walk_side_joins", {"sends_per_walk": nsend, "real_joins_per_walk": nwait, "tape_steps": [len(t.steps) for t in tapes]})
 
 
 def test_overlapped_allreduce_on_rccl_one_rank_group():

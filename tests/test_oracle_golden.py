@@ -410,3 +410,23 @@ def test_legacy_dehaze_matches_golden(golden_dir, manifest):
         yo = legacy_ref.dehaze_forward(sd, x.clone(), False)
     for nm, t in zip(("dehaze", "tran", "atp", "dehaze2"), yo[:4]):
         assert float((t[:, :, ::8, ::8] - torch.from_numpy(g[nm + "_eval"])).abs().max()) < 1e-4, nm
+
+
+def test_oracle_training_step_learns_on_a_fixed_batch():
+    """VERDICT r4 next #7 (b), oracle side: the loss composition of the training step is this repository's reconstruction (the
+    reference ships no training loop), so nothing pins it except that it TRAINS.  Thirty oracle steps on one fixed batch
+    (2 x 64 x 64): L1 falls by more than 30 %, SSIM rises, every term stays finite.  (The HIP path is held to the same, and to the
+    oracle's trajectory, in tests/test_hip_models.py::test_training_trajectory_matches_oracle_and_learns.)"""
+    import math
+    import torch
+    from oracle.train_ref import TrainStepRef
+    from oracle.detweights import det_input
+    torch.manual_seed(3)
+    ref = TrainStepRef()
+    gt = det_input((2, 3, 64, 64), seed=5)
+    haze = (gt * 0.6 + 0.3).clamp(0, 1)
+    traj = [ref.step(haze, gt) for _ in range(30)]
+    assert all(math.isfinite(v) for r in traj for v in r.values())
+    assert traj[-1]["l1"] < 0.7 * traj[0]["l1"], (traj[0]["l1"], traj[-1]["l1"])
+    assert traj[-1]["ssim"] > traj[0]["ssim"] + 0.1, (traj[0]["ssim"], traj[-1]["ssim"])
+    assert min(r["l1"] for r in traj[10:]) < 0.6 * traj[0]["l1"]
