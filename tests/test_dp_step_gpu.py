@@ -160,7 +160,16 @@ def test_bench_py_plain_python_launches_its_own_ranks(gpus):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
            "--batch", "2", "--size", "64", "--no-forward-leg", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
+    if out.returncode != 0:      # the launcher's summary (SIGTERMs of the surviving ranks) hides the first failure: show the tracebacks
+        err = out.stderr.splitlines()
+        first = [i for i, ln in enumerate(err) if "Traceback" in ln or "Error" in ln][:6]
+        excerpt = "\n".join("\n".join(err[max(0, i - 2):i + 12]) for i in first[:3])
+        try:
+            with open(os.path.join(root, "gpurun_out", "bench_ranks%d_stderr.txt" % gpus), "w") as f:
+                f.write(out.stderr)
+        except OSError:
+            pass
+        assert False, excerpt[-6000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])

@@ -168,6 +168,10 @@ def main():
     if a.suite == "mfma_ab":
         ab_suite(MFMA_SHAPES, variants=tuple(a.variants.split(",")))
         return
+    if a.suite == "mfma":      # the MFMA-bound shapes, `--reps` launches back to back each (sustained clocks: a 20-launch run is still ramping up)
+        for cfg in MFMA_SHAPES:
+            print(json.dumps(run(reps=a.reps or 300, **cfg)), flush=True)
+        return
     if a.suite:
         for cfg in SUITES[a.suite]:
             print(json.dumps(run(**cfg)), flush=True)
