@@ -127,6 +127,135 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(C1FwdArgs a) {
   if (oy < a.Ho && ox < a.Wo) a.y[(long long)n * a.y_sn + (long long)oy * a.y_sh + ox] = fmaxf(acc, a.e_slope * acc);
 }
 
+// ---- round 5: the same one-filter convolution on the matrix pipe, "taps as output channels" -------------------------------------
+// conv_cout1_kernel above is bound by LDS reads (every output pixel re-reads its KS^2 x C window: 9 KB of ds_read_b128 per
+// pixel, 123 us for the 148 MB of D's 127 x 127 x 288 input at B = 16).  Read the sum the other way round:
+//     s[q][tap] = sum_c a[q][c] * w[tap][c]          for every INPUT pixel q: a 1x1 convolution with KS^2 <= 16 "output channels"
+//     y[p]      = sum_(ky,kx) s[p + (ky,kx) - pad][ky KS + kx]                       a gather of KS^2 values per output pixel
+// The first line is one v_mfma_f32_16x16x32_f16 per 16 pixels x 32 channels with the (zero-extended) taps as the 16 rows of the A
+// operand -- no halo in the heavy part, every activation multiplied exactly once -- and its B fragments come straight from HBM in
+// conv1x1_xs's "x-stream" form: lane (m, g) reads 32 contiguous bytes (channels 64 ks + 16 g .. + 15) of pixel m, so four lanes
+// consume one 128-byte line (the filter is laid out for that k order once per workgroup).  The second line reads fp32 sums from
+// LDS ([row][tap][column]: consecutive lanes, consecutive words).  Workgroup = (image, band of C1M_R output rows, block of <= 128
+// input columns); its R + KS - 1 input rows are 8 x (R + KS - 1) units of 16 pixels, spread over 8 waves, each unit's 2 nks loads
+// requested one unit ahead.  Only the band's KS - 1 halo rows are read twice (1.375x at R = 8; the old tile re-read 1.5x).
+constexpr int C1M_R = 8, C1M_CW = 128;
+template <int KS, int NKS>
+__global__ __launch_bounds__(512) void conv_cout1_mfma_kernel(C1FwdArgs a) {
+  constexpr int KK = KS * KS, IR = C1M_R + KS - 1, CSTEP = C1M_CW - (KS - 1), NUNIT = IR * (C1M_CW / 16), UPW = (NUNIT + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) char c1_lds[];
+  float* s_lds = reinterpret_cast<float*>(c1_lds);                       // [IR][16][CW] fp32
+  char* w_lds = c1_lds + IR * 16 * C1M_CW * 4;                           // [NKS][2][64 lanes][16 B]: A fragments, x-stream k order
+  float* sc_lds = reinterpret_cast<float*>(w_lds + NKS * 2 * 1024);      // [NKS * 64] scale, shift
+  float* sh_lds = sc_lds + NKS * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  int blk = blockIdx.x;
+  const int cb = blk % a.tiles_x;
+  blk /= a.tiles_x;
+  const int band = blk % a.tiles_y, n = blk / a.tiles_y;
+  const int oy0 = band * C1M_R, cx0 = cb * CSTEP;      // first output row; first input column of the block
+  // ---- once per workgroup: per-channel scale / shift, the filter as A fragments (taps >= KS^2 and channels >= Cin: zero)
+  for (int c = tid; c < NKS * 64; c += 512) {
+    float sc = 1.f, sh = 0.f;
+    if (a.pro_mode == 2) {
+      sc = 0.f;
+      if (c < a.Cin) {
+        const float gm = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+        sc = gm / sqrtf(a.var[c] + a.eps);
+        sh = bt - a.mean[c] * sc;
+      }
+    }
+    sc_lds[c] = sc, sh_lds[c] = sh;
+  }
+  for (int i = tid; i < NKS * 2 * 64 * 8; i += 512) {
+    const int e = i & 7, l = (i >> 3) & 63, j = (i >> 9) & 1, ks = i >> 10;
+    const int tap = l & 15, c = ks * 64 + (l >> 4) * 16 + j * 8 + e;
+    const bool ok = tap < KK && c < a.Cin;
+    // packed chunk32 image of the [1][Cin][KS][KS] filter: (chunk, tap) fragments of 512 elements, cout row 0 = lanes 0, 16, 32, 48
+    const unsigned short v = a.w[ok ? ((long long)((c >> 5) * KK + tap) * 512 + (((c >> 3) & 3) * 16) * 8 + (c & 7)) : 0];
+    reinterpret_cast<unsigned short*>(w_lds)[i] = ok ? v : (unsigned short)0;
+  }
+  __syncthreads();
+  constexpr bool WREG = NKS <= 5;      // the A fragments live in registers (40) or are re-read from LDS per unit (NKS = 8: 64 would spill)
+  u32x4 wf[WREG ? NKS : 1][2];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[ks][j] = lds_read16(w_lds + ((ks * 2 + j) * 64 + lane) * 16);
+  }
+  const int cmax = ((a.Cin + 7) / 8) * 8;
+  const unsigned short* xn = a.x + (long long)n * a.x_sn;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // unit u = wave + 8 k: input row ir = u / 8 of the band, 16-pixel tile u % 8; this lane's pixel (gy, gx)
+  u32x4 cur[NKS][2], nxt[NKS][2];
+  auto unit_off = [&](int u, bool& inb) -> long long {
+    const int ir = u >> 3, t = u & 7;
+    const int gy = oy0 - a.pad + ir, gx = cx0 + t * 16 + m;
+    inb = u < NUNIT && gy >= 0 && gy < a.H && gx < a.W;
+    return inb ? (long long)gy * a.x_sh + (long long)gx * a.x_sw : 0;
+  };
+  auto fetch = [&](u32x4 (&dst)[NKS][2], long long off) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = ks * 64 + g * 16 + j * 8;
+        dst[ks][j] = *reinterpret_cast<const u32x4*>(xn + off + (c < cmax ? c : 0));      // past Cin: chunk 0 (its weights are zero)
+      }
+  };
+  bool inb_c, inb_n;
+  long long off_c = unit_off(wave, inb_c);
+  fetch(cur, off_c);
+#pragma unroll 1
+  for (int k = 0; k < UPW; ++k) {
+    const int u = wave + 8 * k;
+    const long long off_n = unit_off(u + 8, inb_n);
+    fetch(nxt, off_n);                                  // (unconditional: a clamped address, masked below)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = ks * 64 + g * 16 + j * 8;
+        u32x4 v = cur[ks][j];
+        if (a.pro_mode != 0) v = fd_xform8(v, sc_lds + c, sh_lds + c, a.slope);
+        v = (inb_c && c < cmax) ? v : zero4;            // zero padding is post-activation; pixels outside the image contribute nothing
+        const u32x4 wfr = WREG ? wf[WREG ? ks : 0][j] : lds_read16(w_lds + ((ks * 2 + j) * 64 + lane) * 16);
+        acc = fd_mfma<FmtA>(wfr, v, acc);
+      }
+    if (u < NUNIT) {
+      const int ir = u >> 3, t = u & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_lds[(ir * 16 + g * 4 + r) * C1M_CW + t * 16 + m] = acc[r];
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) cur[ks][j] = nxt[ks][j];
+    inb_c = inb_n;
+  }
+  __syncthreads();
+  // ---- the gather: this block owns the outputs whose window starts at input column ws = ox - pad in [cx0, cx0 + CSTEP) (block 0: from -pad)
+  const int ox_lo = cb == 0 ? 0 : cx0 + a.pad, ox_hi = min(a.Wo, cx0 + CSTEP + a.pad);
+  const int ncol = ox_hi - ox_lo, nrow = min(C1M_R, a.Ho - oy0);
+  for (int i = tid; i < nrow * ncol; i += 512) {
+    const int ly = i / ncol, ox = ox_lo + (i - ly * ncol);
+    const int wsl = ox - a.pad - cx0;                  // window start, local column (-pad .. CSTEP - 1)
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int lc = wsl + kx;
+        const float v = s_lds[((ly + ky) * 16 + ky * KS + kx) * C1M_CW + (lc >= 0 && lc < C1M_CW ? lc : 0)];
+        acc += (lc >= 0 && lc < C1M_CW) ? v : 0.f;       // columns left of the image (block 0) and right of the block's 128 (image edge) are padding
+      }
+    a.y[(long long)n * a.y_sn + (long long)(oy0 + ly) * a.y_sh + ox] = fmaxf(acc, a.e_slope * acc);
+  }
+}
+
 struct C1BwdArgs {
   const unsigned short* dy;    // NHWC bf16 view, channel 0 used
   long long dy_sn;
@@ -399,6 +528,30 @@ int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* 
   c.w = a.w, c.pro_mode = a.pro_mode, c.slope = a.p_slope, c.eps = a.eps;
   c.mean = a.p_mean, c.var = a.p_var, c.gamma = a.p_gamma, c.beta = a.p_beta;
   c.y = static_cast<float*>(a.y), c.y_sn = a.y_sn, c.y_sh = a.y_sh, c.Ho = a.Ho, c.Wo = a.Wo, c.pad = a.pad, c.e_slope = a.e_slope;
+  // the matrix-pipe form (taps as output channels) for up to 512 input channels; FDGAN_DEBUG_C1_OLD (tuning builds) keeps the dot-product kernel
+  if (a.Cin <= 512 && a.Wo >= 1 && FD_TUNE_GETENV("FDGAN_DEBUG_C1_OLD") == nullptr) {
+    const int nks = a.Cin <= 320 ? 5 : 8, cstep = C1M_CW - (ksize - 1);
+    c.tiles_x = (a.Wo - 1 - a.pad < 0 ? 0 : (a.Wo - 1 - a.pad) / cstep) + 1;      // column blocks: window starts -pad .. Wo - 1 - pad
+    c.tiles_y = (a.Ho + C1M_R - 1) / C1M_R;
+    const unsigned lds_m = (unsigned)((C1M_R + ksize - 1) * 16 * C1M_CW * 4 + nks * 2 * 1024 + nks * 64 * 8);
+    dim3 grid_m((unsigned)(nimg * c.tiles_x * c.tiles_y));
+    if (info) {
+      info->stats_rows = 0, info->stats_cpad = 0, info->grid_x = grid_m.x, info->grid_y = 1, info->lds_bytes = lds_m;
+    }
+    if (dry) return FD_OK;
+    static bool attr_m = false;
+    if (!attr_m) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_m = true;
+    }
+    if (ksize == 4) return nks == 5 ? fd_launch(&conv_cout1_mfma_kernel<4, 5>, "conv4x4_cout1", grid_m, dim3(512), lds_m, c, stream)
+                                    : fd_launch(&conv_cout1_mfma_kernel<4, 8>, "conv4x4_cout1", grid_m, dim3(512), lds_m, c, stream);
+    return nks == 5 ? fd_launch(&conv_cout1_mfma_kernel<3, 5>, "conv3x3_cout1", grid_m, dim3(512), lds_m, c, stream)
+                    : fd_launch(&conv_cout1_mfma_kernel<3, 8>, "conv3x3_cout1", grid_m, dim3(512), lds_m, c, stream);
+  }
   c.tiles_x = (a.Wo + C1_TW - 1) / C1_TW, c.tiles_y = (a.Ho + C1_TH - 1) / C1_TH;
   const int ih = C1_TH + ksize - 1, iw = C1_TW + ksize - 1, npixr = (ih * iw + 15) / 16 * 16;
   const unsigned lds = 2u * 4 * npixr * 16 + 2u * ksize * ksize * 64 + a.nchunk * 32 * 8;

@@ -261,6 +261,12 @@ def test_discriminator_convs(E):
     _run(E, 2, 32, 32, 36, 72, 3, pad=1, p_act=ACT_LEAKY02, stats=True, pitch_in=40, seed=16)
     _run(E, 1, 17, 19, 144, 288, 4, pad=1, bn=True, p_act=ACT_LEAKY02, seed=17)            # odd sizes (127-like)
     _run(E, 1, 16, 18, 288, 1, 4, pad=1, p_act=ACT_LEAKY02, e_act=ACT_SIGMOID, nchw_out=True, seed=18)
+    # the one-filter conv on the matrix pipe (round 5, conv_cout1_mfma_kernel): two column blocks and three row bands with ragged ends,
+    # 512 channels (A fragments from LDS) behind a BatchNorm prologue, and the 3x3 form
+    _run(E, 2, 21, 140, 288, 1, 4, pad=1, p_act=ACT_LEAKY02, nchw_out=True, seed=181)
+    _run(E, 1, 31, 31, 512, 1, 4, pad=1, bn=True, p_act=ACT_LEAKY02, e_act=ACT_SIGMOID, nchw_out=True, seed=182)
+    _run(E, 1, 20, 130, 64, 1, 3, pad=1, p_act=ACT_RELU, nchw_out=True, seed=183)
+    _run(E, 3, 127, 127, 288, 1, 4, pad=1, p_act=ACT_LEAKY02, e_act=ACT_SIGMOID, nchw_out=True, seed=184)
 
 
 def test_plan_replay_matches_eager(E):
