@@ -1023,6 +1023,9 @@ int wgrad_cout1_launch(const FdTensor* x, const FdTensor* dy, int ksize, int str
                        long long workspace_floats, long long* nsplit_out, hipStream_t stream);
 int dgrad_cout1_launch(const FdTensor* dy, const void* w_packed_flipped, const FdTensor* fwd_x, const FdPrologue* fwd_pro, const FdTensor* dpre,
                        int accumulate, const FdConvDesc* d, hipStream_t stream);
+// the image-reading first layers (3 -> 64 3x3, 9 -> 36 4x4 stride 2): k = (tap, channel) with the channels padded to 4 / 16 (conv_sc.hip)
+int conv_sc_variant(const ConvArgs& a, int cout_total, int ksize, int stride, bool pool);
+int conv_sc_launch(int variant, ConvArgs& a, long long nimg, FdConvInfo* info, long long stats_cap, bool dry, hipStream_t stream);
 extern unsigned long long* g_fd_debug_timing;
 // tanh / sigmoid applied in place on what a conv stored (elementwise.hip)
 int fd_act_inplace(const FdTensor* y, int act, hipStream_t stream);

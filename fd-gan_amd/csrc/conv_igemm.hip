@@ -27,6 +27,7 @@ static int conv_dispatch(ConvArgs& a, long long nimg, int cout_total, int ksize,
   }
   if (w_layout != FD_WLAYOUT_CHUNK32) FD_FAIL(FD_EINVAL, "conv2d: unknown weight layout %d", w_layout);
   if (conv_cout1_fits(a, cout_total, ksize, stride, pool)) return conv_cout1_launch(a, nimg, ksize, info, dry, stream);
+  if (const int sc = conv_sc_variant(a, cout_total, ksize, stride, pool)) return conv_sc_launch(sc, a, nimg, info, stats_cap, dry, stream);
   switch (ksize) {
     case 1: return conv_dispatch_k1(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);
     case 3: return conv_dispatch_k3(a, nimg, cout_total, stride, pool, info, stats_cap, dry, stream);

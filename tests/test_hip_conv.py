@@ -256,6 +256,15 @@ def test_first_and_last_conv(E):
     _run(E, 2, 32, 32, 16, 3, 3, pad=1, bias=True, e_act=ACT_TANH, nchw_out=True, seed=14)
 
 
+def test_image_reading_first_layers_small_cin_kernel(E):
+    """csrc/conv_sc.hip (round 5): k = (tap, channel) with 4 / 16 channels per tap instead of one 32-channel chunk per tap."""
+    _run(E, 1, 37, 45, 3, 64, 3, pad=1, bias=True, e_act=ACT_RELU, stats=True, pitch_out=256, seed=131)   # ragged tiles, slice of a concat buffer
+    _run(E, 2, 64, 64, 3, 64, 3, pad=1, bias=True, e_act=ACT_RELU, seed=132)                              # VGG16 conv1_1
+    _run(E, 1, 70, 66, 9, 36, 4, stride=2, pad=1, pitch_in=16, seed=133)                                   # D layer1, ragged
+    _run(E, 1, 32, 32, 12, 40, 4, stride=2, pad=1, pitch_in=16, stats=True, seed=134)
+    _run(E, 1, 16, 16, 4, 48, 3, pad=1, seed=135)
+
+
 def test_discriminator_convs(E):
     _run(E, 2, 64, 64, 9, 36, 4, stride=2, pad=1, pitch_in=16, seed=15)                    # D layer1
     _run(E, 2, 32, 32, 36, 72, 3, pad=1, p_act=ACT_LEAKY02, stats=True, pitch_in=40, seed=16)

@@ -47,5 +47,26 @@ def main():
     print(json.dumps({"op": "forward 288 -> 1 4x4 @127^2 n16", "kernel": name, "us": round(us, 1), "input_MB": round(mb, 1), "TB/s": round(mb / us, 2)}))
 
 
+def first_layers(reps):
+    """The image-reading first layers (csrc/conv_sc.hip): 3 -> 64 3x3 @256^2 and 9 -> 36 4x4 stride 2 @256^2, B = 16."""
+    dev = torch.device("cuda:0")
+    for (cin, pitch, cout, k, st, hw, name) in ((3, 8, 64, 3, 1, 256, "3 -> 64 3x3 @256^2"), (9, 16, 36, 4, 2, 256, "9 -> 36 4x4 s2 @256^2")):
+        x = (torch.randn(16, hw, hw, pitch, device=dev) * 0.7).to(torch.float16)
+        x[..., cin:] = 0
+        wt = torch.randn(cout, cin, k, k, device=dev) * 0.1
+        pw = E.PackedWeight(wt, cout, cin, k, stride=st)
+        pw.pack()
+        ho = (hw + 2 - k) // st + 1
+        cst = (cout + 7) // 8 * 8
+        y = torch.empty(16, ho, ho, cst, dtype=torch.float16, device=dev)
+        desc = E.conv_desc(k, st, 1, L.ACT_RELU, False, cout=cout, w_layout=pw.layout)
+        b = torch.randn(cout, device=dev)
+        xv, yv = E.View(x, 0, cin), E.View(y, 0, (cout + 3) // 4 * 4)
+        us, kn = timed(lambda: E.conv2d(xv.fd, pw, b, None, yv.fd, desc, None), reps)
+        mb = (x.numel() + y.numel()) * 2 / 1e6
+        print(json.dumps({"op": name + " n16", "kernel": kn, "us": round(us, 1), "MB": round(mb, 1), "TB/s": round(mb / us, 2)}))
+
+
 if __name__ == "__main__":
     main()
+    first_layers(int(sys.argv[1]) if len(sys.argv) > 1 else 100)
