@@ -908,7 +908,13 @@ int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   if (strips * item_stride > workspace_floats || strips >= 65536) return 1;
   static const char* wgs_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
   const long long base = strips * ci_tiles * zt;
-  long long segs = (wgs_env ? atoll(wgs_env) : 256) / base;   // one resident workgroup per CU
+  // one resident workgroup per CU -- but never fewer than 8 rows per item: every item writes a 147 KB partial (and the reduction reads
+  // it back) whatever it covers, so at 64 x 64 (B = 16: 1024 rows) 256 items move 37.7 MB of partials for 21 MB of data; 128 items of
+  // 8 rows measured 26.4 us against 27.7 (kernel + reduction, tools/wgrad_one.py) for half of that traffic.  At 128 x 128 and above the
+  // 256-item split stays faster (39.6 vs 47.6 us).
+  long long want = wgs_env ? atoll(wgs_env) : 256;
+  if (!wgs_env && strips * ci_tiles * zt * a.Ho <= 1024) want = 128;
+  long long segs = want / base;
   if (segs < 1) segs = 1;
   if (segs > (a.Ho + 3) / 4) segs = (a.Ho + 3) / 4;             // two of a segment's steps only see one or two of its rows
   while (segs > 1 && (strips * segs * item_stride > workspace_floats || strips * segs >= 65536)) --segs;
