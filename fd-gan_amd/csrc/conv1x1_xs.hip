@@ -171,15 +171,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv1x1_xs_kernel(ConvArgs a) {
           const bool ok = cok && (full || px0 + p * 16 < a.P);
           xf[p] = __builtin_bit_cast(f16x8, ok ? v : zero4);
         }
-        if (!last) {
-          load(ks + 1, j);
-        } else if (has_next) {
-          if (j == 0) {   // re-target the source offsets; this tile issues no further loads
+        // The next fragments are requested UNCONDITIONALLY (round 5): inside `if (!last) ... else if (has_next) ...` the loads sat in
+        // conditional blocks, hipcc drained them at the end of each block (s_waitcnt vmcnt(0) right behind the loads: tools/
+        // loop_wait_audit.py) and this "prefetch" overlapped nothing.  The last k-step of the last tile re-reads its own first
+        // k-step (a valid address, never used).
+        if (last && j == 0) {   // re-target the source offsets (no loads in this block); this tile issues no further loads
+          const unsigned tn = has_next ? tnext : tile;
 #pragma unroll
-            for (int p = 0; p < PT; ++p) xoff[p] = x_offset(tnext * C::TILE_PX + wave * C::WPX + p * 16 + m);
-          }
-          load(0, j);
+          for (int p = 0; p < PT; ++p) xoff[p] = x_offset(tn * C::TILE_PX + wave * C::WPX + p * 16 + m);
         }
+        load(last ? 0 : ks + 1, j);
         constexpr int CH = CT > 4 ? 4 : CT;  // filter fragments live at a time
 #pragma unroll
         for (int c0 = 0; c0 < CT; c0 += CH) {

@@ -1322,6 +1322,12 @@ extern "C" int fdgan_bn_bwd_finalize(const float* partial, int64_t rows, int64_t
 }
 
 static int launch_sum_finalize(SumFinArgs a, float* scratch, int64_t scratch_floats, FdStream stream) {
+  {  // measurement aid (tuning builds; results wrong): after N finalize launches skip them all -- what do these single-workgroup launches
+     // cost the step IN PLACE, queued behind the side stream's workgroups at every boundary?  (upper bound for any scheme that removes them)
+    static const char* skip = FD_TUNE_GETENV("FDGAN_DEBUG_SKIP_FINALIZE");
+    static long long calls = 0;
+    if (skip && ++calls > atoll(skip)) return FD_OK;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 cgrid((unsigned)((a.channels + 31) / 32));
   constexpr int SLICES = 32;

@@ -126,18 +126,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(WgSmallArgs a) {
       bool okv[WS_CH];
 #pragma unroll
       for (int k = 0; k < WS_CH; ++k) {
+        // (round 5) every unit loads UNCONDITIONALLY from a clamped address and is zeroed by a select: with the loads inside
+        // `if (pok)` / `if (okv)` blocks hipcc drained each one at the end of its block (tools/loop_wait_audit.py: 22 loads per
+        // tile followed by s_waitcnt vmcnt(0)) -- the "round of loads in flight" was one load in flight
         const int mt = __builtin_amdgcn_readfirstlane(mrow[rd * WS_CH + k]);
-        raw[k] = u32x4{0u, 0u, 0u, 0u};
-        okv[k] = false;
-        if (!(mt & 1)) continue;
-        if (mt & 2) {
-          okv[k] = pok;
-          if (pok) raw[k] = *reinterpret_cast<const u32x4*>(dyp + ((mt >> 12) & 15) * 8);
-        } else {
-          const int iy = iy0 + ((mt >> 4) & 15), ix = ix0 + ((mt >> 8) & 15);
-          okv[k] = pok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-          if (okv[k]) raw[k] = *reinterpret_cast<const u32x4*>(ximg + ((long long)iy * a.x_sh + (long long)(ix * a.x_sw + ((mt >> 12) & 15) * 8)));
-        }
+        const bool valid = (mt & 1) != 0, isdy = (mt & 2) != 0;
+        const int iy = iy0 + ((mt >> 4) & 15), ix = ix0 + ((mt >> 8) & 15);
+        const bool okx = pok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        okv[k] = valid && (isdy ? pok : okx);
+        const unsigned short* srcx = ximg + (okx ? ((long long)iy * a.x_sh + (long long)(ix * a.x_sw + ((mt >> 12) & 15) * 8)) : 0);
+        const unsigned short* srcd = dyp + (valid && isdy ? ((mt >> 12) & 15) * 8 : 0);      // dyp itself is clamped to pixel 0 when !pok
+        const u32x4 v = *reinterpret_cast<const u32x4*>(valid && !isdy ? srcx : srcd);
+        raw[k] = okv[k] ? v : u32x4{0u, 0u, 0u, 0u};
       }
 #pragma unroll
       for (int k = 0; k < WS_CH; ++k) {

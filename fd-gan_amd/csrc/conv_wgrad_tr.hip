@@ -117,7 +117,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   int xdst[C::XK];
 #pragma unroll
   for (int k = 0; k < C::XK; ++k) xdst[k] = C::xoff(xpix0 + XPSTEP * k, xchunk >> 1) + ((xchunk & 1) << 4);
-  u32x4 xr[C::XK], dr[DK];
+  // two register sets: the rows of step y + 2 are requested while step y computes (round 5: with ONE set, requested at the top of a
+  // step and stored at its end, every step waited out a whole memory latency -- 36 MFMAs of work against ~2 us -- MFMA busy 0.14)
+  u32x4 xrA[C::XK], drA[DK], xrB[C::XK], drB[DK];
+  unsigned xokA = 0, xokB = 0;
   // bias gradient = per-channel sum of dy: the workgroups of cin slice 0 / filter-row group 0 add up the dy rows they stage
   const bool want_bias = a.bias_part != nullptr && blockIdx.x == 0 && ky0 == 0;
   float bs[DK][8];
@@ -125,44 +128,39 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   for (int k = 0; k < DK; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[k][e] = 0.f;
-  unsigned xok = 0;   // bit k: xr[k] holds raw data (else the unit is zero padding)
-  auto load_x_row = [&](int row) __attribute__((always_inline)) {
+  // bit k of xok: xr[k] holds raw data (else the unit is zero padding).  Loads are unconditional from a clamped address (a load
+  // behind a branch is waited for at the join: DESIGN.md, status round 4 #7); the mask decides what the store writes.
+  auto load_x_row = [&](int row, u32x4 (&xr)[C::XK], unsigned& xok) __attribute__((always_inline)) {
     xok = 0;
     const bool rok = row >= 0 && row < a.H && xc_ok;
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       const int pix = xpix0 + XPSTEP * k, px = xbase - a.pad + pix;
-      xr[k] = zero4;
-      if (rok && px >= 0 && px < a.W && pix < C::XPIX) {
-        xr[k] = *reinterpret_cast<const u32x4*>(ximg + (long long)row * a.x_sh + (long long)px * a.x_sw);
-        xok |= 1u << k;
-      }
+      const bool ok = rok && px >= 0 && px < a.W && pix < C::XPIX;
+      xr[k] = *reinterpret_cast<const u32x4*>(ximg + (ok ? (long long)row * a.x_sh + (long long)px * a.x_sw : 0));
+      xok |= ok ? 1u << k : 0u;
     }
   };
-  auto store_x_row = [&](int row) __attribute__((always_inline)) {
+  auto store_x_row = [&](int row, const u32x4 (&xr)[C::XK], unsigned xok) __attribute__((always_inline)) {
     char* slot = Xs + ((unsigned)(row - row_off) % C::XSLOTS) * C::XROW_B;
 #pragma unroll
     for (int k = 0; k < C::XK; ++k) {
       if (xpix0 + XPSTEP * k >= C::XPIX) break;
-      u32x4 v = xr[k];
-      if ((xok >> k) & 1) {
-        v = fd_xform8<FmtA, FmtG>(v, sc_s + xchunk * 8, sh_s + xchunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);   // fp16 x -> bf16 operand
-      } else {
-        v = zero4;   // zero padding of the ACTIVATED input
-      }
+      u32x4 v = fd_xform8<FmtA, FmtG>(xr[k], sc_s + xchunk * 8, sh_s + xchunk * 8, a.pro_mode != 0 ? a.p_slope : 1.f);   // fp16 x -> bf16 operand
+      v = ((xok >> k) & 1) ? v : zero4;   // zero padding of the ACTIVATED input (a select, not a branch)
       lds_write16(slot + xdst[k], v);
     }
   };
-  auto load_d_row = [&](int row) __attribute__((always_inline)) {
+  auto load_d_row = [&](int row, u32x4 (&dr)[DK]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
       const int dpix = (tid + k * C::NT) >> 2;
-      dr[k] = zero4;
-      if (dpix < G3_PB && dc_ok && row < y_end && xbase + dpix < a.Wo)
-        dr[k] = *reinterpret_cast<const u32x4*>(dimg + (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw);
+      const bool ok = dpix < G3_PB && dc_ok && row < y_end && xbase + dpix < a.Wo;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dimg + (ok ? (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw : 0));
+      dr[k] = ok ? v : zero4;
     }
   };
-  auto store_d_row = [&](int row) __attribute__((always_inline)) {
+  auto store_d_row = [&](int row, const u32x4 (&dr)[DK]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
       const int dpix = (tid + k * C::NT) >> 2;
@@ -185,21 +183,31 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
 
   // input rows of the first output row, and its dy row
   for (int r = y_begin + row_off; r < y_begin + row_off + KYN; ++r) {
-    load_x_row(r);
-    store_x_row(r);
+    load_x_row(r, xrA, xokA);
+    store_x_row(r, xrA, xokA);
   }
-  load_d_row(y_begin);
-  store_d_row(y_begin);
+  load_d_row(y_begin, drA);
+  store_d_row(y_begin, drA);
   __syncthreads();
-
-  for (int y = y_begin; y < y_end; ++y) {
-    if (!(a.dbg_skip & 4)) {
-      load_x_row(y + row_off + KYN);   // in flight during this row's MFMAs
-      load_d_row(y + 1);
-    }
+  // step y computes output row y from the staged rows, stores the rows of step y + 1 (requested in step y - 1, set A / B by parity)
+  // and requests those of step y + 2
+  // DEPTH 2 (two register sets) where the registers are there; the 9-wave 4x4 instantiation (168 registers per lane) keeps one set:
+  // its rows are requested at the top of the step that stores them (DEPTH 1) -- still without a branch between request and store
+  constexpr int DEPTH = NW <= 8 ? 2 : 1;
+  if constexpr (DEPTH == 2) {
+    load_x_row(y_begin + row_off + KYN, xrA, xokA);
+    load_d_row(y_begin + 1, drA);
+  }
+  auto step = [&](int y, u32x4 (&xs)[C::XK], unsigned& xoks, u32x4 (&ds)[DK], u32x4 (&xn)[C::XK], unsigned& xokn, u32x4 (&dn)[DK]) __attribute__((always_inline)) {
+    // NO control flow between these requests and the stores that consume them a step later: hipcc waits for a load at the end of
+    // the conditional block it sits in (the first version had `if (!(a.dbg_skip & 4))` here and `vmcnt(0)` right behind the loads:
+    // every step began by waiting out the latency of the rows it had just asked for -- MFMA busy 0.14)
+    load_x_row(y + DEPTH - 1 + row_off + KYN, xn, xokn);   // in flight during this row's (DEPTH 2: AND the next row's) MFMAs
+    load_d_row(y + DEPTH, dn);
     const char* dcur = Ds + (y & 1) * C::DROW_B;
-    if (!(a.dbg_skip & 2))
-    for (int sub = 0; sub < nsub; ++sub) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub >= nsub) break;
       const int pa = 32 * sub + kpix;
       const bf16x8 af0 = g3_frag(dcur + g3_doff(pa, 0) + piece, dcur + g3_doff(pa + 4, 0) + piece);
       const bf16x8 af1 = g3_frag(dcur + g3_doff(pa, 1) + piece, dcur + g3_doff(pa + 4, 1) + piece);
@@ -215,9 +223,20 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
         }
       }
     }
-    if (!(a.dbg_skip & 4)) store_x_row(y + row_off + KYN);   // its slot held the row above this step's first: last read one barrier ago
-    store_d_row(y + 1);
-    __syncthreads();
+    store_x_row(y + row_off + KYN, xs, xoks);   // its slot held the row above this step's first: last read one barrier ago
+    store_d_row(y + 1, ds);
+    // LDS-only barrier: __syncthreads() carries s_waitcnt vmcnt(0), which would wait for the rows just requested for step y + 2
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  // (both steps unconditionally: an `if (y + 1 < y_end)` around the second one is a conditional block with loads in it, drained at its
+  // end.  A step past the segment multiplies a dy row that was loaded as zeros -- `row < y_end` in load_d_row -- and adds nothing.)
+  if constexpr (DEPTH == 2) {
+    for (int y = y_begin; y < y_end; y += 2) {
+      step(y, xrA, xokA, drA, xrB, xokB, drB);
+      step(y + 1, xrB, xokB, drB, xrA, xokA, drA);
+    }
+  } else {
+    for (int y = y_begin; y < y_end; ++y) step(y, xrA, xokA, drA, xrA, xokA, drA);
   }
   if (want_bias) {   // after the loop's last barrier: the x slots are free
     float* red = reinterpret_cast<float*>(Xs);   // [64 pixels][32 channels]
