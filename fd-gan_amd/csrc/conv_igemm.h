@@ -977,6 +977,7 @@ struct WgradRowsArgs {
   float* bias_part;              // [items][cout tiles][32] per-item sums of dy (bias gradient) or NULL
   int dbg_skip;                  // FDGAN_DEBUG_PHASES (results wrong): 1 no partial stores, 2 no MFMA loop, 4 no staging in the row loop
   int vgx, vgy, vgz;             // conv_wgrad_r4: the logical (cin tile, item, cout slice) grid behind its 1-D XCD-aware launch
+  int zt;                        // conv_wgrad_tr: 32-filter groups x filter-row groups of the partial-sum layout (>= gridDim.z)
 };
 // streaming 1x1 data gradient + prologue backward (conv1x1_bwd.hip)
 bool conv1x1_bwd_fits(const FdTensor* dy, const FdTensor* fwd_x, const FdTensor* dpre);

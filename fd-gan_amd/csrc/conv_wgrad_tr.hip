@@ -36,7 +36,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // KS x KS stride-1 conv; a workgroup owns KYN filter rows (KYN * KS taps), NW 16-channel cin tiles (one per wave) and
 // 2 cout tiles (32 filters): 2 * KYN * KS accumulator tiles per wave
-template <int KS, int KYN, int NW>
+template <int KS, int KYN, int NW, int NCO = 2>
 struct G3Cfg {
   static constexpr int KK = KS * KS;
   static constexpr int TAPS = KYN * KS;
@@ -50,7 +50,8 @@ struct G3Cfg {
   static_assert(XOR_SWZ ? NW == 8 : (NW & 1) == 1, "bank-conflict-free layouts exist for 8 or an odd number of cin tiles");
   static constexpr int XROW_B = XPIX * XPB + (XOR_SWZ ? 0 : (XPIX / 8 + 1) * 128);
   static constexpr int XSLOTS = KYN + 1;                 // KYN rows in use + the row being written
-  static constexpr int DROW_B = G3_PB * 64;              // 32 filters x 2 B per pixel
+  static constexpr int DROW_B = G3_PB * NCO * 32;        // NCO x 16 filters x 2 B per pixel
+  static constexpr int DPP = NCO * 2;                    // 16-byte pieces per dy pixel
   static constexpr int SC_OFF = XSLOTS * XROW_B + 2 * DROW_B;
   static constexpr int LDS = SC_OFF + 2 * NW * 16 * 4;
   static constexpr int XUNITS = XPIX * NW * 2;           // 16-byte units per staged row
@@ -69,10 +70,23 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* p0, const char* p1) {
 __device__ __forceinline__ int g3_doff(int pix, int c16) {
   return pix * 64 + ((c16 ^ ((pix >> 3) & 1)) << 5);
 }
+// dy rows with NCO cout tiles: [pixel][NCO x 32 B].  NCO = 4 (round 5): a transpose read touches pixels {8 g + j} and {8 g + 4 + j}
+// (g < 4, j < 4) of ONE 32-byte group; at a 128-byte pitch pixels of equal parity share half a bank row, so the group is rotated by
+// ((pix >> 1) & 1) | ((pix >> 3) & 1) << 1: the four equal-parity pixels of a half-wave land in four different 32-byte bank groups.
+template <int NCO>
+__device__ __forceinline__ int g3_doffn(int pix, int c16) {
+  if constexpr (NCO == 2) return g3_doff(pix, c16);
+  else return pix * 128 + ((c16 ^ (((pix >> 1) & 1) | (((pix >> 3) & 1) << 1))) << 5);
+}
 
-template <int KS, int KYN, int NW>
+// NCO: cout tiles per workgroup.  2: the original split (32 filters, grid z = filter groups x filter-row groups).  4 (round 5, 3x3 only):
+// 64 filters per workgroup -- 13 fragment reads per 72 MFMAs instead of 11 per 36, and every input row is re-staged by half as many
+// filter groups (D's 72 -> 144: 3 instead of 5) -- whose partial sums are written as TWO 32-filter groups of the original layout, so
+// the reduction kernels do not know the difference.
+template <int KS, int KYN, int NW, int NCO = 2>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a) {
-  using C = G3Cfg<KS, KYN, NW>;
+  using C = G3Cfg<KS, KYN, NW, NCO>;
+  static_assert(NCO == 2 || (NCO == 4 && KS == KYN), "64-filter workgroups: all filter rows in one workgroup");
   extern __shared__ __attribute__((aligned(16))) char g3_lds[];
   char* Xs = g3_lds;
   char* Ds = g3_lds + C::XSLOTS * C::XROW_B;
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   float* sh_s = sc_s + NW * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int KYG = KS / KYN;   // filter-row groups
-  const int ci0 = blockIdx.x * (NW * 16), co0 = ((int)blockIdx.z / KYG) * 32, ky0 = ((int)blockIdx.z % KYG) * KYN;
+  const int ci0 = blockIdx.x * (NW * 16), co0 = ((int)blockIdx.z / KYG) * (NCO * 16), ky0 = ((int)blockIdx.z % KYG) * KYN;
   const int row_off = ky0 - a.pad;   // input row of (output row y, local filter row ky) = y + row_off + ky
   const int item = blockIdx.y;                       // (image, column block, row segment)
   const int seg = item % a.segs, xb = (item / a.segs) % a.xblocks, n = item / (a.segs * a.xblocks);
@@ -108,9 +122,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   const int xchunk = tid % (2 * NW), xpix0 = tid / (2 * NW);
   constexpr int XPSTEP = C::NT / (2 * NW);   // 32
   const bool xc_ok = ci0 + xchunk * 8 < a.Cin;
-  static_assert(C::NT >= 256 || NW == 3, "dy row staging: 256 units");
-  constexpr int DK = C::NT >= 256 ? 1 : 2;        // dy units per thread (192 threads: 2 rounds, the second partly idle)
-  const int dpiece = tid & 3;
+  static_assert(C::NT % C::DPP == 0, "a thread's dy units share one 16-byte column");
+  constexpr int DUNITS = G3_PB * C::DPP;          // dy units per row: 256 (NCO = 2) / 512 (NCO = 4)
+  constexpr int DK = (DUNITS + C::NT - 1) / C::NT;   // dy units per thread (the last round partly idle)
+  const int dpiece = tid % C::DPP;
   const bool dc_ok = co0 + dpiece * 8 < a.Cout;
   const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0 + xchunk * 8;
   const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + co0 + dpiece * 8;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   auto load_d_row = [&](int row, u32x4 (&dr)[DK]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
-      const int dpix = (tid + k * C::NT) >> 2;
+      const int dpix = (tid + k * C::NT) / C::DPP;
       const bool ok = dpix < G3_PB && dc_ok && row < y_end && xbase + dpix < a.Wo;
       const u32x4 v = *reinterpret_cast<const u32x4*>(dimg + (ok ? (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw : 0));
       dr[k] = ok ? v : zero4;
@@ -163,8 +178,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   auto store_d_row = [&](int row, const u32x4 (&dr)[DK]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
-      const int dpix = (tid + k * C::NT) >> 2;
-      if (dpix < G3_PB) lds_write16(Ds + (row & 1) * C::DROW_B + g3_doff(dpix, dpiece >> 1) + ((dpiece & 1) << 4), dr[k]);
+      const int dpix = (tid + k * C::NT) / C::DPP;
+      if (dpix < G3_PB) lds_write16(Ds + (row & 1) * C::DROW_B + g3_doffn<NCO>(dpix, dpiece >> 1) + ((dpiece & 1) << 4), dr[k]);
       if (want_bias) {   // rows >= y_end were loaded as zeros
         const f32x8 f = __builtin_convertvector(__builtin_bit_cast(bf16x8, dr[k]), f32x8);
 #pragma unroll
@@ -176,9 +191,11 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   // ---- fragment addresses: lane (g, i): k rows 8 g + (i >> 2) (+ 4 for the second read), 4-channel piece i & 3
   const int g = lane >> 4, i = lane & 15;
   const int kpix = 8 * g + (i >> 2), piece = (i & 3) * 8;
-  f32x4 acc[C::TAPS][2];
+  f32x4 acc[C::TAPS][NCO];
 #pragma unroll
-  for (int t = 0; t < C::TAPS; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < C::TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsub = (min(G3_PB, a.Wo - xbase) + 31) / 32;
 
   // input rows of the first output row, and its dy row
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   // and requests those of step y + 2
   // DEPTH 2 (two register sets) where the registers are there; the 9-wave 4x4 instantiation (168 registers per lane) keeps one set:
   // its rows are requested at the top of the step that stores them (DEPTH 1) -- still without a branch between request and store
-  constexpr int DEPTH = NW <= 8 ? 2 : 1;
+  constexpr int DEPTH = (NW <= 8 && NCO == 2) ? 2 : 1;      // (64-filter workgroups: 144 accumulator registers, one staging set)
   if constexpr (DEPTH == 2) {
     load_x_row(y_begin + row_off + KYN, xrA, xokA);
     load_d_row(y_begin + 1, drA);
@@ -209,8 +226,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     for (int sub = 0; sub < 2; ++sub) {
       if (sub >= nsub) break;
       const int pa = 32 * sub + kpix;
-      const bf16x8 af0 = g3_frag(dcur + g3_doff(pa, 0) + piece, dcur + g3_doff(pa + 4, 0) + piece);
-      const bf16x8 af1 = g3_frag(dcur + g3_doff(pa, 1) + piece, dcur + g3_doff(pa + 4, 1) + piece);
+      bf16x8 af[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) af[c] = g3_frag(dcur + g3_doffn<NCO>(pa, c) + piece, dcur + g3_doffn<NCO>(pa + 4, c) + piece);
 #pragma unroll
       for (int ky = 0; ky < KYN; ++ky) {
         const char* slot = Xs + ((unsigned)(y + ky) % C::XSLOTS) * C::XROW_B;   // input row y + row_off + ky
@@ -218,8 +236,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
         for (int kx = 0; kx < KS; ++kx) {
           const int pb = pa + kx;   // staged pixel index = output pixel + kx (staged pixel 0 is x = xbase - pad)
           const bf16x8 bfr = g3_frag(slot + C::xoff(pb, wave) + piece, slot + C::xoff(pb + 4, wave) + piece);
-          acc[ky * KS + kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr, acc[ky * KS + kx][0], 0, 0, 0);
-          acc[ky * KS + kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr, acc[ky * KS + kx][1], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NCO; ++c)
+            acc[ky * KS + kx][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfr, acc[ky * KS + kx][c], 0, 0, 0);
         }
       }
     }
@@ -239,31 +258,41 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     for (int y = y_begin; y < y_end; ++y) step(y, xrA, xokA, drA, xrA, xokA, drA);
   }
   if (want_bias) {   // after the loop's last barrier: the x slots are free
-    float* red = reinterpret_cast<float*>(Xs);   // [64 pixels][32 channels]
+    constexpr int BC = NCO * 16;                 // this workgroup's filters
+    float* red = reinterpret_cast<float*>(Xs);   // [64 pixels][BC channels]
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
-      const int dpix = (tid + k * C::NT) >> 2;
+      const int dpix = (tid + k * C::NT) / C::DPP;
       if (dpix < G3_PB)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[dpix * 32 + dpiece * 8 + e] = bs[k][e];
+        for (int e = 0; e < 8; ++e) red[dpix * BC + dpiece * 8 + e] = bs[k][e];
     }
     __syncthreads();
-    if (tid < 32) {
+    if (tid < BC) {
       float t = 0.f;
-      for (int q = 0; q < G3_PB; ++q) t += red[q * 32 + tid];
-      a.bias_part[((long long)item * (gridDim.z / KYG) + blockIdx.z / KYG) * 32 + tid] = t;
+      for (int q = 0; q < G3_PB; ++q) t += red[q * BC + tid];
+      // [item][32-filter group][32]: this workgroup's NCO / 2 groups are consecutive (groups past the last filter are never read)
+      const long long grp = (long long)(blockIdx.z / KYG) * (NCO / 2) + (tid >> 5);
+      if (grp < a.zt / KYG) a.bias_part[((long long)item * (a.zt / KYG) + grp) * 32 + (tid & 31)] = t;
     }
   }
   // partial sums in accumulator order, [item][cin slice][z][wave][tap][cout tile][r][lane]: every store is 256
   // contiguous bytes (scattering them to [co][ci][tap] here cost 50 us per launch); wgrad_tr_reduce_kernel maps back
   if (!(a.dbg_skip & 1)) {
-    float* blk = a.part + ((((long long)item * gridDim.x + blockIdx.x) * gridDim.z + blockIdx.z) * NW + wave) * (C::TAPS * 512) + lane;
+    // the layout stays [item][cin slice][z: 32-filter group x filter-row group][wave][tap][2 cout tiles][r][lane]: a 64-filter
+    // workgroup writes its two halves as z = 2 blockIdx.z and 2 blockIdx.z + 1 (a.zt groups in all; the half past the last is skipped)
 #pragma unroll
-    for (int t = 0; t < C::TAPS; ++t)
+    for (int h = 0; h < NCO / 2; ++h) {
+      const int z = (int)blockIdx.z * (NCO / 2) + h;
+      if (z >= a.zt) break;
+      float* blk = a.part + ((((long long)item * gridDim.x + blockIdx.x) * a.zt + z) * NW + wave) * (C::TAPS * 512) + lane;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int t = 0; t < C::TAPS; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) blk[((t * 2 + ct) * 4 + r) * 64] = acc[t][ct][r];
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) blk[((t * 2 + ct) * 4 + r) * 64] = acc[t][h * 2 + ct][r];
+    }
   }
 }
 
@@ -870,25 +899,40 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_batch_kernel(TrBatchArgs 
   tr_reduce_group(job, (long long)blockIdx.x - job.first_group, sh);
 }
 
-template <int KS, int KYN, int NW>
+template <int KS, int KYN, int NW, int NCO = 2>
 int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long workspace_floats, float* dw, float* dbias, int accumulate,
               hipStream_t stream, const char* name, FdTrReduceJob* job, int defer) {
-  using C = G3Cfg<KS, KYN, NW>;
+  using C = G3Cfg<KS, KYN, NW, NCO>;
   a.xblocks = (a.Wo + G3_PB - 1) / G3_PB;
   const long long strips = nimg * a.xblocks, ci_tiles = (a.Cin + NW * 16 - 1) / (NW * 16), zt = (a.Cout + 31) / 32 * (KS / KYN);
   const long long ctiles = (a.Cout + 31) / 32;
   const long long item_stride = ci_tiles * zt * NW * C::TAPS * 512, item_floats = item_stride + (dbias ? ctiles * 32 : 0);
   if (strips * item_floats > workspace_floats || strips >= 65536) return 1;   // caller falls back to the per-tap kernel
   static const char* wgs_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS");   // tuning aid
-  const long long base = strips * ci_tiles * zt;
+  const long long zwg = (zt + NCO / 2 - 1) / (NCO / 2);       // workgroups along z (NCO = 4: two 32-filter groups each)
+  const long long base = strips * ci_tiles * zwg;
+  a.zt = (int)zt;
   long long segs = (wgs_env ? atoll(wgs_env) : 256) / base;   // one resident workgroup per CU
   if (segs < 1) segs = 1;
-  if (!wgs_env && a.Cout > 32) {
+  if (!wgs_env && a.Cout > 32 && NCO == 2) {
     // MFMA-bound shapes (D, the wide 3x3): two workgroups fit a CU (LDS), so fill 512 slots; and a grid just past a
     // multiple of the resident capacity (D's 4x4 144 -> 288: 576 workgroups = 1.125 rounds) runs a nearly empty last
     // round -- split the rows once more (measured 909 -> 805 us; 72 -> 144: 219 -> 185 us)
     if (base < 200) segs = (1024 + base - 1) / base;   // 256-workgroup grids (160 -> 128, 512 -> 128) measured WORSE when split
     else if (base % 512 != 0 && base % 512 <= 256 && base < 2048) segs = 2;
+  }
+  if (!wgs_env && NCO == 4) {
+    // 64-filter workgroups hold ~200 registers per lane: ONE workgroup per CU (two for the 3-wave form).  Pick the row split whose
+    // grid fills whole rounds of the resident capacity best (a grid just past a multiple runs a nearly empty last round); at
+    // least 8 rows per item, fewer items on ties (every item writes a partial)
+    const long long slots = NW <= 3 ? 512 : 256;
+    double best_eff = 0.0;
+    segs = 1;
+    for (long long sg = 1; sg <= (a.Ho + 7) / 8; ++sg) {
+      const long long wgs = base * sg;
+      const double eff = (double)wgs / (double)((wgs + slots - 1) / slots * slots);
+      if (eff > best_eff + 0.02) best_eff = eff, segs = sg;
+    }
   }
   if (segs > (a.Ho + 1) / 2) segs = (a.Ho + 1) / 2;             // at least 2 rows per item (KYN - 1 halo rows re-staged per item)
   while (segs > 1 && (strips * segs * item_floats > workspace_floats || strips * segs >= 65536)) --segs;
@@ -897,7 +941,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   a.part = workspace;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr_kernel<KS, KYN, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr_kernel<KS, KYN, NW, NCO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(%s): %s", name, hipGetErrorString(e));
     attr_done = true;
@@ -906,7 +950,7 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   a.dbg_skip = ph ? atoi(ph) : 0;
   const long long items = strips * a.segs;
   a.bias_part = dbias ? workspace + items * item_stride : nullptr;
-  if (int rc = fd_launch(&conv_wgrad_tr_kernel<KS, KYN, NW>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zt), dim3(64 * NW),
+  if (int rc = fd_launch(&conv_wgrad_tr_kernel<KS, KYN, NW, NCO>, name, dim3((unsigned)ci_tiles, (unsigned)items, (unsigned)zwg), dim3(64 * NW),
                          C::LDS, a, stream))
     return rc;
   TrRedArgs r{workspace, dw, item_stride, (int)items, (int)zt, KS / KYN, KYN, KS, NW, C::TAPS, a.Cin, a.Cout, accumulate, 0, item_stride / 64};
@@ -1042,10 +1086,21 @@ int conv_wgrad_tr_launch(int variant, WgradRowsArgs& a, long long nimg, float* w
         if (a.pro_mode != 0 && a.p_slope == 0.f) return r3_launch<true>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3", job, defer);
         return r3_launch<false>(a, nimg, workspace, workspace_floats, dw, accumulate, stream, "conv_wgrad3x3_r3_leaky", job, defer);
       }
+      // 96 filters and more: 64 per workgroup (round 5; measured 72 -> 144 @128^2 198 -> 152 us, 160 -> 128 224 -> 168, 640 -> 512 @32^2
+      // 281 -> 219, 1024 -> 256 226 -> 160; 36 -> 72, whose second workgroup would be seven eighths padding, 75 -> 95: stays on 32);
+      // FDGAN_DEBUG_WGRAD_NCO2 (tuning builds) keeps the 32-filter split
+      if (a.Cout >= 96 && FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_NCO2") == nullptr)
+        return g3_launch<3, 3, 8, 4>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8c4", job, defer);
       return g3_launch<3, 3, 8>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr8", job, defer);
     }
-    case 5: return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5", job, defer);
-    case 3: return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3", job, defer);
+    case 5:
+      if (a.Cout >= 96 && FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_NCO2") == nullptr)
+        return g3_launch<3, 3, 5, 4>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5c4", job, defer);
+      return g3_launch<3, 3, 5>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr5", job, defer);
+    case 3:
+      if (a.Cout >= 96 && FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_NCO2") == nullptr)
+        return g3_launch<3, 3, 3, 4>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3c4", job, defer);
+      return g3_launch<3, 3, 3>(a, nimg, workspace, workspace_floats, dw, dbias, accumulate, stream, "conv_wgrad3x3_tr3", job, defer);
     case 9: {
       static const char* r4 = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_R4");   // tuning aid: '0' first-generation kernel
       if (dbias == nullptr && a.Cin % 48 == 0 && a.Cout % 32 == 0 && a.pad == 1 && a.Wo == a.W - 1 && a.Ho == a.H - 1 && !(r4 && r4[0] == '0')) {
