@@ -976,7 +976,8 @@ int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   // 8 rows measured 26.4 us against 27.7 (kernel + reduction, tools/wgrad_one.py) for half of that traffic.  At 128 x 128 and above the
   // 256-item split stays faster (39.6 vs 47.6 us).
   long long want = wgs_env ? atoll(wgs_env) : 256;
-  if (!wgs_env && strips * ci_tiles * zt * a.Ho <= 1024) want = 128;
+  static const char* small_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS_SMALL");   // tuning aid: the 64 x 64 item count
+  if (!wgs_env && strips * ci_tiles * zt * a.Ho <= 1024) want = small_env ? atoll(small_env) : 128;
   long long segs = want / base;
   if (segs < 1) segs = 1;
   if (segs > (a.Ho + 3) / 4) segs = (a.Ho + 3) / 4;             // two of a segment's steps only see one or two of its rows

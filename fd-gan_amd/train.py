@@ -18,6 +18,7 @@ Activations live in the modules' plan buffers, so each module's backward runs be
 backward calls for the two halves of the D loss).
 """
 import argparse
+import os
 import time
 
 import torch
@@ -77,7 +78,13 @@ class TrainStep:
         self.dp = dp
         # second HIP stream: work that does not depend on the generator's output (the discriminator's real half, VGG16 on
         # the ground truth) is enqueued there and fills the CUs the generator's small-grid launches leave idle
-        self.side = torch.cuda.Stream(device=device)
+        # (FDGAN_NO_SIDE_STREAM: profiling aid -- everything on one stream, so that a kernel trace's durations are not inflated by
+        # two networks sharing the CUs; with FDGAN_NO_WGRAD_STREAM it gives the strictly serial step of profiles/*_serial_*.)
+        self.side = torch.cuda.current_stream(device) if os.environ.get("FDGAN_NO_SIDE_STREAM") else torch.cuda.Stream(device=device)
+        # D's fake half on the side stream too (measured round 5, same box: 25.70 -> 25.59, 25.87 -> 25.79 ms; FDGAN_D_FAKE_MAIN=1: the
+        # round-4 placement).  Also measured and NOT adopted: the whole step on a high-priority stream so that the side streams only
+        # fill idle CUs (+0.55 ms), the weight-gradient stream at high priority (46 ms: it starves the chain).
+        self.d_fake_side = os.environ.get("FDGAN_D_FAKE_MAIN") is None
         if dp is not None and dp.world > 1:
             self.sync_replicas()
 
@@ -137,21 +144,37 @@ class TrainStep:
             l_real.backward()
             feats_gt = vgg_targets(self.vgg, gt)
         fake = self.netG(haze)                                                     # autograd graph of the generator
-        main.wait_stream(self.side)
-        with torch.no_grad():
-            fake_in = fusion_input(self.pool.query(fake.detach()))
-        l_fake = bce_loss(self.netD(fake_in), 0.0)
-        l_fake.backward()
-        # ---- D's gradient exchange + Adam(D) + the G step's adversarial branch (frequency split -> D -> BCE) on the side
-        # stream; the perceptual / SSIM / L1 branch, which does not need D, meanwhile on the main one.  So D's all-reduce
-        # (3.2 MB: latency-priced on xGMI) is hidden under VGG16's forward instead of waited for.  The two branches only
-        # meet at `fake`; autograd replays a node on its forward's stream, so the adversarial BACKWARD runs beside VGG16's too.
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self.optD.allreduce_end(self.optD.allreduce_begin(self.dp))
-            self.optD.step()
-            self._set_d_grad(False)                                                # D is a fixed critic here: no dW work
-            l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        if self.d_fake_side:
+            # D's fake half, its Adam and the adversarial branch as ONE chain on the side stream, the perceptual / SSIM / L1 branch
+            # meanwhile on the main one: the main stream only needs VGG16's target features from the side stream (an event), not D
+            ev_gt = self.side.record_event()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                with torch.no_grad():
+                    fake_in = fusion_input(self.pool.query(fake.detach()))
+                l_fake = bce_loss(self.netD(fake_in), 0.0)
+                l_fake.backward()
+                self.optD.allreduce_end(self.optD.allreduce_begin(self.dp))
+                self.optD.step()
+                self._set_d_grad(False)
+                l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+            main.wait_event(ev_gt)
+        else:
+            main.wait_stream(self.side)
+            with torch.no_grad():
+                fake_in = fusion_input(self.pool.query(fake.detach()))
+            l_fake = bce_loss(self.netD(fake_in), 0.0)
+            l_fake.backward()
+            # ---- D's gradient exchange + Adam(D) + the G step's adversarial branch (frequency split -> D -> BCE) on the side
+            # stream; the perceptual / SSIM / L1 branch, which does not need D, meanwhile on the main one.  So D's all-reduce
+            # (3.2 MB: latency-priced on xGMI) is hidden under VGG16's forward instead of waited for.  The two branches only
+            # meet at `fake`; autograd replays a node on its forward's stream, so the adversarial BACKWARD runs beside VGG16's too.
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.optD.allreduce_end(self.optD.allreduce_begin(self.dp))
+                self.optD.step()
+                self._set_d_grad(False)                                                # D is a fixed critic here: no dW work
+                l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
         self.optG.zero_grad()
         l_perc = vgg_perceptual(self.vgg, fake, feats_gt)
         ssim = pytorch_ssim.ssim(fake, gt)
