@@ -1335,8 +1335,10 @@ def test_taped_walk_joins_the_side_stream_before_every_bucket(monkeypatch):
     tapes = [t for b in bwd if b is not None for t in b.tapes.values() if t is not None]
     assert tapes and any(len(t.steps) > 3 for t in tapes), [len(t.steps) for t in tapes]     # the hook cut the tape into segments
     assert nsend[-1] >= 8, nsend
-    # eager walks raise the flag after every side launch; a replayed walk must wait about as often (not once)
-    assert nwait[-1] >= max(2, nwait[0] // 2), (nwait, nsend)
+    # eager walks raise the flag after every side launch; a replayed walk must wait about as often (not once).  The walk to compare
+    # with is the SECOND one: the first defers no reduction yet, finishes a parameter per record and sends 49 buckets where the
+    # later walks -- their growth convs' gradients complete at the batched reduce -- send 11 (measured: waits 49, 8, 9, 8, 8)
+    assert nwait[-1] >= max(2, nwait[1] // 2) and nwait[-1] >= nsend[-1] // 2, (nwait, nsend)
     assert torch.equal(grads[3], grads[4])
     monkeypatch.setattr(BW, "FORCE_EAGER", True)          # the same walk once more, eagerly, with the same hook
     opt.zero_grad()
