@@ -56,7 +56,13 @@ static int do_launch(const FdLaunch& L, hipStream_t stream) {
     }
     ++g_kt.seen;
   }
+  static const char* trace = FD_TUNE_GETENV("FDGAN_DEBUG_TRACE_LAUNCH");   // tuning build: name every launch and wait for it (a GPU
+  if (trace) {                                                              // memory fault aborts the process: the last name is the culprit)
+    fprintf(stderr, "[launch] %s grid=(%u,%u,%u) block=%u lds=%u\n", L.name, L.grid.x, L.grid.y, L.grid.z, L.block.x, L.shmem);
+    fflush(stderr);
+  }
   hipError_t e = hipLaunchKernel(L.fn, L.grid, L.block, argv, L.shmem, stream);
+  if (trace && e == hipSuccess) e = hipStreamSynchronize(stream);
   if (slot >= 0) (void)hipEventRecord(g_kt.ev[slot].second, stream);
   if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "launch %s grid=(%u,%u,%u) block=%u lds=%u: %s", L.name, L.grid.x, L.grid.y,
                                L.grid.z, L.block.x, L.shmem, hipGetErrorString(e));
