@@ -227,6 +227,7 @@ def build_parser():
     ap.add_argument("--display", type=int, default=5, help="read the losses back (one host sync) every this many steps")
     ap.add_argument("--vgg", default="", help="pretrained VGG16: vgg16.weight, a torchvision state_dict or vgg16.t7")
     ap.add_argument("--densenet", default="", help="torchvision densenet121 state_dict for the generator's encoder")
+    ap.add_argument("--fixedBatch", action="store_true", help="synthetic runs: ONE batch of smooth images reused every step (an overfit / learning check)")
     return ap
 
 
@@ -259,8 +260,12 @@ def run(opt):
     if synthetic:
         g = torch.Generator(device="cpu").manual_seed(1234 + dp.rank)
         vals = None
+        fixed = None
+        if getattr(opt, "fixedBatch", False):      # smooth images (8 x 8 noise, bilinear): something a generator can fit, unlike white noise
+            lo = torch.rand(opt.batchSize, 3, 8, 8, generator=g)
+            fixed = torch.nn.functional.interpolate(lo, size=(opt.imageSize, opt.imageSize), mode="bilinear", align_corners=False).to(dev)
         for _ in range(opt.niter):
-            gt = torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)
+            gt = fixed if fixed is not None else torch.rand(opt.batchSize, 3, opt.imageSize, opt.imageSize, generator=g).to(dev)
             vals = one((gt * 0.6 + 0.3).clamp(0, 1), gt)
         if vals is not None:
             last = ts.losses_dict(vals)
