@@ -8,6 +8,8 @@ missing the import of any product module fails loudly (FdganLibraryError).
 import ctypes as C
 import os
 
+from . import buildid
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FDGAN_LIB: tuning aid -- an experiment build of the same ABI (`FDGAN_BUILD_TAG=x python __graft_entry__.py` writes
 # variants/libfdgan_hip_x.so); unset everywhere outside tools/
@@ -17,7 +19,7 @@ FD_OK, FD_EINVAL, FD_EUNSUPPORTED, FD_ELAUNCH, FD_ESTATE = 0, -1, -2, -3, -4
 FD_BF16, FD_F32, FD_F16 = 0, 1, 2   # fp16: forward activations / filter images; bf16: gradients (include/fdgan_hip.h)
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 WLAYOUT_CHUNK32, WLAYOUT_X64 = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class FdganLibraryError(RuntimeError):
@@ -76,6 +78,7 @@ class FdConvInfo(C.Structure):
 SIGNATURES = {
     "fdgan_last_error": (C.c_char_p, []),
     "fdgan_version": (C.c_int, []),
+    "fdgan_build_id": (C.c_char_p, []),
     "fdgan_device_arch": (C.c_char_p, []),
     "fdgan_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fdgan_conv_weight_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -237,6 +240,14 @@ def load():
         fn.argtypes = args
     if lib.fdgan_version() != ABI_VERSION:
         raise FdganLibraryError("ABI version mismatch: library %d, binding %d" % (lib.fdgan_version(), ABI_VERSION))
+    # the library must have been built from the sources lying next to it (fdgan_hip/buildid.py); FDGAN_ALLOW_STALE_LIB=1 is for
+    # tools/ that A/B a variant built from another commit's sources
+    built = (lib.fdgan_build_id() or b"").decode().split(":")[0]
+    have = buildid.source_build_id()
+    if have is not None and built != have and os.environ.get("FDGAN_ALLOW_STALE_LIB") != "1":
+        raise FdganLibraryError(
+            "%s is stale: built from sources %s, the tree next to it hashes to %s -- rebuild with `python __graft_entry__.py`"
+            % (LIB_PATH, built or "<none>", have))
     _lib = lib
     return lib
 

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define FDGAN_ABI_VERSION 15
+#define FDGAN_ABI_VERSION 16
 
 enum FdStatus {
   FD_OK = 0,
@@ -148,6 +148,10 @@ typedef struct FdConvInfo {
 
 const char* fdgan_last_error(void);
 int fdgan_version(void); /* == FDGAN_ABI_VERSION */
+/* ABI v16: "<16 hex digits>[:flags]" -- the hash of the sources this library was compiled from (csrc/*.hip, csrc/*.h and this
+ * header; fdgan_hip/buildid.py), written at build time.  The Python binding refuses a library whose id differs from the hash
+ * of the sources lying next to it: a stale build never runs. */
+const char* fdgan_build_id(void);
 /* Name of the device the library sees (e.g. "gfx950"); NULL without a GPU. */
 const char* fdgan_device_arch(void);
 

@@ -24,6 +24,44 @@ def test_library_exports_every_declared_symbol():
     assert lib.fdgan_version() == L.ABI_VERSION
 
 
+def test_stale_library_is_refused(monkeypatch, tmp_path):
+    """the library carries the hash of the sources it was compiled from, and the binding refuses one whose
+    sources have changed since (the library is git-ignored and rebuilt by mtime; FDGAN_ABI_VERSION is bumped by hand)."""
+    import shutil
+    from fdgan_hip import buildid
+    from fdgan_hip import lib as L
+    lib = L.load()
+    built = lib.fdgan_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}(:.*)?", built), built
+    assert built.split(":")[0] == buildid.source_build_id()
+    # the hash covers every translation unit, every header of csrc/ and the public header, by name and content
+    files = [os.path.basename(f) for f in buildid.source_files()]
+    assert "conv1x1_bwd.hip" in files and "conv_igemm.h" in files and files[-1] == "fdgan_hip.h"
+    csrc = tmp_path / "csrc"
+    shutil.copytree(buildid.CSRC, csrc)
+    hdr = tmp_path / "fdgan_hip.h"
+    shutil.copy(buildid.HEADER, hdr)
+    assert buildid.source_build_id(str(csrc), str(hdr)) == built.split(":")[0]
+    with open(csrc / "common.h", "a") as f:
+        f.write("// an edit after the build\n")
+    changed = buildid.source_build_id(str(csrc), str(hdr))
+    assert changed != built.split(":")[0]
+    os.rename(csrc / "pool.hip", csrc / "pool2.hip")
+    assert buildid.source_build_id(str(csrc), str(hdr)) not in (changed, built.split(":")[0])
+    # a tree that differs from the loaded library's: load() fails loudly, nothing is bound
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(buildid, "source_build_id", lambda *a: changed)
+    with pytest.raises(L.FdganLibraryError, match="stale"):
+        L.load()
+    assert L._lib is None
+    monkeypatch.setenv("FDGAN_ALLOW_STALE_LIB", "1")      # tools/ only: A/B against a variant built from another commit
+    assert L.load() is not None
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(buildid, "source_build_id", lambda *a: None)   # an installed library without its sources: nothing to compare
+    monkeypatch.delenv("FDGAN_ALLOW_STALE_LIB")
+    assert L.load() is not None
+
+
 def test_host_only_entry_points():
     from fdgan_hip import engine as E
     from fdgan_hip import lib as L
