@@ -18,6 +18,14 @@ void fd_set_error(const char* fmt, ...) {
 extern "C" const char* fdgan_last_error(void) { return g_err; }
 extern "C" int fdgan_version(void) { return FDGAN_ABI_VERSION; }
 
+static thread_local int g_cu_budget = 0;
+int fd_cu_budget() { return g_cu_budget; }
+extern "C" int fdgan_set_cu_budget(int ncu) {
+  const int prev = g_cu_budget;
+  g_cu_budget = ncu > 0 ? ncu : 0;
+  return prev;
+}
+
 extern "C" const char* fdgan_device_arch(void) {
   static thread_local char arch[256];
   int dev = 0;

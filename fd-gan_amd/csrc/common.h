@@ -137,6 +137,15 @@ __device__ __forceinline__ f32x4 fd_mfma_g(bf16x8 a, bf16x8 b, f32x4 c) { return
 
 // ---- errors ---------------------------------------------------------------
 void fd_set_error(const char* fmt, ...);
+// CU budget of the launches being issued (fdgan_set_cu_budget, include/fdgan_hip.h): the persistent kernels -- one (or two) resident
+// workgroups per CU walking the work -- size their grids by it instead of the device's CU count, so that a stream created with a CU
+// mask (hipExtStreamCreateWithCUMask) gets a grid that fills exactly its share of the chip.  0: no budget, the launcher's default.
+int fd_cu_budget();
+static inline int fd_cus(int dflt) {
+  const int b = fd_cu_budget();
+  return b > 0 && b < dflt ? b : dflt;
+}
+
 #define FD_FAIL(code, ...)      \
   do {                          \
     fd_set_error(__VA_ARGS__);  \

@@ -573,7 +573,7 @@ int conv1x1_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
   const bool fused = wpart != nullptr;                         // one 8-wave workgroup per CU instead of two 4-wave ones
   if (fused && a.Cy != 128) return 1;
-  long long nslots = (fused ? 256 : 512) / a.nct;
+  long long nslots = (fused ? fd_cus(256) : 2 * fd_cus(256)) / a.nct;   // one 8-wave / two 4-wave workgroups per CU of the budget
   if (nslots < 1) nslots = 1;
   if (nslots > a.ntiles) nslots = a.ntiles;
   const long long grid = nslots * a.nct;

@@ -355,7 +355,7 @@ static int ds_dispatch(ConvArgs& a, FdConvInfo* info, long long stats_cap, bool 
   using C = DsCfg<NW, PT>;
   a.nks = (a.Cin + 63) / 64;
   a.ntiles = (int)((a.P + C::PX - 1) / C::PX);
-  const int ncu = dry ? 256 : ds_num_cus();
+  const int ncu = fd_cus(dry ? 256 : ds_num_cus());
   dim3 grid((unsigned)(a.ntiles < ncu ? a.ntiles : ncu), 1, 1);
   a.stats_cpad = 128;
   const unsigned lds = C::lds_bytes(a.nks);

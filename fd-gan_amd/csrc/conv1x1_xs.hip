@@ -328,7 +328,7 @@ static int num_cus() {
     const unsigned lds = C::lds_bytes(a.nks, a.kgroup);                                                         \
     a.ntiles = (int)((a.P + C::TILE_PX - 1) / C::TILE_PX);                                                      \
     const int per_cu = PERCU_;                                                                                  \
-    const int ncu = dry ? 256 : num_cus();                                                                      \
+    const int ncu = fd_cus(dry ? 256 : num_cus());                                                                     \
     const unsigned gy = (unsigned)((cout_total + C::BN - 1) / C::BN);                                           \
     long long gx = (long long)per_cu * ncu / gy;                                                                \
     if (gx < 1) gx = 1;                                                                                         \
@@ -383,7 +383,7 @@ int conv_dispatch_k1_xs(ConvArgs& a, long long nimg, int cout_total, bool pool, 
     return conv_dispatch_k1_ds(a, info, stats_cap, dry, stream);
   const int nks = a.nks;
   const long long big_tiles = (a.P + 511) / 512;
-  const int ncu_ = dry ? 256 : num_cus();
+  const int ncu_ = fd_cus(dry ? 256 : num_cus());
   if (pool) {
     if (cout_total <= 32) FD_XS_LAUNCH(1, 2, 2, 4, 2, "conv1x1_xs_pool_bn32");
     if (cout_total <= 64) FD_XS_LAUNCH(1, 2, 4, 4, 2, "conv1x1_xs_pool_bn64");

@@ -521,7 +521,7 @@ int conv3x3_bwd_launch(const FdTensor* dy, const void* w_packed, const FdTensor*
   if (norm) a.mean = pro->mean, a.var = pro->var, a.gamma = pro->gamma, a.beta = pro->beta, a.eps = pro->eps;
   a.xblocks = (a.W + B3_PB - 1) / B3_PB;
   const long long strips = dpre->n * a.xblocks;
-  long long segs = 256 / strips;                               // one resident workgroup per CU
+  long long segs = fd_cus(256) / strips;                       // one resident workgroup per CU (of the budget)
   if (segs < 1) segs = 1;
   if (segs > (a.H + 3) / 4) segs = (a.H + 3) / 4;              // at least 4 rows per item (2 halo rows re-staged per item)
   a.seg_rows = (int)((a.H + segs - 1) / segs);

@@ -346,7 +346,7 @@ int conv_dispatch_k3_pw(ConvArgs& a, long long nimg, int cout_total, FdConvInfo*
   const long long nt = nimg * a.tiles_x * a.tiles_y;
   if (nt >= (1ll << 31)) FD_FAIL(FD_EUNSUPPORTED, "conv3x3_pw: too many tiles");
   a.ntiles = (int)nt;
-  const int ncu = dry ? 256 : pw_num_cus();
+  const int ncu = fd_cus(dry ? 256 : pw_num_cus());
   dim3 grid((unsigned)(nt < ncu ? nt : ncu), 1, 1), block(PW_NT, 1, 1);
   a.stats_cpad = PW_CT * 16;
   const unsigned lds = pw_lds_bytes(a.nchunk);

@@ -931,7 +931,7 @@ bool conv3x3_rs_fits(const ConvArgs& a, int cout_total) {
 int conv_dispatch_k3_rs(ConvArgs& a, long long nimg, int cout_total, FdConvInfo* info, long long stats_cap, bool dry,
                         hipStream_t stream) {
   if (!conv3x3_rs_fits(a, cout_total)) FD_FAIL(FD_EUNSUPPORTED, "conv3x3_rs: shape not supported");
-  const int ncu = dry ? 256 : rs_num_cus();
+  const int ncu = fd_cus(dry ? 256 : rs_num_cus());
   const int strips = (a.Wo + RS_TW - 1) / RS_TW;
   int seg = (a.Ho + RS_R - 1) / RS_R * RS_R;
   auto nitems = [&](int s) { return nimg * strips * ((a.Ho + s - 1) / s); };

@@ -539,12 +539,14 @@ int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* 
       info->stats_rows = 0, info->stats_cpad = 0, info->grid_x = grid_m.x, info->grid_y = 1, info->lds_bytes = lds_m;
     }
     if (dry) return FD_OK;
-    static bool attr_m = false;
+    static bool attr_m = false;      // (per process like every launcher's: the library drives one device per process)
     if (!attr_m) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const void* ks[4] = {reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 5>), reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<4, 8>),
+                           reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 5>), reinterpret_cast<const void*>(&conv_cout1_mfma_kernel<3, 8>)};
+      for (const void* k : ks) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_cout1_mfma): %s", hipGetErrorString(e));
+      }
       attr_m = true;
     }
     if (ksize == 4) return nks == 5 ? fd_launch(&conv_cout1_mfma_kernel<4, 5>, "conv4x4_cout1", grid_m, dim3(512), lds_m, c, stream)
@@ -562,8 +564,10 @@ int conv_cout1_launch(const ConvArgs& a, long long nimg, int ksize, FdConvInfo* 
   if (dry) return FD_OK;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void* k : {reinterpret_cast<const void*>(&conv_cout1_kernel<4>), reinterpret_cast<const void*>(&conv_cout1_kernel<3>)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) FD_FAIL(FD_ELAUNCH, "hipFuncSetAttribute(conv_cout1): %s", hipGetErrorString(e));
+    }
     attr_done = true;
   }
   if (ksize == 4) return fd_launch(&conv_cout1_kernel<4>, "conv4x4_cout1", grid, dim3(256), lds, c, stream);

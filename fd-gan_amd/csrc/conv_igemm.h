@@ -975,7 +975,9 @@ struct WgradRowsArgs {
   const float *p_mean, *p_var, *p_gamma, *p_beta;
   float* part;                   // per-item partial sums in accumulator order (conv_wgrad_tr.hip)
   float* bias_part;              // [items][cout tiles][32] per-item sums of dy (bias gradient) or NULL
-  int dbg_skip;                  // FDGAN_DEBUG_PHASES (results wrong): 1 no partial stores, 2 no MFMA loop, 4 no staging in the row loop
+  int dbg_skip;                  // FDGAN_DEBUG_PHASES (tuning builds, results wrong): 1 no partial stores (every row-walking kernel);
+                                 // conv_wgrad_r3 / r4 also take 8 / 32 / 256 (see there).  Bits 2 and 4 (no MFMA loop / no staging) are GONE
+                                 // from conv_wgrad_tr since its row loop lost every branch between a load and its store (round 5)
   int vgx, vgy, vgz;             // conv_wgrad_r4: the logical (cin tile, item, cout slice) grid behind its 1-D XCD-aware launch
   int zt;                        // conv_wgrad_tr: 32-filter groups x filter-row groups of the partial-sum layout (>= gridDim.z)
 };

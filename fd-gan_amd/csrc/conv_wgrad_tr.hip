@@ -937,6 +937,11 @@ int g3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   if (segs > (a.Ho + 1) / 2) segs = (a.Ho + 1) / 2;             // at least 2 rows per item (KYN - 1 halo rows re-staged per item)
   while (segs > 1 && (strips * segs * item_floats > workspace_floats || strips * segs >= 65536)) --segs;
   a.seg_rows = (int)((a.Ho + segs - 1) / segs);
+  // The two-register-set instantiations (DEPTH 2 in the kernel: NW <= 8, NCO == 2) run their steps in PAIRS: a segment with an odd
+  // row count would run one whole extra MFMA pass against a dy row loaded as zeros (+33 % matrix work for a 3-row segment) and
+  // rely on 0 * x == 0 for staged inputs (an Inf / NaN activation would poison every accumulator of the item).  Even segments
+  // only; the last segment of an odd Ho keeps its single tail row.
+  if (NW <= 8 && NCO == 2 && (a.seg_rows & 1) && a.seg_rows < a.Ho) ++a.seg_rows;
   a.segs = (int)((a.Ho + a.seg_rows - 1) / a.seg_rows);
   a.part = workspace;
   static bool attr_done = false;
@@ -975,7 +980,7 @@ int r3_launch(WgradRowsArgs& a, long long nimg, float* workspace, long long work
   // it back) whatever it covers, so at 64 x 64 (B = 16: 1024 rows) 256 items move 37.7 MB of partials for 21 MB of data; 128 items of
   // 8 rows measured 26.4 us against 27.7 (kernel + reduction, tools/wgrad_one.py) for half of that traffic.  At 128 x 128 and above the
   // 256-item split stays faster (39.6 vs 47.6 us).
-  long long want = wgs_env ? atoll(wgs_env) : 256;
+  long long want = wgs_env ? atoll(wgs_env) : fd_cus(256);
   static const char* small_env = FD_TUNE_GETENV("FDGAN_DEBUG_WGRAD_ITEMS_SMALL");   // tuning aid: the 64 x 64 item count
   if (!wgs_env && strips * ci_tiles * zt * a.Ho <= 1024) want = small_env ? atoll(small_env) : 128;
   long long segs = want / base;

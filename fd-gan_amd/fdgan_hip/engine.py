@@ -418,11 +418,14 @@ class Plan:
             raise MemoryError("fdgan_plan_create")
         self.graph = False
 
+    def close(self):
+        if self.h:
+            self.lib.fdgan_plan_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if self.h:
-                self.lib.fdgan_plan_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
@@ -696,6 +699,22 @@ GRAD_ADD, GRAD_UNPOOL, GRAD_SUMPOOL, GRAD_RELU_MASK, GRAD_LEAKY_MASK = 0, 1, 2, 
 def grad_ew(mode, src, dst, ref=None):
     L.check(L.load().fdgan_grad_ew(mode, C.byref(src.fd), C.byref(ref.fd) if ref is not None else None, C.byref(dst.fd),
                                    stream_ptr()), "grad_ew")
+
+
+class cu_budget:
+    """`with cu_budget(n):` -- the persistent kernels launched (or recorded) inside size their grids for n CUs (a stream created with
+    a CU mask: tools/cu_mask_sweep.py); 0 / None: the whole device."""
+
+    def __init__(self, ncu):
+        self.ncu = int(ncu or 0)
+
+    def __enter__(self):
+        self.prev = L.load().fdgan_set_cu_budget(self.ncu)
+        return self
+
+    def __exit__(self, *exc):
+        L.load().fdgan_set_cu_budget(self.prev)
+        return False
 
 
 def kernel_timer_arm(name=None, stride=1, max_samples=4096):

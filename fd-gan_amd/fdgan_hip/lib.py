@@ -79,6 +79,7 @@ SIGNATURES = {
     "fdgan_last_error": (C.c_char_p, []),
     "fdgan_version": (C.c_int, []),
     "fdgan_build_id": (C.c_char_p, []),
+    "fdgan_set_cu_budget": (C.c_int, [C.c_int]),
     "fdgan_device_arch": (C.c_char_p, []),
     "fdgan_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "fdgan_conv_weight_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

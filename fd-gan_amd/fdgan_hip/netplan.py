@@ -219,6 +219,35 @@ class NetPlan:
     def param_ptrs(self):
         return tuple(w.param.data_ptr() for w in self.weights)
 
+    def close(self):
+        """Deterministic teardown of an evicted plan (VERDICT r5 #2d): its backward walker joins and drains its side stream and
+        destroys its tapes, the device finishes whatever still reads this plan's activation set (the plan may have been launched
+        from more than one stream: train.py runs the discriminator on a side stream), then the recorded launches and the
+        buffers go -- here, not at a random garbage collection of the cycle plan <-> PlanBackward inside later work."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        bwd = self.__dict__.pop("_bwd", None)
+        if bwd is not None:
+            bwd.close()
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
+        if self.main is not None:
+            self.main.close()
+        self.main = None
+        self.records, self.keep, self.weights, self.drops = [], [], [], []
+        self.flipped.clear()
+        self._table = self.ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def bn_flags(module):
     """Cache key part: the train/eval state of every BatchNorm under `module`.  The list of norms is found once per module

@@ -39,7 +39,7 @@ class _PlannedModule(nn.Module):
         # plans whose parameters were moved / re-allocated (FlatAdam re-points them into its flat buffer, .to()) can never
         # be used again: drop them and their activation sets instead of keeping them behind a dead key
         for k_ in [k_ for k_, pl in cache.items() if pl.param_ptrs() != pl._built_ptrs]:
-            del cache[k_]
+            cache.pop(k_).close()
         plan = cache.pop(key, None)                       # re-inserted below: the dict's order is the LRU order
         if plan is None:
             for p in self.parameters():
@@ -48,15 +48,21 @@ class _PlannedModule(nn.Module):
             self.__dict__["_plan_keep"] = keep
             plan = self._build_plan(tuple(x.shape), x.device)
             plan._built_ptrs = plan.param_ptrs()
-            while len(cache) >= self.MAX_PLANS:           # least recently used first
-                cache.pop(next(iter(cache)))
+            while len(cache) >= self.MAX_PLANS:           # least recently used first; close(): side streams joined, buffers freed HERE
+                cache.pop(next(iter(cache))).close()
         cache[key] = plan
         self.__dict__.setdefault("_last_plan", {})[key[:3]] = key     # a key, not the plan: eviction must free it
         plan.forced_dropout = self.__dict__.get("_forced_dropout_masks")     # tests: the masks the oracle drew (NetPlan.refresh_dropout)
         return plan
 
+    def release_plans(self):
+        """Closes and drops every cached plan (activation sets, backward workspaces, recorded tapes): deterministic teardown."""
+        for pl in self.__dict__.pop("_plans", {}).values():
+            pl.close()
+        self.__dict__.pop("_last_plan", None)
+
     def _apply(self, fn, *a, **k):                        # .cuda()/.to(): storages change
-        self.__dict__.pop("_plans", None)
+        self.release_plans()
         self.__dict__.pop("_last_plan", None)
         self.__dict__.pop("_fd_param_list", None)
         return super()._apply(fn, *a, **k)

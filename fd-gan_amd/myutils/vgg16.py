@@ -26,8 +26,13 @@ class Vgg16(torch.nn.Module):
             if isinstance(item, tuple):
                 setattr(self, item[0], nn.Conv2d(item[1], item[2], kernel_size=3, stride=1, padding=1))
 
+    def release_plans(self):
+        """Closes and drops every cached plan (models.dehaze1113._PlannedModule.release_plans)."""
+        for pl in self.__dict__.pop("_plans", {}).values():
+            pl.close()
+
     def _apply(self, fn, *a, **k):
-        self.__dict__.pop("_plans", None)
+        self.release_plans()
         return super()._apply(fn, *a, **k)
 
     def _plan_for(self, X, slot=0):
@@ -38,6 +43,7 @@ class Vgg16(torch.nn.Module):
         key = (tuple(X.shape), X.device.index, slot)
         P = cache.get(key)
         if P is not None and P.param_ptrs() != P._built_ptrs:
+            cache.pop(key).close()
             P = None
         if P is None:
             P = self._build(tuple(X.shape), X.device)

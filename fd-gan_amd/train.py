@@ -116,9 +116,18 @@ class TrainStep:
         for n, m in module.named_modules():                          # the probe must not count as a training step
             if n in was:
                 m.running_mean.copy_(was[n][0]), m.running_var.copy_(was[n][1]), m.num_batches_tracked.copy_(was[n][2])
-        module.__dict__.pop("_plans", None)                          # the 1x3x32x32 probe plan and its buffers
-        module.__dict__.pop("_last_plan", None)
+        module.release_plans()                                       # the 1x3x32x32 probe plan and its buffers
         return got
+
+    @staticmethod
+    def _cross(stream, *tensors):
+        """Tensors allocated on one stream and used on `stream`: explicit waits order the WORK; record_stream makes torch's caching
+        allocator, which hands a freed block back to its allocating stream at once, also wait for `stream`'s use before the memory
+        is handed out again (VERDICT r5 #2d)."""
+        for t in tensors:
+            t = getattr(t, "buf", t)                    # engine.View (VGG16's target features live in its plan's buffers)
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
 
     def _set_d_grad(self, flag):
         for p in self.netD.parameters():
@@ -136,7 +145,10 @@ class TrainStep:
         self._set_d_grad(True)
         self.optD.zero_grad()
         main = torch.cuda.current_stream(self.dev)
+        two = self.side is not main and self.side != main
         self.side.wait_stream(main)
+        if two:
+            gt.record_stream(self.side)                 # the caller's batch is read over there (allocator lifetime, see _cross)
         with torch.cuda.stream(self.side):
             with torch.no_grad():
                 real_in = fusion_input(gt)
@@ -144,6 +156,9 @@ class TrainStep:
             l_real.backward()
             feats_gt = vgg_targets(self.vgg, gt)
         fake = self.netG(haze)                                                     # autograd graph of the generator
+        if two:
+            self._cross(main, l_real, *getattr(feats_gt, "taps", ()))   # produced on the side stream (VGG16's target-slot plan), consumed on the main one
+            self._cross(self.side, fake)                # and the other way round
         if self.d_fake_side:
             # D's fake half, its Adam and the adversarial branch as ONE chain on the side stream, the perceptual / SSIM / L1 branch
             # meanwhile on the main one: the main stream only needs VGG16's target features from the side stream (an event), not D
@@ -175,6 +190,8 @@ class TrainStep:
                 self.optD.step()
                 self._set_d_grad(False)                                                # D is a fixed critic here: no dW work
                 l_adv = bce_loss(self.netD(fusion_input(fake)), 1.0)
+        if two:
+            self._cross(main, l_fake, l_adv)
         self.optG.zero_grad()
         l_perc = vgg_perceptual(self.vgg, fake, feats_gt)
         ssim = pytorch_ssim.ssim(fake, gt)

@@ -148,10 +148,16 @@ typedef struct FdConvInfo {
 
 const char* fdgan_last_error(void);
 int fdgan_version(void); /* == FDGAN_ABI_VERSION */
-/* ABI v16: "<16 hex digits>[:flags]" -- the hash of the sources this library was compiled from (csrc/*.hip, csrc/*.h and this
+/* ABI v16: "<16 hex digits>[:flags]" -- the hash of the sources this library was compiled from (every .hip / .h of csrc/ and this
  * header; fdgan_hip/buildid.py), written at build time.  The Python binding refuses a library whose id differs from the hash
  * of the sources lying next to it: a stale build never runs. */
 const char* fdgan_build_id(void);
+/* ABI v16: CU budget of the CALLING THREAD's following launches (and dry runs): the persistent kernels -- one or two resident
+ * workgroups per CU walking the work (conv1x1_ds, conv3x3_rs2 / _pw, conv1x1_xs, the streaming data gradients, the row-walking 3x3
+ * weight gradient) -- size their grids for `ncu` CUs instead of the whole device, so that launches issued on a stream created
+ * with a CU mask (hipExtStreamCreateWithCUMask) fill exactly that stream's share of the chip.  ncu <= 0: no budget.  Returns the
+ * previous value.  Launches recorded into an FdPlan keep the grid they were recorded with. */
+int fdgan_set_cu_budget(int ncu);
 /* Name of the device the library sees (e.g. "gfx950"); NULL without a GPU. */
 const char* fdgan_device_arch(void);
 

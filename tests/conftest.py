@@ -10,6 +10,14 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# FDGAN_TEST_GUARD_ALLOC=<libguard_alloc.so> (tools/dbg/guard_alloc.cpp): every device tensor gets its own virtual-memory reservation
+# that ENDS at an unmapped guard range -- an access 16 bytes past the end of any buffer faults at the offending launch (run with
+# AMD_SERIALIZE_KERNEL=3 and a tuning build's FDGAN_DEBUG_TRACE_LAUNCH to have it named).  Must be installed before the first allocation.
+if os.environ.get("FDGAN_TEST_GUARD_ALLOC"):
+    import torch
+    _guard = torch.cuda.memory.CUDAPluggableAllocator(os.environ["FDGAN_TEST_GUARD_ALLOC"], "guard_malloc", "guard_free")
+    torch.cuda.memory.change_current_allocator(_guard)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
