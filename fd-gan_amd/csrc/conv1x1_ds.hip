@@ -172,11 +172,14 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
       const int px = wave * C::WPX + p * 16 + m;
       boff[p][j] = px * 128 + (((2 * g + j) ^ ((px >> 1) & 5)) * 16);
     }
-  float st1[DS_CT][4], st2[DS_CT][4];
+  // batch statistics of the lane's 32 outputs per pixel tile, as packed pairs (v_pk_add_f32 / v_pk_fma_f32: round 6 -- the epilogue was
+  // two thirds of the kernel's VALU instructions, 128 of them these sums, and `conv1x1_ds` is issue-bound: its rate follows the CUs
+  // it is given, profiles/r6_cu_mask_sweep.txt)
+  f32x2 st1[DS_CT][2], st2[DS_CT][2];
 #pragma unroll
   for (int c = 0; c < DS_CT; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st1[c][r] = st2[c][r] = 0.f;
+    for (int h = 0; h < 2; ++h) st1[c][h] = st2[c][h] = f32x2{0.f, 0.f};
   f32x4 acc[DS_PT][DS_CT];
 #pragma unroll
   for (int p = 0; p < DS_PT; ++p)
@@ -249,17 +252,29 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
 #pragma unroll
       for (int p = 0; p < DS_PT; ++p) {
         const unsigned pxt = (unsigned)tile * DS_PX + wave * C::WPX + p * 16;
-        const bool pok = full || pxt + m < a.P;
+        // whole tiles (every tile of the generator's shapes) skip the per-element pixel mask: a uniform branch with no load inside
+        if (!DS_SKIP(32)) {
+          if (full) {
 #pragma unroll
-        for (int c = 0; c < DS_CT; ++c)
+            for (int c = 0; c < DS_CT; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = pok ? acc[p][c][r] : 0.f;
-            if (!DS_SKIP(32)) {
-              st1[c][r] += v;
-              st2[c][r] = fmaf(v, v, st2[c][r]);
-            }
+              for (int h = 0; h < 2; ++h) {
+                const f32x2 v = {acc[p][c][2 * h], acc[p][c][2 * h + 1]};
+                st1[c][h] += v;
+                st2[c][h] = __builtin_elementwise_fma(v, v, st2[c][h]);
+              }
+          } else {
+            const bool pok = pxt + m < a.P;
+#pragma unroll
+            for (int c = 0; c < DS_CT; ++c)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x2 v = {pok ? acc[p][c][2 * h] : 0.f, pok ? acc[p][c][2 * h + 1] : 0.f};
+                st1[c][h] += v;
+                st2[c][h] = __builtin_elementwise_fma(v, v, st2[c][h]);
+              }
           }
+        }
         unsigned short* yrow = reinterpret_cast<unsigned short*>(a.y) + (unsigned long long)pxt * (unsigned)a.y_sw;
         const int npix = full ? 16 : (pxt < a.P ? (int)min(16u, a.P - pxt) : 0);
 #pragma unroll
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
     for (int c = 0; c < DS_CT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = fd_row_sum16(st1[c][r]), s2 = fd_row_sum16(st2[c][r]);
+        const float s1 = fd_row_sum16(st1[c][r >> 1][r & 1]), s2 = fd_row_sum16(st2[c][r >> 1][r & 1]);
         if (m == 0) {
           float* d = red + ((wave * 128) + c * 16 + g * 4 + r) * 2;
           d[0] = s1;

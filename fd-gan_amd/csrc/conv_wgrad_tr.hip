@@ -127,8 +127,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   constexpr int DK = (DUNITS + C::NT - 1) / C::NT;   // dy units per thread (the last round partly idle)
   const int dpiece = tid % C::DPP;
   const bool dc_ok = co0 + dpiece * 8 < a.Cout;
-  const unsigned short* ximg = a.x + (long long)n * a.x_sn + ci0 + xchunk * 8;
-  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + co0 + dpiece * 8;
+  // The clamped address of a masked unit is the image's pixel 0 -- and its channel piece must be clamped WITH it: a piece past the last
+  // channel (NW = 5 slices of an 64-channel input: chunks 8 and 9; filters past Cout) read at pixel 0 lies past the END of the tensor when
+  // the image is the batch's last and a few pixels small (the legacy U-Nets' 1 x 1 / 2 x 2 stages).  That was round 5's intermittent
+  // "Memory access fault by GPU": up to 32 bytes past a 512-byte tensor, harmless unless the caching allocator had put it at the very
+  // end of a segment (found with tools/dbg/guard_alloc.cpp, GUARD_ALLOC_END=1 GUARD_ALLOC_LEAK=1: every tensor ends at an unmapped page).
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn + (xc_ok ? ci0 + xchunk * 8 : 0);
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + (dc_ok ? co0 + dpiece * 8 : 0);
   int xdst[C::XK];
 #pragma unroll
   for (int k = 0; k < C::XK; ++k) xdst[k] = C::xoff(xpix0 + XPSTEP * k, xchunk >> 1) + ((xchunk & 1) << 4);

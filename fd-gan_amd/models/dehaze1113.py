@@ -151,6 +151,9 @@ def _apply_plan_function(module, x):
 
 
 def _plan_backward(P):
+    if getattr(P, "_closed", False):
+        raise RuntimeError("backward through a released plan: the module's plans were closed (release_plans(), .to(), eviction) after "
+                           "this forward -- its activation set is gone; run the forward again")
     if getattr(P, "_bwd", None) is None:
         P._bwd = PlanBackward(P)
     return P._bwd

@@ -23,6 +23,58 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+# FDGAN_TEST_MEMTRACE=<dir> (fault forensics, tools/dbg/memtrace_lookup.py): torch's allocator history is recorded with Python
+# stacks and a daemon thread writes a compact snapshot -- every segment with its blocks, the last few thousand alloc / free /
+# segment events, the running test -- once a second, so that after a "Memory access fault by GPU ... on address X" (the process
+# is aborted from a runtime thread: no Python code runs any more) the buffer that ended or began at X can be named.
+_MEMTRACE = os.environ.get("FDGAN_TEST_MEMTRACE")
+_CURRENT_TEST = ["<none>"]
+if _MEMTRACE:
+    import json
+    import threading
+    import time
+    import torch
+    os.makedirs(_MEMTRACE, exist_ok=True)
+    torch.cuda.memory._record_memory_history(max_entries=60000, context="alloc", stacks="python")
+
+    def _frames(ev):
+        out = []
+        for fr in ev.get("frames", [])[:40]:
+            fn = fr.get("filename", "")
+            if "site-packages" in fn or "dist-packages" in fn or fn.startswith("/usr/lib") or fn.startswith("<"):
+                continue
+            out.append("%s:%s:%s" % (os.path.basename(fn), fr.get("line"), fr.get("name")))
+            if len(out) == 6:
+                break
+        return out
+
+    def _memtrace_loop():
+        i = 0
+        while True:
+            time.sleep(1.0)
+            try:
+                snap = torch.cuda.memory._snapshot()
+                segs = [[sg["address"], sg["total_size"], sg.get("stream", 0),
+                         [[b["address"] if "address" in b else None, b["size"], b["state"]] for b in sg["blocks"]]] for sg in snap["segments"]]
+                tr = snap["device_traces"][0] if snap.get("device_traces") else []
+                evs = [[e["action"], e.get("addr"), e.get("size"), e.get("stream"), _frames(e)] for e in tr[-6000:]]
+                tmp = os.path.join(_MEMTRACE, "snap_%d.tmp" % (i & 1))
+                with open(tmp, "w") as f:
+                    json.dump({"test": _CURRENT_TEST[0], "time": time.time(), "segments": segs, "events": evs}, f)
+                os.replace(tmp, os.path.join(_MEMTRACE, "snap_%d.json" % (i & 1)))
+                i += 1
+            except Exception as e:      # never disturb the tests
+                with open(os.path.join(_MEMTRACE, "error.txt"), "a") as f:
+                    f.write(repr(e) + "\n")
+    threading.Thread(target=_memtrace_loop, daemon=True).start()
+
+
+@pytest.fixture(autouse=True)
+def _current_test_name(request):
+    _CURRENT_TEST[0] = request.node.nodeid
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -1212,7 +1212,8 @@ TRAJ_CAP = {"lossG": 1e-2, "l1": 1e-2, "ssim": 3e-2, "perc": 3e-2, "adv": 3e-2, 
 
 
 # relative, no floor: 10x the deltas measured at B = 16 @ 256^2 on the GPU box (profiles/r6_parity_train_step_full_size.json)
-FULL_SIZE_TOL = {"lossD": 2e-3, "lossG": 5e-4, "l1": 5e-4, "ssim": 2e-3, "perc": 2e-3, "adv": 3e-3}
+# (measured: lossD 2.7e-5, lossG 7.6e-7, l1 9.9e-7, ssim 1.6e-5, perc 2.7e-5, adv 1.5e-4; first Adam update's sign agreement D 1.0000, G 0.9971)
+FULL_SIZE_TOL = {"lossD": 3e-4, "lossG": 2e-5, "l1": 2e-5, "ssim": 2e-4, "perc": 3e-4, "adv": 1.5e-3}
 
 
 def test_training_step_full_size_configs2():
@@ -1278,7 +1279,52 @@ def test_training_step_full_size_configs2():
                                      "first_update_sign_agreement": agree, "launchers": sorted(names)})
     for k, t in FULL_SIZE_TOL.items():
         assert rel[k] <= t, (k, r1[k], r_ref[k], rel)
-    assert agree["D"] > 0.98 and agree["G"] > 0.95, agree
+    assert agree["D"] > 0.995 and agree["G"] > 0.99, agree
+
+
+def test_release_plans_is_deterministic_teardown(nets):
+    """a planned module's activation set, gradient buffers, workspaces and recorded tapes are reference cycles
+    (plan <-> backward walker) whose launches hold raw pointers; `release_plans()` / plan eviction / `.to()` close them explicitly:
+    the side stream is joined and drained first, the memory is back in the allocator WITHOUT a garbage collection, a backward
+    through the released plan raises instead of walking freed buffers, and the module simply builds a new plan at its next forward."""
+    import gc
+    net, _ = nets
+    from oracle.detweights import fill_state_dict
+    gc.collect()
+    torch.cuda.synchronize()
+    d = net.D(9, 36)
+    fill_state_dict(d, seed=1)
+    d = d.to(DEV)
+    x = torch.rand(2, 9, 64, 64, device=DEV)
+    gc.disable()
+    stats = os.environ.get("FDGAN_TEST_GUARD_ALLOC") is None      # a pluggable allocator (tests/conftest.py) keeps no statistics
+    try:
+        base = torch.cuda.memory_allocated() if stats else 0
+        for _ in range(4):                                   # eager walks, the recording walk, a replay
+            d.zero_grad()
+            y = d(x)
+            y.mean().backward()
+        plans = list(d.__dict__["_plans"].values())
+        walkers = [p._bwd for p in plans]
+        assert walkers and all(w is not None and not w._closed and w.gbuf for w in walkers)
+        held = torch.cuda.memory_allocated() - base if stats else 0
+        assert not stats or held > (256 << 20)               # activation set + two 256 MiB split-K workspaces per walker
+        y = d(x)                                             # a graph whose plan is about to be released
+        g_before = d.main.layer4.conv.weight.grad.clone()
+        d.release_plans()
+        assert all(w._closed and not w.gbuf and not w.tapes and w.plan is None for w in walkers)
+        assert all(p._closed and p.main is None for p in plans)
+        left = torch.cuda.memory_allocated() - base if stats else 0
+        assert not stats or left < held // 8, (held, left)   # freed here, not at some later collection
+        with pytest.raises(RuntimeError, match="released plan"):
+            y.mean().backward()
+        assert torch.equal(d.main.layer4.conv.weight.grad, g_before)
+        d.zero_grad()
+        d(x).mean().backward()                               # a new plan, the same numbers
+        torch.cuda.synchronize()
+        assert torch.allclose(d.main.layer4.conv.weight.grad, g_before, rtol=0, atol=0)
+    finally:
+        gc.enable()
 
 
 def test_first_writer_of_a_gradient_buffer_stores(monkeypatch, nets):

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 
 typedef int (*hipFree_t)(void*);
 static int g_fd = -2, g_n = 0;
@@ -21,7 +22,9 @@ int hipFree(void* p) {
   }
   if (g_fd >= 0 && p) {
     char line[96];
-    int n = snprintf(line, sizeof line, "hipFree #%d %p\n", ++g_n, p);
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    int n = snprintf(line, sizeof line, "hipFree #%d %p t=%ld.%03ld\n", ++g_n, p, (long)ts.tv_sec, ts.tv_nsec / 1000000);
     (void)!write(g_fd, line, (size_t)n);
     if (g_n <= 6 || g_n % 200 == 0) {
       void* bt[24];
