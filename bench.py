@@ -132,9 +132,12 @@ def cpu_baseline_train(size, seconds):
     res = {"value": round(n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
            "sample": "%d full training steps (G + Fusion-D + VGG16 + SSIM, Adam), batch 1 @%dx%d, fp32 PyTorch-CPU oracle "
                      "(oracle/train_ref.py), %.1f s" % (n, size, size, dt), "host_cpus": os.cpu_count()}
-    # SURVEY 8(d) asks for batch 1 AND the benchmark's batch 16: one step of the same oracle at the same thread count (more
-    # threads are SLOWER for torch's CPU convolutions on this host: 64 threads took 52.7 s for this step, 16 take ~10 s)
-    cores16 = cores
+    # SURVEY 8(d) asks for batch 1 AND the benchmark's batch 16: one step of the same oracle (many more threads are SLOWER for
+    # torch's CPU convolutions on this host)
+    # (round 6, tools/cpu_threads.py train16 on the GPU box's 2 x 64-core host: 16 threads 44.3 s, 32 threads 41.5 s, 64 threads 56.2 s
+    # per batch-16 step: the batch-16 leg has its own optimum -- profiles/r6_cpu_threads_train16.txt)
+    cores16 = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores16)
     gt16 = det_input((16, 3, size, size), seed=98)
     haze16 = (gt16 * 0.6 + 0.3).clamp(0, 1)
     t0 = time.perf_counter()

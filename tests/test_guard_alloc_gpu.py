@@ -34,8 +34,11 @@ def test_guard_allocator_is_sound_and_catches_an_overrun(tmp_path_factory):
           "assert bool(((x * 2).cpu() == torch.arange(3000) * 2.0).all())\n" % so)
     r = subprocess.run([sys.executable, "-c", ok], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    bad = ok + ("y = torch.as_strided(x, (3008,), (1,))\n"      # 8 floats past the end of x's 12000-byte allocation
-                "print(float(y.sum()))\n")
+    # a library launch told to zero 64 bytes more than the tensor has (torch's own ops refuse an out-of-bounds view)
+    bad = ok + ("import sys\nsys.path[:0] = [%r, %r]\n"
+                "from fdgan_hip import lib as L\n"
+                "L.check(L.load().fdgan_fill_zero(x.data_ptr(), 12000 + 64, 1, 0, None), 'fill_zero')\n"
+                "torch.cuda.synchronize()\n" % (ROOT, os.path.join(ROOT, "fd-gan_amd")))
     r = subprocess.run([sys.executable, "-c", bad], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "Memory access fault" in (r.stderr + r.stdout), (r.returncode, r.stderr[-1500:])
 
