@@ -127,13 +127,15 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
   constexpr int DK = (DUNITS + C::NT - 1) / C::NT;   // dy units per thread (the last round partly idle)
   const int dpiece = tid % C::DPP;
   const bool dc_ok = co0 + dpiece * 8 < a.Cout;
-  // The clamped address of a masked unit is the image's pixel 0 -- and its channel piece must be clamped WITH it: a piece past the last
+  // The clamped address of a masked unit is the image's pixel 0, CHANNEL 0 -- the channel piece must be clamped with the pixel (it is
+  // added inside the `ok ?` of the loads; as part of the base pointer it cost the 64-filter instantiation a spilled register): a piece past the last
   // channel (NW = 5 slices of an 64-channel input: chunks 8 and 9; filters past Cout) read at pixel 0 lies past the END of the tensor when
   // the image is the batch's last and a few pixels small (the legacy U-Nets' 1 x 1 / 2 x 2 stages).  That was round 5's intermittent
   // "Memory access fault by GPU": up to 32 bytes past a 512-byte tensor, harmless unless the caching allocator had put it at the very
   // end of a segment (found with tools/dbg/guard_alloc.cpp, GUARD_ALLOC_END=1 GUARD_ALLOC_LEAK=1: every tensor ends at an unmapped page).
-  const unsigned short* ximg = a.x + (long long)n * a.x_sn + (xc_ok ? ci0 + xchunk * 8 : 0);
-  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn + (dc_ok ? co0 + dpiece * 8 : 0);
+  const int xcoff = ci0 + xchunk * 8, dcoff = co0 + dpiece * 8;      // added to the address only where the unit is real (ok implies xc_ok / dc_ok)
+  const unsigned short* ximg = a.x + (long long)n * a.x_sn;
+  const unsigned short* dimg = a.dy + (long long)n * a.dy_sn;
   int xdst[C::XK];
 #pragma unroll
   for (int k = 0; k < C::XK; ++k) xdst[k] = C::xoff(xpix0 + XPSTEP * k, xchunk >> 1) + ((xchunk & 1) << 4);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     for (int k = 0; k < C::XK; ++k) {
       const int pix = xpix0 + XPSTEP * k, px = xbase - a.pad + pix;
       const bool ok = rok && px >= 0 && px < a.W && pix < C::XPIX;
-      xr[k] = *reinterpret_cast<const u32x4*>(ximg + (ok ? (long long)row * a.x_sh + (long long)px * a.x_sw : 0));
+      xr[k] = *reinterpret_cast<const u32x4*>(ximg + (ok ? (long long)row * a.x_sh + (long long)px * a.x_sw + xcoff : 0));
       xok |= ok ? 1u << k : 0u;
     }
   };
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_tr_kernel(WgradRowsArgs a)
     for (int k = 0; k < DK; ++k) {
       const int dpix = (tid + k * C::NT) / C::DPP;
       const bool ok = dpix < G3_PB && dc_ok && row < y_end && xbase + dpix < a.Wo;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(dimg + (ok ? (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw : 0));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dimg + (ok ? (long long)row * a.dy_sh + (long long)(xbase + dpix) * a.dy_sw + dcoff : 0));
       dr[k] = ok ? v : zero4;
     }
   };
