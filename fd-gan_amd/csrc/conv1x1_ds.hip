@@ -175,6 +175,8 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_ds_kernel(ConvArgs a) {
   // batch statistics of the lane's 32 outputs per pixel tile, as packed pairs (v_pk_add_f32 / v_pk_fma_f32: round 6 -- the epilogue was
   // two thirds of the kernel's VALU instructions, 128 of them these sums, and `conv1x1_ds` is issue-bound: its rate follows the CUs
   // it is given, profiles/r6_cu_mask_sweep.txt)
+  // (Also tried in round 6, not kept: the tile's first stage starting from the MFMA's inline-zero accumulator operand instead of 64 v_mov
+  // after the epilogue -- two copies of the stage body behind a uniform `ks == 0` cost 11 spilled registers and vmcnt(0) waits at the joins.)
   f32x2 st1[DS_CT][2], st2[DS_CT][2];
 #pragma unroll
   for (int c = 0; c < DS_CT; ++c)

@@ -600,7 +600,8 @@ class PlanBackward:
                 gslice.zero_()
             rec = dict(label="%dx%d %d->%d @%dx%d%s%s" % (k, k, w.cin, w.cout, dy_view.shape[1], dy_view.shape[2],
                                                        " pool" if meta["pool"] else "", " bn" if meta.get("bn") is not None else ""),
-                       dw=float((tmp - dw_ref).norm() / (dw_ref.norm() + 1e-30)))
+                       dw=float((tmp - dw_ref).norm() / (dw_ref.norm() + 1e-30)),
+                       dw_hip_finite=bool(torch.isfinite(tmp).all()), dw_ref_finite=bool(torch.isfinite(dw_ref).all()))
         if not need_dx:
             if r.get("_first_full", False) and self.checks is None:      # nobody stores into this buffer now: zero it after all
                 E.fill_zero(self.gbuf[x.buf.data_ptr()])

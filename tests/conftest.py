@@ -23,6 +23,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+# FDGAN_TEST_POISON=1: every `torch.empty` / `empty_like` on the GPU comes back filled with a huge FINITE value (1e30; 3e4 in fp16; all-ones
+# bytes for integers) instead of whatever the caching allocator's block held before: a kernel that consumes a workspace slot, a partial sum
+# or a temporary nobody wrote shows up as a 1e30-sized error in EVERY run, not as a NaN in one run of six (finite on purpose: padded channels
+# are legitimately multiplied by zero filter entries, and 0 x NaN would flag those).
+if os.environ.get("FDGAN_TEST_POISON"):
+    import torch as _torch
+    _empty, _empty_like = _torch.empty, _torch.empty_like
+
+    def _poison(t):
+        if t.is_cuda and t.numel():
+            if t.dtype == _torch.float16:
+                t.fill_(3.0e4)
+            elif t.dtype.is_floating_point:
+                t.fill_(1.0e30)
+            elif t.dtype == _torch.bool:
+                t.fill_(True)
+            elif not t.dtype.is_complex:
+                t.view(_torch.uint8).fill_(255) if t.is_contiguous() else None
+        return t
+    _torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
+    _torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
 # FDGAN_TEST_MEMTRACE=<dir> (fault forensics, tools/dbg/memtrace_lookup.py): torch's allocator history is recorded with Python
 # stacks and a daemon thread writes a compact snapshot -- every segment with its blocks, the last few thousand alloc / free /
 # segment events, the running test -- once a second, so that after a "Memory access fault by GPU ... on address X" (the process

@@ -132,9 +132,35 @@ def op_reference(r, dy_view, meta):
         a = st(a)
         p = w.param.detach()
         wt = (p.permute(1, 0, 2, 3) if w.transposed else p).to(torch.bfloat16).float().requires_grad_(True)
+        dy = dy_view.torch_nchw()[:, :w.cout]
         y = F.conv2d(a, wt, None, r["stride"], pad)
-        y.backward(dy_view.torch_nchw()[:, :w.cout])
+        y.backward(dy)
+        if not (bool(torch.isfinite(wt.grad).all()) and bool(torch.isfinite(xr.grad).all())):
+            # Round 6: one full-suite run in ~20 came back with a NaN in a per-op check of the legacy `dehaze` tail (3 .. 24 channels).  The
+            # HIP side of the comparison consumes no unwritten memory (tests/conftest.py FDGAN_TEST_POISON) and reads nothing out of bounds
+            # (the guard-page allocator), so the suspect is this reference, i.e. the vendor's convolution backward on few-channel shapes:
+            # a non-finite REFERENCE is recomputed on the host from the same operands (and reported: OP_REFERENCE_RETRIES).
+            OP_REFERENCE_RETRIES.append("%dx%d %d->%d" % (k, k, w.cin, w.cout))
+            xc = xr.detach().cpu().requires_grad_(True)
+            ac = xc
+            if meta.get("bn") is not None:
+                ac = F.batch_norm(ac, None, None, meta["gamma"].detach().cpu(), meta["beta"].detach().cpu(), True, 0.0, meta["eps"])
+                for lo, hi in meta.get("identity", ()):
+                    ac = torch.cat([ac[:, :lo], xc[:, lo:hi], ac[:, hi:]], 1)
+            if meta["act"] == ACT_RELU:
+                ac = torch.relu(ac)
+            elif meta["act"] == ACT_LEAKY02:
+                ac = F.leaky_relu(ac, 0.2)
+            if meta["pool"]:
+                ac = F.avg_pool2d(ac, 2)
+            ac = st(ac)
+            wc = wt.detach().cpu().requires_grad_(True)
+            F.conv2d(ac, wc, None, r["stride"], pad).backward(dy.cpu())
+            return wc.grad.to(wt.device), xc.grad.to(xr.device)
     return wt.grad, xr.grad
+
+
+OP_REFERENCE_RETRIES = []      # labels of the ops whose device-side torch reference came back non-finite (see op_reference)
 
 
 class emulated_functional_convs:

@@ -83,6 +83,15 @@ def test_host_only_entry_points():
     assert (info.grid_x, info.grid_y, info.stats_rows, info.stats_cpad) == (256, 1, 256, 32)
     assert info.lds_bytes <= 160 * 1024
     assert lib.fdgan_conv_weight_layout(128, 256, 1, 1) == L.WLAYOUT_X64
+    # CU budget (ABI v16): the persistent kernels size their grid for the CUs of a masked stream; thread-local, restored on exit
+    with E.cu_budget(192):
+        info192 = E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1))
+        assert (info192.grid_x, info192.stats_rows) == (192, 192)
+        with E.cu_budget(0):
+            assert E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1)).grid_x == 256
+        assert lib.fdgan_set_cu_budget(192) == 192
+    assert lib.fdgan_set_cu_budget(0) == 0
+    assert E.conv_info(fd(16, 256, 256, 128, 128), fd(16, 256, 256, 32, 256), 32, E.conv_desc(3, 1, 1)).grid_x == 256
     info = E.conv_info(fd(16, 256, 256, 256, 256), fd(16, 128, 128, 128, 160), 128,
                        E.conv_desc(1, w_layout=L.WLAYOUT_X64),
                        E.make_prologue(pool=True))

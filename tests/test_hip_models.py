@@ -2139,7 +2139,8 @@ def test_legacy_dehaze_backward(golden_dir):
     sum((y * c.to(DEV)).sum() for y, c in zip(ys, cots)).backward()
     torch.cuda.synchronize()
     checks, B.checks = B.checks, None
-    summary.update(ops_checked=len(checks), op_dw_worst=max(o["dw"] for o in checks), op_dx_worst=max(o.get("dx", 0.0) for o in checks))
+    summary.update(ops_checked=len(checks), op_dw_worst=max(o["dw"] for o in checks), op_dx_worst=max(o.get("dx", 0.0) for o in checks),
+                   ops=checks)      # per op: label, dw / dx distance, which side of a comparison was non-finite if one was
     _report("legacy_dehaze_backward", summary)
     assert summary["ops_checked"] == 3 and summary["op_dw_worst"] < 5e-3 and summary["op_dx_worst"] < 3e-2, summary
     _assert_legacy_grads(summary)
