@@ -1401,6 +1401,9 @@ struct AffineAccArgs {
   long long P;
   const float *bsum, *csum;
   int gpp, dense;   // channel groups per pixel in a workgroup pass (<= 8); both views pixel-dense
+  unsigned short* out;   // where dx + B x + C goes: dx itself (in place), or a separate view (fdgan_affine_accumulate_out)
+  long long o_sn;
+  int o_sh, o_sw;
 };
 template <bool DENSE>
 __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
@@ -1434,18 +1437,19 @@ __global__ __launch_bounds__(256) void affine_acc_kernel(AffineAccArgs a) {
       const long long pk = p0 + k * stride;
       ok[k] = pk < a.P;
       const long long p = ok[k] ? pk : p0;
-      long long xo, go;
+      long long xo, go, oo;
       if constexpr (DENSE) {
-        xo = p * a.x_sw, go = p * a.dx_sw;
+        xo = p * a.x_sw, go = p * a.dx_sw, oo = p * a.o_sw;
       } else {
         const unsigned pu = (unsigned)p, n = pu / HWu, r = pu - n * HWu;
         const int y = (int)(r / Wu), xx = (int)(r - (unsigned)y * Wu);
         xo = n * a.x_sn + (long long)y * a.x_sh + (long long)xx * a.x_sw;
         go = n * a.dx_sn + (long long)y * a.dx_sh + (long long)xx * a.dx_sw;
+        oo = n * a.o_sn + (long long)y * a.o_sh + (long long)xx * a.o_sw;
       }
       xv[k] = *reinterpret_cast<const u32x4*>(a.x + xo + c8 * 8);
-      op[k] = a.dx + go + c8 * 8;
-      gv[k] = *reinterpret_cast<const u32x4*>(op[k]);
+      op[k] = a.out + oo + c8 * 8;
+      gv[k] = *reinterpret_cast<const u32x4*>(a.dx + go + c8 * 8);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1468,11 +1472,24 @@ extern "C" int fdgan_bn_bwd_coef(const float* dgamma, const float* dbeta, const 
                    static_cast<hipStream_t>(stream));
 }
 
+static int affine_accumulate_impl(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, const FdTensor* out, FdStream stream);
 extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream) {
+  return affine_accumulate_impl(x, bsum, csum, dx, dx, stream);
+}
+extern "C" int fdgan_affine_accumulate_out(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* g, const FdTensor* out,
+                                          FdStream stream) {
+  FD_REQUIRE(out != nullptr, "affine_accumulate_out: NULL output view");
+  return affine_accumulate_impl(x, bsum, csum, g, out, stream);
+}
+static int affine_accumulate_impl(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, const FdTensor* out, FdStream stream) {
   if (int rc = check_view(x, "affine_accumulate(x)", FD_F16)) return rc;
   if (int rc = check_view(dx, "affine_accumulate(dx)")) return rc;
+  if (int rc = check_view(out, "affine_accumulate(out)")) return rc;
   FD_REQUIRE(bsum && csum && dx->n == x->n && dx->h == x->h && dx->w == x->w && dx->c == x->c, "affine_accumulate: shape mismatch");
+  FD_REQUIRE(out->n == x->n && out->h == x->h && out->w == x->w && out->c == x->c, "affine_accumulate: output shape mismatch");
   AffineAccArgs a{};
+  a.out = static_cast<unsigned short*>(out->ptr);
+  a.o_sn = out->stride[0], a.o_sh = (int)out->stride[1], a.o_sw = (int)out->stride[2];
   a.x = static_cast<const unsigned short*>(x->ptr);
   a.x_sn = x->stride[0], a.x_sh = (int)x->stride[1], a.x_sw = (int)x->stride[2];
   a.dx = static_cast<unsigned short*>(dx->ptr);
@@ -1482,7 +1499,7 @@ extern "C" int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, con
   a.bsum = bsum, a.csum = csum;
   FD_REQUIRE(a.P < (1ll << 31), "affine_accumulate: more than 2^31 pixels");
   auto pixel_dense = [](const FdTensor* t) { return t->stride[1] == t->w * t->stride[2] && t->stride[0] == t->h * t->stride[1]; };
-  a.dense = pixel_dense(x) && pixel_dense(dx) ? 1 : 0;
+  a.dense = pixel_dense(x) && pixel_dense(dx) && pixel_dense(out) ? 1 : 0;
   a.gpp = a.C8 < 8 ? a.C8 : 8;
   const int ppp = 256 / a.gpp;
   const long long chunks = (a.C8 + a.gpp - 1) / a.gpp;

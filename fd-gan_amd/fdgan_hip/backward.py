@@ -222,6 +222,13 @@ class PlanBackward:
         self.fuse_wgrad = os.environ.get("FDGAN_NO_FUSED_WGRAD") is None        # tuning aid: separate 1x1 weight-gradient kernel
         self.fold_flush = os.environ.get("FDGAN_NO_FOLDED_FLUSH") is None       # tuning aid: separate affine_accumulate pass
         self.pool_one_pass = os.environ.get("FDGAN_NO_POOL_ONEPASS") is None    # tuning aid: pooled prologues through bn_bwd_apply
+        # The flushed gradient of a 32-channel growth slice goes to a private PIXEL-DENSE buffer instead of back into its slice of the
+        # concat-pitched gradient buffer (round 6): the slice is 64-byte pieces at a 512 .. 2048-byte pitch, and the memory system moves
+        # 128-byte lines (profiles/r6_ubench_raggedrow.txt) -- its two readers, the 3x3 data- and weight-gradient kernels, then read
+        # half the lines, and the flush writes whole ones.  One buffer per record (the weight gradient reads it from the side stream
+        # while the walk goes on): 0.7 GB for the generator at B = 16 @ 256^2.
+        self.compact_dy = os.environ.get("FDGAN_NO_COMPACT_DY") is None
+        self.dyc = {}               # record index -> private dense dy buffer (n, h, w, 32)
         # Weight gradients off the critical path: dW only feeds the optimizer, while the data gradient is what the next
         # (earlier) layer waits for.  Every unfused weight gradient (kernel + its fixed-order reduction) whose operands are
         # persistent buffers runs on a second HIP stream with its own split-K workspace; the walk joins it at the end (and
@@ -414,7 +421,7 @@ class PlanBackward:
                 tape.close()
         self.tapes.clear()
         self._rec = None
-        for name in ("gbuf", "wparts", "tr_parts", "_persist", "_zero_tables", "deferred"):
+        for name in ("gbuf", "wparts", "tr_parts", "dyc", "_persist", "_zero_tables", "deferred"):
             getattr(self, name).clear()
         self.ws = self.ws_bn = self.ws_fin = self.ws_w = None
         self.reduce_table = self.tr_table = None
@@ -562,7 +569,8 @@ class PlanBackward:
                 dw_t = grad_target(grads, p)
                 # dy must be a view of a persistent gradient buffer that nothing rewrites before the walk ends (not the
                 # dense blocks' shared bottleneck-gradient buffer, not a temporary of this call)
-                side = (self.offload_wgrad and self.checks is None and r.get("y") is not None and dy_view.buf is self.gbuf.get(r["y"].buf.data_ptr())
+                side = (self.offload_wgrad and self.checks is None and r.get("y") is not None
+                        and (dy_view.buf is self.gbuf.get(r["y"].buf.data_ptr()) or dy_view.buf is self.dyc.get(r.get("_idx")))
                         and r["y"].buf.data_ptr() not in self.multi_version)
                 if side:
                     self._share(x.buf, dw_t, db)              # the plan's activation buffer and the gradient targets: used over there
@@ -759,6 +767,33 @@ class PlanBackward:
         else:
             d["stale"].update(range(lo, hi))          # zeroed by zero_() at the start of the next walk, or by _unstale before a += in this one
         d["dirty"].difference_update(range(lo, hi))
+
+    def _flush_compact(self, i, r, y):
+        """flush(y) for the output slice of a dense layer's growth conv, written to the record's private dense buffer; returns that
+        buffer's view (the dy both gradient kernels of the conv read), or None when this is not such a slice / nothing is pending."""
+        if not (self.compact_dy and self.checks is None and isinstance(y, E.View) and y.c == 32 and y.c0 % 32 == 0 and r["k"] == 3
+                and r["stride"] == 1 and not r["upsample"] and r["e_act"] == L.ACT_NONE and r.get("bias") is None
+                and y.buf.shape[-1] > 32 and y.buf.data_ptr() not in self.multi_version):
+            return None
+        d = self.deferred.get(y.buf.data_ptr())
+        lo, hi = y.c0, y.c0 + 32
+        if d is None or not d["dirty"] or d["dirty"].isdisjoint(range(lo, hi)):      # (clean channels of the slice hold a zero pair)
+            return None
+        for c in [c for c in range(lo, hi) if c in d["stale"] and c not in d["dirty"]]:
+            self._unstale(d, c, c + 1)
+        buf = self.dyc.get(i)
+        if buf is None:
+            n, h, w, _ = y.buf.shape
+            buf = self.dyc[i] = E.new_grad(n, h, w, 32, y.buf.device)
+            self._share(buf)
+        xv, out = E.View(d["buf"], lo, 32), E.View(buf)
+        E.affine_accumulate(xv.fd, d["coef"][0, lo:hi], d["coef"][1, lo:hi], self.G(xv).fd, out_fd=out.fd)
+        if d.get("store"):
+            E.fill_zero(d["coef"][:, lo:hi])
+        else:
+            d["stale"].update(range(lo, hi))
+        d["dirty"].difference_update(range(lo, hi))
+        return out
 
     def flush_all(self):
         for d in self.deferred.values():
@@ -1038,9 +1073,13 @@ class PlanBackward:
                 self._hook(i)
                 continue
             pending = self._pending_for_fused(r, need_dx)
+            gy = None
             if pending is None:
-                self.flush(y)
-            gy = self.G(y)
+                gy = self._flush_compact(i, r, y)
+                if gy is None:
+                    self.flush(y)
+            if gy is None:
+                gy = self.G(y)
             dyv = gy
             if r["upsample"]:
                 n, h2, w2, _ = y.shape

@@ -617,10 +617,14 @@ def bn_bwd_coef(dgamma, dbeta, pro, channels, count, bsum, csum):
                                        csum.data_ptr(), stream_ptr()), "bn_bwd_coef")
 
 
-def affine_accumulate(x_fd, bsum, csum, dx_fd):
-    """dx += bsum * x + csum per channel."""
-    L.check(L.load().fdgan_affine_accumulate(C.byref(x_fd), bsum.data_ptr(), csum.data_ptr(), C.byref(dx_fd), stream_ptr()),
-            "affine_accumulate")
+def affine_accumulate(x_fd, bsum, csum, dx_fd, out_fd=None):
+    """dx += bsum * x + csum per channel; with out_fd: out = dx + bsum * x + csum, dx untouched."""
+    if out_fd is None:
+        L.check(L.load().fdgan_affine_accumulate(C.byref(x_fd), bsum.data_ptr(), csum.data_ptr(), C.byref(dx_fd), stream_ptr()),
+                "affine_accumulate")
+    else:
+        L.check(L.load().fdgan_affine_accumulate_out(C.byref(x_fd), bsum.data_ptr(), csum.data_ptr(), C.byref(dx_fd), C.byref(out_fd),
+                                                     stream_ptr()), "affine_accumulate_out")
 
 
 def bn_bwd_apply(dpre_fd, x_fd, pro, dgamma, dbeta, dx_fd, accumulate=False):

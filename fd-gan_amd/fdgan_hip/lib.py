@@ -202,6 +202,7 @@ SIGNATURES = {
     "fdgan_bn_bwd_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FdPrologue), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "fdgan_affine_accumulate": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.c_void_p]),
+    "fdgan_affine_accumulate_out": (C.c_int, [C.POINTER(FdTensor), C.c_void_p, C.c_void_p, C.POINTER(FdTensor), C.POINTER(FdTensor), C.c_void_p]),
     "fdgan_kernel_timer_arm": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "fdgan_kernel_timer_read": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_float), C.c_char_p]),

@@ -471,6 +471,10 @@ int fdgan_wgrad_tr_reduce_batch(const FdTrReduceJob* jobs_device, int64_t njobs,
 
 /* dx += bsum[c] * x + csum[c] (x: NHWC fp16 activation, dx: NHWC bf16 gradient of equal shape). */
 int fdgan_affine_accumulate(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* dx, FdStream stream);
+/* ABI v16: the same sum written to ANOTHER view, out = g + bsum * x + csum (g is not modified; same rounding, same random bits as the
+ * in-place form).  The backward walk uses it to hand the flushed gradient of a 32-channel growth slice -- 64-byte pieces at the concat
+ * buffer's pitch -- to its two readers as a pixel-dense tensor (half the 128-byte lines per read). */
+int fdgan_affine_accumulate_out(const FdTensor* x, const float* bsum, const float* csum, const FdTensor* g, const FdTensor* out, FdStream stream);
 /* Pooled prologues (pro->pool2, the transitions: BatchNorm + ReLU + 2x2 average in front of the 1x1 conv,
  * torchvision _Transition as used at dehaze1113.py:716-728): fdgan_bn_act_bwd and fdgan_bn_bwd_apply accept the HALF-resolution
  * gradient w.r.t. the pooled activation as `da` / `dpre` and un-pool (x 1/4) and mask on the fly -- bn_act_bwd then only

@@ -1561,7 +1561,7 @@ def test_backward_variants_agree(monkeypatch):
     tgt = torch.rand(2, 3, 64, 64, device=DEV) * 2 - 1
 
     def grads_of(switches):
-        for k in ("FDGAN_NO_DX_STORE", "FDGAN_NO_DEFERRED_AFFINE", "FDGAN_DEBUG_NO_BWD1X1S", "FDGAN_DEBUG_NO_BWD3X3S",
+        for k in ("FDGAN_NO_DX_STORE", "FDGAN_NO_DEFERRED_AFFINE", "FDGAN_NO_COMPACT_DY", "FDGAN_DEBUG_NO_BWD1X1S", "FDGAN_DEBUG_NO_BWD3X3S",
                   "FDGAN_DEBUG_NO_WGRAD1X1_TR", "FDGAN_DEBUG_NO_WGRAD_TR"):
             monkeypatch.delenv(k, raising=False)
         for k in switches:
@@ -1576,6 +1576,11 @@ def test_backward_variants_agree(monkeypatch):
     assert fast.keys() == no_store.keys() and len(fast) == 282
     for k in fast:
         assert torch.equal(fast[k], no_store[k]), k
+    # round 6: the flushed gradient of a growth slice goes to a private pixel-dense buffer (fdgan_affine_accumulate_out) instead of back
+    # into its 64-byte pieces of the concat-pitched gradient buffer: the same sum, the same stochastic-rounding bits, another address
+    in_place = grads_of(("FDGAN_NO_COMPACT_DY",))
+    for k in fast:
+        assert torch.equal(fast[k], in_place[k]), k
     plain = grads_of(("FDGAN_NO_DX_STORE", "FDGAN_NO_DEFERRED_AFFINE"))
     # the dense blocks' gradients are chaotic at this size (ReLU masks flip under any rounding change: the two CPU oracles
     # of test_fdgan_backward differ by 35-75 % there); judge the worst case on the parameters downstream of them
