@@ -25,8 +25,6 @@
 //
 // Reference call sites replaced: see include/fdgan_hip.h (fdgan_conv2d_fwd).
 #pragma once
-#include <type_traits>
-
 #include "common.h"
 
 struct ConvArgs {
@@ -114,39 +112,15 @@ __device__ __forceinline__ u32x4 fd_pack8(f32x8 f) {
 // BatchNorm + ReLU on 8 channels in 20 VALU ops: 8 widening conversions, 4 v_pk_fma_f32,
 // 4 v_cvt_pk_{f16,bf16}_f32 and the ReLU as 4 v_pk_max_i16 on the packed result (a negative fp16 / bf16 is a
 // negative int16; rounding is monotone, so relu(round(t)) == round(relu(t))).
-// fp16 in, fp16 out: out = f16(fma(f32(x), sc, sh)) as ONE instruction per element -- v_fma_mixlo_f16 / v_fma_mixhi_f16 take the
-// fp16 half of a register as source 0, fp32 sources 1 and 2, compute in fp32 and write the rounded fp16 result into the low / high
-// half of the destination: bit for bit what v_cvt_f32_f16 + v_pk_fma_f32 + v_cvt_pk_f16_f32 compute (same single fp32 fma, same
-// round-to-nearest-even to fp16), in 2 instructions per pair instead of 4 (round 6: the dense-layer forward kernels are issue-bound;
-// hipcc does not select the mix forms itself -- it packs the two fmas into v_pk_fma_f32 and keeps the conversions).
-__device__ __forceinline__ unsigned fd_fma_mix_f16x2(unsigned raw, float s_lo, float s_hi, float h_lo, float h_hi) {
-  unsigned r;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(r)
-      : "v"(raw), "v"(s_lo), "v"(h_lo), "v"(s_hi), "v"(h_hi));
-  return r;
-}
-
 template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const float* sh) {
   typedef f32x2 f32x2_t;
   typedef __attribute__((ext_vector_type(2))) short s16x2_t;
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
   const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
-  u32x4 out;
-  if constexpr (std::is_same<F, FmtA>::value && std::is_same<FO, FmtA>::value) {   // fp16 -> fp16: the mix forms (above)
-    const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-    const float shv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const s16x2_t pk = __builtin_bit_cast(s16x2_t, fd_fma_mix_f16x2(raw[i], scv[2 * i], scv[2 * i + 1], shv[2 * i], shv[2 * i + 1]));
-      out[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
-    }
-    return out;
-  }
   const f32x2_t sv[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
   const f32x2_t hv[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
+  u32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x2_t f = fd_cvt2<F>(raw[i]);
@@ -163,19 +137,6 @@ template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_xform8_r(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 h0, f32x4 h1, float slope) {
   typedef f32x2 f32x2_t;
   typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-  if constexpr (std::is_same<F, FmtA>::value && std::is_same<FO, FmtA>::value) {
-    if (slope == 0.f) {   // uniform: BatchNorm + ReLU on fp16 pairs, 3 instructions per pair
-      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-      const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      u32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const s16x2_t pk = __builtin_bit_cast(s16x2_t, fd_fma_mix_f16x2(raw[i], sc[2 * i], sc[2 * i + 1], sh[2 * i], sh[2 * i + 1]));
-        o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(pk, (s16x2_t){0, 0}));
-      }
-      return o;
-    }
-  }
   const f32x2_t sv[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
   const f32x2_t hv[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
   u32x4 out;
