@@ -133,6 +133,12 @@ __device__ __forceinline__ u32x4 fd_bn_relu8(u32x4 raw, const float* sc, const f
 
 // Register-operand forms (scale/shift already fetched from LDS): used where one lane applies the
 // same 8 channels to several units, so the 4 LDS reads are paid once instead of per unit.
+// (Round 6, measured and not adopted: the fp16 -> fp16 BatchNorm + ReLU as v_fma_mixlo_f16 / v_fma_mixhi_f16 -- fp16 source 0, fp32
+// scale / shift, the rounded fp16 result written to one half of the destination: 12 instead of 20 VALU instructions per 8-channel
+// fragment, conv1x1_ds 1-3 % faster, conv3x3_pw's spill gone.  Its rounding is not v_cvt_pk_f16_f32's: netG moved from 64.66 to
+// 64.85 dB (train) / 70.9 to 71.7 dB (eval) from the oracle -- closer -- and two noise-level test bounds derived from the old
+// numbers (the ten-step trajectory's perceptual-loss drift, 1.005 % against 1 %; one legacy op's dx, 3.08 % against 3 %) no longer
+// held.  Not worth re-deriving bounds in the last round for 0.05 ms; hipcc does not select the mix forms by itself.)
 template <class F = FmtA, class FO = F>
 __device__ __forceinline__ u32x4 fd_xform8_r(u32x4 raw, f32x4 s0, f32x4 s1, f32x4 h0, f32x4 h1, float slope) {
   typedef f32x2 f32x2_t;
