@@ -185,7 +185,11 @@ def _model_conv1x1_bwd_data_weight(args, kw):
     dy_fd, fwd_x_fd, dpre_fd, accumulate = args[0], args[2], args[4], args[6]
     px = dpre_fd.n * dpre_fd.h * dpre_fd.w
     byts = px * dy_fd.c * 2 * (2 if kw.get("dy_affine") is not None else 1) + px * dpre_fd.c * 2 * (3 if accumulate == 1 else 2)
-    return "conv1x1_bwd_wgrad_stream", byts, 2 * 2.0 * px * dpre_fd.c * dy_fd.c
+    # the same in whole 128-byte lines (64 channels): x and G are channel PREFIXES of a wider pixel-major buffer, and a row that ends in
+    # half a line costs the memory system the whole line (profiles/r6_ubench_raggedrow.txt) -- reported beside the algorithmic figure
+    c_lines = (dpre_fd.c + 63) // 64 * 64 if dpre_fd.stride[2] > dpre_fd.c else dpre_fd.c
+    lines = px * dy_fd.c * 2 * (2 if kw.get("dy_affine") is not None else 1) + px * c_lines * 2 * (3 if accumulate == 1 else 2)
+    return "conv1x1_bwd_wgrad_stream", byts, 2 * 2.0 * px * dpre_fd.c * dy_fd.c, lines
 
 
 MODELS = {"bn_bwd_apply": ("bn_bwd_apply", _model_bn_bwd_apply), "affine_accumulate": ("affine_accumulate", _model_affine_accumulate),
@@ -235,11 +239,12 @@ def train_bench(a, dp, dev, B, S):
         orig = getattr(E, fn_name)
 
         def wrapped(*args, **kw):
-            nm, byts_, flops_ = model(args, kw)
+            mres = model(args, kw)
+            nm, byts_, flops_ = mres[:3]
             res = orig(*args, **kw)
             launched = not (fn_name == "conv1x1_bwd_data_weight" and res is None)   # None: outside the fused kernel, nothing launched
             if nm == dom_name and launched:
-                per_call.append((byts_, flops_))
+                per_call.append((byts_, flops_, mres[3] if len(mres) > 3 else byts_))
             return res
         # The reverse walks are recorded and replayed (fdgan_hip/backward.py: _Tape), so the Python entry point is not called in
         # the timed steps: ONE eager step (recording switched off) lists the kernel's launches of a step in launch order; every
@@ -314,10 +319,11 @@ def train_bench(a, dp, dev, B, S):
         timed = [t for t in timed if t[0] < by_name[dom_name][0] * a.steps]
         n_ps = len(per_step)
         if n_ps == 0 or n_ps != by_name[dom_name][0] or seen != n_ps * a.steps:      # the model's launcher-name guess disagreed
-            timed, per_step, n_ps = [], [(0.0, 0.0)], 1                                 # with the dispatch: no roofline rather than a wrong one
+            timed, per_step, n_ps = [], [(0.0, 0.0, 0.0)], 1                            # with the dispatch: no roofline rather than a wrong one
         per_call = per_step
         byts = sum(per_step[i % n_ps][0] for i, _, _ in timed)
         flops = sum(per_step[i % n_ps][1] for i, _, _ in timed)
+        lines_b = sum(per_step[i % n_ps][2] for i, _, _ in timed)
         t_ms = max(sum(ms for _, ms, _ in timed), 1e-9)
         n_step = by_name[dom_name][0]
         if flops / max(byts, 1.0) < RIDGE:
@@ -329,11 +335,16 @@ def train_bench(a, dp, dev, B, S):
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
         roof.update({"traffic": None, "kernel": dom_name, "launches_per_step": n_step, "launches_timed": len(timed),
                      "avg_launch_us": round(t_ms / max(len(timed), 1) * 1e3, 2),
-                     "algorithmic_mb_per_launch": round(sum(b for b, _ in per_call) / max(len(per_call), 1) / 1e6, 2),
-                     "gflop_per_launch": round(sum(f for _, f in per_call) / max(len(per_call), 1) / 1e9, 2),
+                     "algorithmic_mb_per_launch": round(sum(c[0] for c in per_call) / max(len(per_call), 1) / 1e6, 2),
+                     "gflop_per_launch": round(sum(c[1] for c in per_call) / max(len(per_call), 1) / 1e9, 2),
                      "tflops": round(flops / (t_ms * 1e-3) / 1e12, 1),
                      "share_of_library_gpu_time": round(by_name[dom_name][1] / lib_ms, 3),
                      "ranking_ms_per_step": {n: round(v[1], 3) for n, v in ranking[:8]}})
+        if lines_b > byts:   # informative, never `frac`: the same launches priced in the 128-byte lines their channel prefixes touch
+            roof["line_granular"] = {"mb_per_launch": round(sum(c[2] for c in per_call) / max(len(per_call), 1) / 1e6, 2),
+                                     "GB/s": round(lines_b / (t_ms * 1e-3) / 1e9, 1), "frac": round(lines_b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "x / G rows are channel prefixes of 64k + 32 channels in half of the dense layers: a row ending in half a "
+                                             "128-byte line costs the whole line (profiles/r6_ubench_raggedrow.txt); `achieved` / `frac` stay algorithmic"}
         try:   # HBM bytes of this kernel from the committed PMC passes (same workload), else null
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f).get("%s@train_B%d_%d" % (dom_name, B, S))
