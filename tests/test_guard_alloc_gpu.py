@@ -15,6 +15,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 def _guard_lib(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc on this box: the guard allocator is built where it runs")
     so = str(tmp_path_factory.mktemp("guard") / "libguard_alloc.so")
     r = subprocess.run([HIPCC, "-O2", "-w", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "dbg", "guard_alloc.cpp")],
                        capture_output=True, text=True)
