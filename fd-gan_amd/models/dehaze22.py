@@ -422,14 +422,12 @@ class _UNet(_PlannedModule):
 
     def forward(self, x):
         if _wants_grad(self, x):
-            if x.requires_grad:
-                raise NotImplementedError("models.dehaze22.%s: the gradient w.r.t. the input image is not produced on the HIP path" % type(self).__name__)
             return _apply_plan_function(self, x)
         return self._run(x)
 
     def _autograd_forward(self, x):
         out = self._run(x)
-        return out, (self._plan_for(x), out)
+        return out, (self._plan_for(x), out, bool(x.requires_grad))
 
     def _autograd_backward(self, state, dout):
         """torch.autograd through dehaze22.py:205-362 / :364-488 (train mode): the plan walked in reverse -- every transposed conv as
@@ -438,7 +436,7 @@ class _UNet(_PlannedModule):
         head on csrc/legacy_bwd.hip."""
         if not self.training:
             raise NotImplementedError("%s backward is built for train-mode BatchNorm" % type(self).__name__)
-        P, out = state
+        P, out, need_dx = state
         B = _plan_backward(P)
         B.zero_()
         grads = {}
@@ -446,7 +444,14 @@ class _UNet(_PlannedModule):
         B.run(grads, skip_dx_of={P.xin.data_ptr()})
         self._derived_grads(P, grads)
         self._table_grads(P, grads)
-        return None, grads
+        dx = None
+        if need_dx:      # round 6: the gradient w.r.t. the input image, as models.dehaze22.D forms it -- layer1 reads the raw image (no
+            # prologue), so it is the 4x4 stride-2 conv's data gradient of layer1's output gradient, on the any-stride direct kernel
+            n, h, w, _ = P.xin.shape          # NHWC
+            y1 = E.View(P.cat[1], self.cd[2], self.ce[0])
+            dx = torch.empty((n, self.input_nc, h, w), dtype=torch.float32, device=out.device)
+            E.conv_bwd_data_direct(B.G(y1).fd, self.layer1.layer1.weight.detach().contiguous(), E.conv_desc(4, 2, 1, cout=self.ce[0]), dx)
+        return dx, grads
 
 
 class G(_UNet):
