@@ -647,20 +647,18 @@ class _DenseBase(_PlannedModule):
 
     def forward(self, x):
         if _wants_grad(self, x):
-            if x.requires_grad:
-                raise NotImplementedError("models.%s: the gradient w.r.t. the input image is not produced on the HIP path" % type(self).__name__)
             return _apply_plan_function(self, x)
         return self._forward_plan(x)[1]
 
     def _autograd_forward(self, x):
         P, out = self._forward_plan(x)
-        return out, (P, out)
+        return out, (P, out, bool(x.requires_grad))
 
     def _autograd_backward(self, state, dout):
         """torch.autograd through dehaze1113.py:431-570 / :572-699 (dehaze22.py:531-660), train- or eval-mode BatchNorm: the recorded plan
         walked in reverse (fdgan_hip/backward.py) -- the encoder's and decoder's dense blocks on the generator's own backward
         kernels, the stem's MaxPool2d(3, 2, 1) and the four-scale head on csrc/legacy_bwd.hip."""
-        P, out = state
+        P, out, need_dx = state
         B = _plan_backward(P)
         B.zero_()
         n, _, h, w = out.shape
@@ -672,7 +670,16 @@ class _DenseBase(_PlannedModule):
         grads = {}
         B.run(grads, skip_dx_of={P.xs.data_ptr()})
         self._derived_grads(P, grads)
-        return None, grads
+        dx = None
+        if need_dx:
+            # round 6: the input image has two readers -- conv0 (7x7 stride 2, pad 3: here on the space-to-depth copy, so its data
+            # gradient is taken with the parameter's own 7x7 filter on the any-stride direct kernel) and the concatenation in front
+            # of conv_refin (:552 / :681), whose gradient the walk left in channels 16..18 of cat8's buffer
+            rec0 = next(r for r in P.records if r["kind"] == "conv" and r["x"].buf is P.xs)
+            dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=out.device)
+            E.conv_bwd_data_direct(B.G(rec0["y"]).fd, self.conv0.weight.detach().contiguous(), E.conv_desc(7, 2, 3, cout=64), dx)
+            dx += B.G(E.View(P.cat8, 16, 3)).torch_nchw()
+        return dx, grads
 
     def _derived_grads(self, P, grads):
         """Gradients of the filters the plan derives from parameters, mapped back to those parameters."""

@@ -1767,8 +1767,7 @@ def test_legacy_dense_matches_oracle_and_golden(golden_dir, nm, mod, cls, tail):
                 rep["running_mean_" + bn] = float((after[bn + ".running_mean"] - sdm[bn + ".running_mean"]).abs().max())
                 rep["running_var_" + bn] = rel_rms(after[bn + ".running_var"], sdm[bn + ".running_var"])
                 assert int(after[bn + ".num_batches_tracked"]) == 1, bn
-    with pytest.raises(NotImplementedError):
-        net(x.to(DEV).requires_grad_(True))
+    assert net(x.to(DEV).requires_grad_(True)).requires_grad      # the input image's gradient: test_legacy_dense_backward
     _report("legacy_" + nm, rep)
     assert rep["eval_psnr_vs_oracle"] > 35.0 and rep["train_psnr_vs_oracle"] > 35.0, rep
     assert max(v for k, v in rep.items() if k.startswith("running_")) < 2e-2, rep
@@ -1900,8 +1899,30 @@ def test_legacy_dense_backward(nm, mod, cls, tail):
     assert summary["parameters"] > 300 and summary["ops_checked"] > 100, summary
     assert summary["op_dw_worst"] < 5e-3 and summary["op_dx_worst"] < 3e-2, summary      # dx: 2.4 % on a 2 x 3-pixel BatchNorm'd op (12 values per channel)
     _assert_legacy_grads(summary)
-    with pytest.raises(NotImplementedError):
-        net(x.to(DEV).requires_grad_(True))
+    # round 6: the gradient w.r.t. the input image -- conv0's 7x7 stride-2 data gradient plus the gradient of the concatenation in
+    # front of conv_refin.  As for the U-Nets the op is checked on the walk's own operands (this fixture puts a BatchNorm over 12
+    # values: an input gradient cannot be compared with the fp32 oracle's), and the parameters' gradients must not move.
+    from fdgan_hip import engine as E
+    net.zero_grad()
+    (net(x.to(DEV)) * cot.to(DEV)).sum().backward()
+    before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    xg = x.to(DEV).requires_grad_(True)
+    net.zero_grad()
+    (net(xg) * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    P = net._plan_for(xg)
+    Bw = _plan_backward(P)
+    rec0 = next(r for r in P.records if r["kind"] == "conv" and r["x"].buf is P.xs)
+    dx_ref = torch.nn.functional.conv_transpose2d(Bw.G(rec0["y"]).torch_nchw().double(), net.conv0.weight.detach().half().double(),
+                                                  stride=2, padding=3, output_padding=1)
+    dx_ref = dx_ref + Bw.G(E.View(P.cat8, 16, 3)).torch_nchw().double()
+    assert xg.grad is not None and xg.grad.shape == x.shape and bool(torch.isfinite(xg.grad).all())
+    summary["input_gradient_vs_operands"] = rel_rms(xg.grad.double().cpu(), dx_ref.cpu())
+    summary["input_gradient_abs_mean"] = float(xg.grad.abs().mean())
+    _report("legacy_%s_backward" % nm, summary)
+    assert summary["input_gradient_vs_operands"] < 1e-5 and summary["input_gradient_abs_mean"] > 0, summary
+    for k, g in before.items():
+        assert torch.equal(dict(net.named_parameters())[k].grad, g), k
 
 
 @pytest.mark.parametrize("nm,mod,cls,tail", [("dense1113", "dehaze1113", "Dense", "bn"), ("dense22", "dehaze22", "Dense", "pyramid")])
@@ -1934,10 +1955,12 @@ def test_legacy_dense_backward_wellconditioned(nm, mod, cls, tail):
     x = det_input(shape, seed=33)
     cot = det_input(shape, seed=7, lo=-1.0, hi=1.0)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    ref = _functional_grads(lambda sdg: legacy_ref.dense_forward(sdg, x.clone(), True, tail), sd, x, cot)
+    xr, xe = x.clone().requires_grad_(True), x.clone().requires_grad_(True)      # round 6: the input image's gradient too
+    ref = _functional_grads(lambda sdg: legacy_ref.dense_forward(sdg, xr.clone(), True, tail), sd, x, cot)
     with emulated_functional_convs(legacy_ref):
-        emu = _functional_grads(lambda sdg: legacy_ref.dense_forward(sdg, x.clone(), True, tail), sd, x, cot)
-    (net(x.to(DEV)) * cot.to(DEV)).sum().backward()
+        emu = _functional_grads(lambda sdg: legacy_ref.dense_forward(sdg, xe.clone(), True, tail), sd, x, cot)
+    xg = x.to(DEV).requires_grad_(True)
+    (net(xg) * cot.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     rep, norms = _legacy_grad_report(net, ref)
     big = [k for k in rep if norms[k] > 1e-3 * max(norms.values())]                 # analytically-zero gradients excluded
@@ -1949,11 +1972,14 @@ def test_legacy_dense_backward_wellconditioned(nm, mod, cls, tail):
     cos = dot / (sum(float(params[k].grad.norm()) ** 2 for k in rep) ** 0.5 * sum(norms[k] ** 2 for k in rep) ** 0.5)
     bad = [(k, rep[k], d_emu[k]) for k in big if rep[k] > 3.0 * max(d_emu[k], med_e)]
     summary = {"compared": len(big), "hip_median": med_h, "emulated_median": med_e, "hip_p90": p90_h, "emulated_p90": p90_e, "cosine": cos,
-               "worst": sorted(((rep[k], d_emu[k], k) for k in big), reverse=True)[:5], "outliers": bad[:8]}
+               "worst": sorted(((rep[k], d_emu[k], k) for k in big), reverse=True)[:5], "outliers": bad[:8],
+               "input_gradient_hip": rel_rms(xg.grad.cpu(), xr.grad), "input_gradient_emulated": rel_rms(xe.grad, xr.grad)}
     _report("legacy_%s_backward_wellcond" % nm, summary)
     assert len(big) > 100 and cos > 0.999, summary
     assert med_h < 1.75 * med_e and p90_h < 1.75 * p90_e, summary
     assert not bad, summary
+    # the input image's gradient: the deepest one of the walk, held to the same yardstick as a parameter
+    assert summary["input_gradient_hip"] < 1.75 * max(summary["input_gradient_emulated"], med_e), summary
 
 
 def test_legacy_backward_kernels_match_autograd():
