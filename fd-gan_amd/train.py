@@ -70,7 +70,9 @@ class TrainStep:
         # Only parameters that can receive a gradient go into the optimizer: FDGAN registers 2.2 M that never do
         # (conv0, dense_block31, dense_norm31, the dy blocks' bn1 / bn2 -- SURVEY 8e).  One dry forward + backward
         # at a tiny size finds them.
+        self._init_trace("networks on the device")
         self.g_params = self._params_with_grad(self.netG, device)
+        self._init_trace("probe forward + backward done, plans released")
         self.optG = FlatAdam(self.g_params, lr=lrG, betas=(beta1, 0.999))
         self.optD = FlatAdam(list(self.netD.parameters()), lr=lrD, betas=(beta1, 0.999))
         self.pool = misc.ImagePool(pool_size)
@@ -85,8 +87,20 @@ class TrainStep:
         # round-4 placement).  Also measured and NOT adopted: the whole step on a high-priority stream so that the side streams only
         # fill idle CUs (+0.55 ms), the weight-gradient stream at high priority (46 ms: it starves the chain).
         self.d_fake_side = os.environ.get("FDGAN_D_FAKE_MAIN") is None
+        self._init_trace("optimizers built")
         if dp is not None and dp.world > 1:
             self.sync_replicas()
+
+    @staticmethod
+    def _init_trace(what):
+        """FDGAN_DEBUG_INIT_TRACE=1 (tools/ranks8_loop.sh): drain the device and say on stderr how far this rank's start-up got -- the
+        last line of a rank that dies names the phase whose GPU work raised the abort (profiles/r6_oversubscription.txt)."""
+        if os.environ.get("FDGAN_DEBUG_INIT_TRACE"):
+            import sys
+            import time
+            torch.cuda.synchronize()
+            sys.stderr.write("[init-trace rank %s %.3f] %s\n" % (os.environ.get("RANK", "0"), time.time() % 1000.0, what))
+            sys.stderr.flush()
 
     def sync_replicas(self):
         """Data-parallel replicas must START identical: only gradients are exchanged afterwards.  Rank 0's parameters
@@ -96,12 +110,19 @@ class TrainStep:
         bufs += [b for m in (self.netG, self.netD) for b in m.buffers() if b.dtype.is_floating_point]
         bufs += [p.data for p in self.netG.parameters() if not any(p is q for q in self.optG.params)]   # never-trained tensors
         bufs += [p.data for p in self.vgg.parameters()]                                                  # frozen, but must agree
+        self._init_trace("sync_replicas: %d tensors to broadcast" % len(bufs))
         for b in bufs:
             dist.broadcast(b, src=0)
-        chk = torch.stack([b.double().sum() for b in bufs[:2]])
+        self._init_trace("broadcasts done")
+        # the checksums are formed on the HOST (60 MB once): with eight processes sharing one GPU (the tests' dry run) PyTorch's fp64
+        # convert / reduce kernels, first used right here on a drained device, lost a rank to an illegal-instruction queue abort in
+        # 3 of ~90 launches (profiles/r6_oversubscription.txt: FDGAN_DEBUG_INIT_TRACE pins the window)
+        chk = torch.stack([b.detach().cpu().double().sum() for b in bufs[:2]]).to(bufs[0].device)
         lo, hi = chk.clone(), chk.clone()
+        self._init_trace("checksums computed")
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        self._init_trace("checksums reduced")
         if not torch.equal(lo, hi):
             raise RuntimeError("data-parallel replicas differ after the initial broadcast")
 

@@ -165,8 +165,9 @@ def test_bench_py_plain_python_launches_its_own_ranks(gpus):
         # driver never does it) about one launch in 30 loses a rank to an illegal-instruction queue abort while the replicas are
         # being synchronised: every launch of this library in the dying rank had completed (the gloo broadcasts in front of that
         # point synchronise the stream), only PyTorch's checksum kernels / gloo's copies were in flight, and 14 000 steady-state
-        # iterations + 320 process start-ups of this library's kernels alone under the same oversubscription lost none.  One
-        # retry, recorded; a second abort fails the test.
+        # iterations + 320 process start-ups of this library's kernels alone under the same oversubscription lost none.  Start-up
+        # markers pinned it to PyTorch's fp64 checksum kernels on a drained device; those checksums are formed on the host since
+        # (30 of 30 launches clean).  One retry stays, recorded; a second abort fails the test.
         try:
             with open(os.path.join(root, "gpurun_out", "bench_ranks%d_startup_abort.txt" % gpus), "w") as f:
                 f.write(out.stderr)
