@@ -598,9 +598,9 @@ class dehaze(_PlannedModule):
         if _wants_grad(self, x):
             # autograd composes the three pieces: the two sub-networks are planned modules with their own reverse walks, the tail
             # (scattering model + refinement) is one more autograd.Function; `tran` is returned as the sub-network produced it
-            if x.requires_grad:
-                raise NotImplementedError("models.dehaze22.dehaze: the gradient w.r.t. the input image is not produced on the HIP path")
-            xf = x.detach().float().contiguous()
+            # an input image that requires grad (round 6) stays in the graph: both sub-networks return its gradient through their
+            # own reverse walks, the tail returns the scattering model's and the refinement's (`_tail_backward`), autograd adds them
+            xf = x.float().contiguous() if x.requires_grad else x.detach().float().contiguous()
             tran = self.tran_dense(xf)
             atp_raw = self.atp_est(xf)
             params = tuple(p for nm, p in self.named_parameters() if p.requires_grad and not nm.startswith(("tran_dense.", "atp_est.", "tran_est.")))
@@ -631,8 +631,10 @@ class dehaze(_PlannedModule):
             P.launch()
             return P, (P.out.clone(), tran, atp, dehaze2)
 
-    def _tail_backward(self, P, xf, tran, atp_raw, out, g_out, g_atp, g_dehaze2):
-        """Reverse of `_tail`: the refinement plan walked in reverse, then the scattering model (csrc/legacy_bwd.hip)."""
+    def _tail_backward(self, P, xf, tran, atp_raw, out, g_out, g_atp, g_dehaze2, need_dx=False):
+        """Reverse of `_tail`: the refinement plan walked in reverse, then the scattering model (csrc/legacy_bwd.hip).  need_dx: also the
+        tail's own gradient w.r.t. the image -- dJ/dI = 1 / (|t| + eps) on J's total gradient, plus the image's copy in the
+        refinement's input [J | x] (three-channel elementwise glue on the gradient buffer the walk left)."""
         B = _plan_backward(P)
         B.zero_()
         n, c, h, w = out.shape
@@ -645,7 +647,11 @@ class dehaze(_PlannedModule):
         B.run(grads)
         _permuted_final_grad(P, grads, self.refine3)
         d_tran, d_atp = E.scatter_dehaze_bwd(xf, tran, atp_raw, P.wmean, 0.2, 1e-10, g_dehaze2, g_atp, B.G(E.View(P.cat6)))
-        return d_tran, d_atp, grads
+        if not need_dx:
+            return d_tran, d_atp, grads
+        gcat = B.G(E.View(P.cat6, 0, 6)).torch_nchw()
+        d_x = (gcat[:, :3] + g_dehaze2) / (tran.abs() + 1e-10) + gcat[:, 3:]
+        return d_tran, d_atp, grads, d_x.contiguous()
 
 
 class _DehazeTail(torch.autograd.Function):
@@ -654,6 +660,8 @@ class _DehazeTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, xf, tran, atp_raw, *params):
         tran_c, atp_c = tran.detach().contiguous(), atp_raw.detach().contiguous()
+        ctx.need_dx = bool(xf.requires_grad)
+        xf = xf.detach()
         P, (out, _, atp, dehaze2) = module._tail(xf, tran_c, atp_c)
         ctx.module, ctx.plan, ctx.params = module, P, params
         ctx.gen = _bump_generation(P)
@@ -665,5 +673,6 @@ class _DehazeTail(torch.autograd.Function):
         _check_generation(ctx.plan, ctx.gen)
         xf, tran, atp_raw, out = ctx.saved_tensors
         f = lambda g: g.detach().float().contiguous()
-        d_tran, d_atp, grads = ctx.module._tail_backward(ctx.plan, xf, tran, atp_raw, out, f(g_out), f(g_atp), f(g_dehaze2))
-        return (None, None, d_tran, d_atp) + autograd_grads(grads, ctx.params)
+        res = ctx.module._tail_backward(ctx.plan, xf, tran, atp_raw, out, f(g_out), f(g_atp), f(g_dehaze2), ctx.need_dx)
+        d_tran, d_atp, grads = res[:3]
+        return (None, res[3] if ctx.need_dx else None, d_tran, d_atp) + autograd_grads(grads, ctx.params)
