@@ -366,6 +366,13 @@ class _UNet(_PlannedModule):
             for nm in ("gamma", "beta"):
                 t[nm].requires_grad_(True)
             pro._meta.update(bn=_BnTable(t["gamma"], t["beta"]), batch_stats=True, identity=ident)
+        elif self.__dict__.get("_plan_keep", False):
+            # eval mode under autograd (round 6): every entry is a constant -- running statistics, or the identity (mean 0, var 1 - eps,
+            # gamma 1, beta 0) where a half has no norm -- so the backward is dx = gamma * rstd * dpre with dgamma / dbeta formed as
+            # always (backward.py: _constant_entries); the identity entries' dgamma / dbeta belong to no module (`_table_grads`)
+            for nm in ("gamma", "beta"):
+                t[nm].requires_grad_(True)
+            pro._meta.update(bn=_BnTable(t["gamma"], t["beta"]), batch_stats=False, identity=())
         return pro
 
     def _table_grads(self, P, grads):
@@ -376,7 +383,7 @@ class _UNet(_PlannedModule):
             if dg is None:
                 continue
             halves = []
-            if k + 1 <= 5:                           # left half: the decoder norm of dlayer k+1 (no dropout there)
+            if k + 1 <= (5 if self.training else 7):  # left half: the decoder norm of dlayer k+1 (train mode: no dropout there; eval: 2..7)
                 halves.append((getattr(self, "dlayer%d" % (k + 1))[0].bn, 0, cl))
             if k >= 2:                               # right half: the encoder norm of layer k
                 halves.append((getattr(self, "layer%d" % k)[0].bn, cl, cl + self.ce[k - 1]))
@@ -430,12 +437,11 @@ class _UNet(_PlannedModule):
         return out, (self._plan_for(x), out, bool(x.requires_grad))
 
     def _autograd_backward(self, state, dout):
-        """torch.autograd through dehaze22.py:205-362 / :364-488 (train mode): the plan walked in reverse -- every transposed conv as
+        """torch.autograd through dehaze22.py:205-362 / :364-488 (train mode; eval mode -- running statistics as constants, no dropout --
+        since round 6): the plan walked in reverse -- every transposed conv as
         its four parity convolutions (their filter gradients gathered back into the (cin, cout, 4, 4) parameter), the side-by-side
         BatchNorm tables' dgamma / dbeta handed to the two modules each table was built from, BatchNorm + Dropout2d and the pooling
         head on csrc/legacy_bwd.hip."""
-        if not self.training:
-            raise NotImplementedError("%s backward is built for train-mode BatchNorm" % type(self).__name__)
         P, out, need_dx = state
         B = _plan_backward(P)
         B.zero_()

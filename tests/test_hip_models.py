@@ -2152,6 +2152,61 @@ def test_legacy_unets_backward(kind):
         assert torch.equal(dict(net.named_parameters())[k].grad, g), k
 
 
+@pytest.mark.parametrize("kind", ["G", "G2"])
+def test_legacy_unets_backward_eval_mode(kind):
+    """Round 6 (the last `NotImplementedError` of the legacy networks' reverse mode): `.eval()` U-Nets under autograd -- fine-tuning with
+    frozen statistics, which torch.autograd supports for the reference's modules (dehaze22.py:205-362, :364-488) although its scripts
+    never do it.  Every entry of the side-by-side norm tables is then a constant (running statistics, or the identity where a half
+    has no norm) and there is no dropout: dx = gamma * rstd * dpre, dgamma / dbeta as always, handed to dlayer 2..7's and layer
+    2..8's modules.  Every parameter and the input image against torch.autograd over the fp32 oracle in eval mode: without batch
+    statistics over a handful of values the whole gradient points the oracle's way (cosine 0.9990 / 0.9998; train mode: > 0.8), and
+    the per-parameter distances (median 5 %: sixteen layers of bf16 gradients) are held to the oracle run with the kernels'
+    rounding (hiputil.emulated_functional_convs), as in test_legacy_dense_backward_wellconditioned."""
+    import models.dehaze22 as net22
+    from oracle import legacy_ref
+    from oracle.detweights import det_input, fill_state_dict
+    net = getattr(net22, kind)(3, 3, 8)
+    fill_state_dict(net, seed=5)
+    if kind == "G":
+        with torch.no_grad():
+            net.dlayerfinal.dlayer1.conv.weight.mul_(0.3)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV).eval()
+    x = det_input((2, 3, 256, 256), seed=21)
+    cot = det_input((2, 3, 256, 256), seed=7, lo=-1.0, hi=1.0)
+    xr = x.clone().requires_grad_(True)
+    ref = _functional_grads(lambda sdg: legacy_ref.unet_forward(sdg, xr.clone(), False, kind)[0], sd, x, cot)
+    from hiputil import emulated_functional_convs
+    xe = x.clone().requires_grad_(True)
+    with emulated_functional_convs(legacy_ref):
+        emu = _functional_grads(lambda sdg: legacy_ref.unet_forward(sdg, xe.clone(), False, kind)[0], sd, x, cot)
+    xg = x.to(DEV).requires_grad_(True)
+    y = net(xg)
+    assert y.requires_grad and y.shape == (2, 3, 256, 256)
+    (y * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    rep, norms = _legacy_grad_report(net, ref)
+    names = [k for k in rep if norms[k] > 1e-3 * max(norms.values())]
+    big = sorted(rep[k] for k in names)
+    d_emu = {k: rel_rms(emu[k], ref[k]) for k in names}
+    ev = sorted(d_emu.values())
+    params = dict(net.named_parameters())
+    dot = sum(float((params[k].grad.cpu() * ref[k]).sum()) for k in rep)
+    cos = dot / (sum(float(params[k].grad.norm()) ** 2 for k in rep) ** 0.5 * sum(norms[k] ** 2 for k in rep) ** 0.5)
+    summary = {"compared": len(big), "median": big[len(big) // 2], "p90": big[len(big) * 9 // 10], "worst": big[-1], "cosine": cos,
+               "emulated_median": ev[len(ev) // 2], "emulated_p90": ev[len(ev) * 9 // 10], "emulated_worst": ev[-1],
+               "worst_names": sorted(((rep[k], d_emu[k], k) for k in names), reverse=True)[:4],
+               "outliers": [(k, rep[k], d_emu[k]) for k in names if rep[k] > 3.0 * max(d_emu[k], ev[len(ev) // 2])][:8],
+               "input_gradient_vs_oracle": rel_rms(xg.grad.cpu(), xr.grad), "input_gradient_emulated": rel_rms(xe.grad, xr.grad),
+               "running_stats_untouched": all(int(m.num_batches_tracked) == int(sd[n + ".num_batches_tracked"])
+                                              for n, m in net.named_modules() if isinstance(m, torch.nn.BatchNorm2d))}
+    _report("legacy_%s_backward_eval" % kind, summary)
+    assert summary["running_stats_untouched"] and summary["compared"] >= 30, summary
+    assert summary["cosine"] > 0.998, summary
+    assert summary["median"] < 1.75 * summary["emulated_median"] and summary["p90"] < 1.75 * summary["emulated_p90"] and not summary["outliers"], summary
+    assert summary["input_gradient_vs_oracle"] < 1.75 * max(summary["input_gradient_emulated"], summary["emulated_median"]), summary
+
+
 def test_legacy_dehaze_backward(golden_dir):
     """SURVEY 8f rank 4, reverse mode: `dehaze` (dehaze22.py:662-753) under autograd -- Dense and G2 as planned modules with their own
     reverse walks, the scattering model J = (I - A) / (|t| + eps) + A and the refinement tail as one more autograd.Function -- with a
