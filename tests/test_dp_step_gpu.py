@@ -167,7 +167,7 @@ def test_bench_py_plain_python_launches_its_own_ranks(gpus):
         # point synchronise the stream), only PyTorch's checksum kernels / gloo's copies were in flight, and 14 000 steady-state
         # iterations + 320 process start-ups of this library's kernels alone under the same oversubscription lost none.  Start-up
         # markers pinned it to PyTorch's fp64 checksum kernels on a drained device; those checksums are formed on the host since
-        # (30 of 30 launches clean).  One retry stays, recorded; a second abort fails the test.
+        # (64 of 64 launches clean).  One retry stays, recorded; a second abort fails the test.
         try:
             with open(os.path.join(root, "gpurun_out", "bench_ranks%d_startup_abort.txt" % gpus), "w") as f:
                 f.write(out.stderr)
