@@ -189,3 +189,39 @@ def test_stem_filter_and_its_gradient_map():
         for dx in range(2):
             g8[:, :, dy::2, dx::2] = d4[:, dy * 2 + dx:12:4]
     assert abs(float((w4 * d4).sum()) - float((w7 * g8[:, :, 1:, 1:]).sum())) < 1e-4 * max(1.0, abs(float((w4 * d4).sum())))
+
+
+@pytest.mark.parametrize("kind", ["G", "G2"])
+def test_unet_table_gradients_reach_their_modules(kind):
+    """models/dehaze22.py `_UNet._table_grads` (host logic, no GPU): the dgamma / dbeta of a concat buffer's side-by-side norm table go to
+    the two BatchNorm modules the table was built from -- left half dlayer k+1's norm, right half layer k's.  Train mode: dlayer 6 / 7
+    are dropout levels whose norm is applied (and differentiated) by the bn_dropout record, so their table entries are identities and
+    must NOT receive a table gradient; eval mode (round 6): no dropout, all of dlayer 2..7's norms are table entries.  dlayer8 and
+    layer1 have no norm in either mode."""
+    import types
+    import models.dehaze22 as net22
+    net = getattr(net22, kind)(3, 3, 8)
+    cd, ce = net.cd, net.ce
+    for training in (True, False):
+        net.train(training)
+        tab = {k: dict(gamma=torch.zeros(cd[k + 1] + ce[k - 1]), beta=torch.zeros(cd[k + 1] + ce[k - 1])) for k in range(1, 8)}
+        grads = {}
+        for k in range(1, 8):
+            grads[tab[k]["gamma"]] = torch.full((cd[k + 1] + ce[k - 1],), float(k))
+            grads[tab[k]["beta"]] = torch.full((cd[k + 1] + ce[k - 1],), float(-k))
+        net._table_grads(types.SimpleNamespace(tab=tab), grads)
+        assert all(t["gamma"] not in grads and t["beta"] not in grads for t in tab.values())      # the table leaves are consumed
+        got = {id(p): g for p, g in grads.items()}
+        for j in range(2, 9):                 # encoder norm of layer j: right half of table j (j <= 7); layer8's norm is not in a table
+            bn = getattr(net, "layer%d" % j)[0].bn
+            if j <= 7:
+                assert torch.equal(got[id(bn.weight)], torch.full((ce[j - 1],), float(j))) and torch.equal(got[id(bn.bias)], torch.full((ce[j - 1],), float(-j)))
+            else:
+                assert id(bn.weight) not in got
+        for j in range(2, 8):                 # decoder norm of dlayer j: left half of table j - 1
+            bn = getattr(net, "dlayer%d" % j)[0].bn
+            if j <= 5 or not training:
+                assert torch.equal(got[id(bn.weight)], torch.full((cd[j],), float(j - 1))), (training, j)
+                assert torch.equal(got[id(bn.bias)], torch.full((cd[j],), float(1 - j))), (training, j)
+            else:
+                assert id(bn.weight) not in got and id(bn.bias) not in got, (training, j)
