@@ -455,13 +455,15 @@ class FDGAN(_PlannedModule):
     def _autograd_forward(self, x):
         P = self._plan_for(x)
         out = self._forward_plan(P, x)
-        return out, (P, out)
+        return out, (P, out, bool(x.requires_grad))
 
     def _autograd_backward(self, state, dout):
         """Gradients of every parameter that receives one (11.8 M of 13.98 M; conv0, dense_block31, dense_norm31
-        and the dy blocks' bn1/bn2 never do).  The gradient w.r.t. the input image is not produced
-        (returns None): the generator's input is data."""
-        P, out = state      # train- or eval-mode BatchNorm (eval: running statistics are constants, backward.py:_constant_entries)
+        and the dy blocks' bn1/bn2 never do).  The generator's input is data and its gradient is normally not
+        formed (the walk skips conv_refin1's data gradient); an input that requires grad gets it (round 6: until then the
+        request was silently answered with None) -- the image's one reader is conv_refin1, whose data gradient the walk then
+        leaves in the input buffer's gradient."""
+        P, out, need_dx = state      # train- or eval-mode BatchNorm (eval: running statistics are constants, backward.py:_constant_entries)
         B = _plan_backward(P)
         B.zero_()
         n, _, h, w = out.shape
@@ -469,8 +471,12 @@ class FDGAN(_PlannedModule):
         E.out_act_bwd(dout, out, L.ACT_TANH, E.View(g8))                          # dehaze = tanh(conv_refin3(x6)) (:799)
         grads = {}
         last = B.persistent("last", lambda: dict(x=E.View(P.x6), w=P.w_last, k=3, pad=1, stride=1, bias=self.conv_refin3.bias, pro=None))
-        B.run(grads, skip_dx_of={P.in8.data_ptr()}, head=(last, E.View(g8, 0, 3)))
-        return None, grads
+        B.run(grads, skip_dx_of=() if need_dx else {P.in8.data_ptr()}, head=(last, E.View(g8, 0, 3)))
+        dx = None
+        if need_dx:
+            dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=out.device)
+            E.to_nchw(B.G(E.View(P.in8, 0, 3)), dx)
+        return dx, grads
 
     def _forward_plan(self, P, x):
         with torch.no_grad():

@@ -747,6 +747,48 @@ def _grad_report(hip_module, oracle_module):
     return rep
 
 
+def test_fdgan_input_gradient(nets):
+    """An input image that requires grad gets its gradient from the generator too (round 6; until then `x.grad` silently stayed None):
+    the image's one reader is conv_refin1 (dehaze1113.py:760), whose data gradient the reverse walk forms when asked.  Against
+    torch.autograd over the fp32 oracle, eval mode (well conditioned: running statistics) and train mode; the parameters' gradients
+    must be bitwise the ones of a walk that was not asked."""
+    net, ref = nets
+    from oracle.detweights import det_input, fill_state_dict
+    og = ref.FDGAN()
+    fill_state_dict(og, seed=3)
+    g = net.FDGAN()
+    g.load_state_dict(og.state_dict())
+    g = g.to(DEV)
+    x = det_input((2, 3, 64, 64), seed=12, lo=0.0, hi=1.0)
+    cot = det_input((2, 3, 64, 64), seed=13, lo=-1.0, hi=1.0)
+    rep = {}
+    for mode in ("eval", "train"):
+        g.train(mode == "train"), og.train(mode == "train")
+        sd0 = {k: v.clone() for k, v in og.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        og.zero_grad()
+        (og(xr.clone()) * cot).sum().backward()       # (the reference's first ReLU is in place: a clone keeps the leaf)
+        og.load_state_dict(sd0)                        # train mode moved the running statistics
+        g.load_state_dict(sd0)
+        g.zero_grad()
+        (g(x.to(DEV)) * cot.to(DEV)).sum().backward()
+        before = {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
+        g.load_state_dict(sd0)
+        xg = x.to(DEV).requires_grad_(True)
+        g.zero_grad()
+        (g(xg) * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert xg.grad is not None and xg.grad.shape == x.shape and bool(torch.isfinite(xg.grad).all())
+        gx, gr = xg.grad.double().cpu(), xr.grad.double()
+        rep[mode] = {"rel_rms": rel_rms(gx, gr), "cosine": float((gx * gr).sum() / (gx.norm() * gr.norm())), "norm_ratio": float(gx.norm() / gr.norm())}
+        params = dict(g.named_parameters())
+        for k, v in before.items():
+            assert torch.equal(params[k].grad, v), (mode, k)
+    _report("fdgan_input_gradient", rep)
+    assert rep["eval"]["rel_rms"] < 0.1 and rep["eval"]["cosine"] > 0.995, rep
+    assert rep["train"]["cosine"] > 0.8 and abs(rep["train"]["norm_ratio"] - 1.0) < 0.1, rep
+
+
 def test_dy_blocks_backward(nets):
     """BottleneckBlockdy / TransitionBlockdy under autograd vs the bf16-emulating oracle (random cotangent)."""
     from hiputil import emulate_kernel_operands
